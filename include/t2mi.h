@@ -1,0 +1,155 @@
+/*
+ * t2mi.h -- C-ABI of libt2mi.so: the MI355X (gfx950) Tacotron2 mel-generation hot path.
+ *
+ * The reference (nii-yamagishilab/tacotron2) has no FFI layer of its own: its "operator API" for
+ * this path is the Python class protocol of tacotron/tacotron_v2.py, tacotron/rnn_wrappers.py and
+ * tacotron/helpers.py, executed by TensorFlow 1.x.  Each entry point below replaces the TensorFlow
+ * execution of the reference symbols it cites (paths relative to the reference root).  The Python
+ * package `tacotron2_amd` binds these with ctypes and mirrors the reference classes on top.
+ *
+ * Conventions
+ *  - every function returns T2_OK (0) or a negative T2_E* code and never throws across the ABI;
+ *    t2_last_error() returns a thread-local message for the last failure on this thread.
+ *  - "dev" pointers are HIP device pointers on the ctx's device (e.g. torch.Tensor.data_ptr());
+ *    "host" pointers are ordinary host memory.  The caller owns every I/O buffer; the library owns
+ *    weights and workspaces inside its handles.
+ *  - all floating point is IEEE fp32; ids / lengths are int64 (util/tfrecord.py:108-109).
+ *  - a handle is not thread-safe; use one ctx per GPU per thread.  All work is enqueued on the
+ *    ctx's stream; only t2_decode_free() synchronises (to return steps_out).
+ *  - batch size B <= T2_MAX_BATCH per call (one reference batch: the stop rule of
+ *    helpers.py:90-94 couples all rows of a batch, so a batch is never split internally).
+ */
+#ifndef T2MI_H
+#define T2MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2_ABI_VERSION 1
+#define T2_MAX_BATCH 64
+#define T2_MAX_PRENET_LAYERS 4
+
+#define T2_OK 0
+#define T2_EINVAL (-1)  /* bad argument / unsupported size  -> Python ValueError / AssertionError   */
+#define T2_ENOMEM (-2)  /* hipMalloc failed                                                          */
+#define T2_EHIP (-3)    /* a HIP runtime call failed (message in t2_last_error)                      */
+#define T2_ESTATE (-4)  /* call order violated (model not finalized, weight missing, ...)            */
+#define T2_ERANGE (-5)  /* embedding id outside [0, num_symbols): modules.py:65-66 assert ops        */
+
+typedef struct t2_ctx t2_ctx;
+typedef struct t2_model t2_model;
+typedef struct t2_state t2_state;
+
+/* Every dimension of the path is a runtime parameter.  Field meaning:
+ * hparams.py:14,23,27,28,50-52 and the constructor arguments of tacotron_v2.py:35-36,83-91,149-151,183. */
+typedef struct t2_dims {
+    int32_t num_symbols;          /* Embedding rows, hparams.py:23                                  */
+    int32_t embedding_dim;        /* Embedding width                                                */
+    int32_t enc_conv_layers;      /* EncoderV2 num_conv_layers                                      */
+    int32_t enc_kernel;           /* EncoderV2 kernel_size                                          */
+    int32_t enc_units;            /* EncoderV2 out_units (even; BiLSTM has enc_units/2 per dir)     */
+    int32_t num_prenet_layers;    /* len(prenets) of AttentionRNN, <= T2_MAX_PRENET_LAYERS          */
+    int32_t prenet_units[T2_MAX_PRENET_LAYERS];
+    int32_t attention_lstm_units; /* A: cell of AttentionRNN (ZoneoutLSTMCell)                      */
+    int32_t decoder_lstm_units;   /* D: DecoderRNNV2 out_units                                      */
+    int32_t attention_dim;        /* U: LocationSensitiveAttention num_units                        */
+    int32_t attention_filters;    /* F: hparams.py:51                                               */
+    int32_t attention_kernel;     /* K: hparams.py:50                                               */
+    int32_t cumulative_weights;   /* hparams.py:52                                                  */
+    int32_t num_mels;             /* M: hparams.py:14                                               */
+    int32_t outputs_per_step;     /* r: hparams.py:27                                               */
+    int32_t n_feed_frame;         /* nf <= r: hparams.py:28, helpers.py:55                          */
+    int32_t postnet_layers;       /* PostNetV2 num_postnet_layers                                   */
+    int32_t postnet_kernel;       /* PostNetV2 kernel_size                                          */
+    int32_t postnet_channels;     /* PostNetV2 out_channels                                         */
+    float zoneout_cell;           /* ZoneoutLSTMCell zoneout_factor_cell, modules.py:237            */
+    float zoneout_output;         /* ZoneoutLSTMCell zoneout_factor_output                          */
+    float bn_eps;                 /* tf.layers.batch_normalization epsilon (1e-3)                   */
+    float forget_bias;            /* tf.nn.rnn_cell.LSTMCell forget_bias (1.0)                      */
+} t2_dims;
+
+int t2_version(void);
+const char* t2_last_error(void);
+
+/* One context per GPU per thread.  hip_stream may be NULL (the library creates its own stream). */
+int t2_ctx_create(int device, void* hip_stream, t2_ctx** out);
+int t2_ctx_destroy(t2_ctx* ctx);
+int t2_ctx_synchronize(t2_ctx* ctx);
+
+/* Model = dims + named fp32 weights in TensorFlow layouts (Dense kernel [in,out]; LSTM kernel
+ * [in+h,4h], rows [inputs;h_prev], column blocks i|j|f|o; conv kernel [k,in,out]; BN vectors [C]).
+ * Variable names: tacotron2_amd/weights.py:weight_shapes.  Validation mirrors the reference's
+ * constructor checks: enc_units even (tacotron_v2.py:40), nf <= r (helpers.py:55), zoneout factors
+ * in [0,1] (modules.py:241-245) -> T2_EINVAL. */
+int t2_model_create(t2_ctx* ctx, const t2_dims* dims, t2_model** out);
+int t2_model_set_weight(t2_model* m, const char* name, const float* host_ptr, const int64_t* shape, int rank);
+int t2_model_finalize(t2_model* m); /* repack into kernel-native layouts and upload */
+int t2_model_destroy(t2_model* m);
+
+/* Embedding.call (modules.py:64-67) + EncoderV2.call (tacotron_v2.py:53-63), inference arithmetic.
+ * ids host int64 [B,T_in]; lens host int64 [B] or NULL (no sequence_length); memory_out dev fp32
+ * [B,T_in,enc_units].  T2_ERANGE if an id is outside [0,num_symbols). */
+int t2_encode(t2_model* m, const int64_t* ids, const int64_t* lens, int B, int T_in, float* memory_out);
+
+/* EncoderV2.call alone on a dev fp32 [B,T_in,embedding_dim] input (tacotron_v2.py:53-63). */
+int t2_encode_embedded(t2_model* m, const float* emb, const int64_t* lens, int B, int T_in, float* memory_out);
+
+/* PostNetV2.call (tacotron_v2.py:200-204): mel dev [B,T_out,M] -> mel_post dev [B,T_out,M]. */
+int t2_postnet(t2_model* m, const float* mel, int B, int T_out, float* mel_post);
+
+/* Decoder state = OutputAndStopTokenWrapper.zero_state (rnn_wrappers.py:99-100) of the cell stack
+ * OutputAndStopTokenWrapper(DecoderRNNV2(AttentionRNN(ZoneoutLSTMCell, prenets,
+ * LocationSensitiveAttention))) plus the attention mechanism's constructor side effects
+ * (tacotron_v2.py:95-101 -> BahdanauAttention: values = memory masked by lens, keys = values .
+ * memory_layer).  memory dev [B,T_in,enc_units]; lens host int64 [B] or NULL. */
+int t2_state_create(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in, t2_state** out);
+int t2_state_reset(t2_state* s);    /* back to zero_state, time = 0 */
+int t2_state_destroy(t2_state* s);
+/* Copy one state tensor to a dev buffer (row-major fp32).  names: "attention_c", "attention_h",
+ * "lstm1_c", "lstm1_h", "lstm2_c", "lstm2_h" ([B,units]), "attention" ([B,enc_units]),
+ * "alignments", "attention_state" ([B,T_in]), "keys" ([B,T_in,U]). */
+int t2_state_get(t2_state* s, const char* name, float* out);
+
+/* RNNCell.call parity: one OutputAndStopTokenWrapper.call (rnn_wrappers.py:105-109) =
+ * prenets (rnn_wrappers.py:51-53) -> AttentionWrapper step with LocationSensitiveAttention.__call__
+ * (tacotron_v2.py:118-141) -> concat (rnn_wrappers.py:76-78) -> 2 ZoneoutLSTM (tacotron_v2.py:155-161)
+ * -> mel / stop projections.  prev_frames dev [B, M*nf]; mel_r dev [B, M*r]; stop dev [B] (logit).
+ * The state is advanced in place. */
+int t2_decode_step(t2_model* m, t2_state* s, const float* prev_frames, float* mel_r, float* stop);
+
+/* dynamic_decode(BasicDecoder(cell, TrainingHelper | ValidationHelper, zero_state)) as wired by
+ * DecoderV1.call (tacotron_v1.py:134-152) for the V2 cell.  targets dev [B,T_out,M] (T_out % r == 0),
+ * S = T_out / r steps for every row (helpers.py:154-156, :105,:133).
+ * teacher_forcing != 0: next input = targets[:, t, -M*nf:] (helpers.py:182 / :134);
+ * teacher_forcing == 0: next input = own output[:, -M*nf:] (ValidationHelper, helpers.py:135-136).
+ * Outputs (dev): mel [B,T_out,M]; stop [B,S] (logits); align [S,B,T_in] (alignment_history.stack()). */
+int t2_decode_teacher(t2_model* m, const float* memory, const int64_t* lens, const float* targets,
+                      int B, int T_in, int T_out, int teacher_forcing,
+                      float* mel, float* stop, float* align);
+
+/* dynamic_decode(BasicDecoder(cell, StopTokenBasedInferenceHelper, zero_state), maximum_iterations)
+ * (tacotron_v1.py:143-150; helpers.py:83-94): free-running decode, finished when every row's stop
+ * logit is > 0 at a step with time > min_iters (batch-coupled), or at max_iters; the output of the
+ * finishing step is kept.  Output buffers (dev) are sized for max_iters steps:
+ * mel [B, max_iters*r, M]; stop [B, max_iters]; align [max_iters, B, T_in]; only the first
+ * *steps_out steps are written.  steps_out: host int. */
+int t2_decode_free(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
+                   int max_iters, int min_iters, float* mel, float* stop, float* align, int* steps_out);
+
+/* Same decode, split for callers that time or overlap it: _launch enqueues everything on the
+ * ctx stream without synchronising, _finish waits and returns the step count. */
+int t2_decode_free_launch(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
+                          int max_iters, int min_iters, float* mel, float* stop, float* align);
+int t2_decode_free_finish(t2_model* m, int* steps_out);
+
+/* Measurement hooks (no reference counterpart): HIP-event time of the last call's dominant
+ * kernel class on the ctx stream. */
+int t2_model_set_option(t2_model* m, const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2MI_H */

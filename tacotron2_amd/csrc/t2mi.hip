@@ -1,0 +1,1091 @@
+// libt2mi.so -- host side of the C-ABI declared in include/t2mi.h.
+// Weight repacking, workspaces, launch sequences (eager or hipGraph-chunked) for the kernels in
+// kernels.h.  No CPU fallback: every entry point runs HIP kernels or fails.
+#include "../../include/t2mi.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? T2_ENOMEM : T2_EHIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    } while (0)
+
+#define T2_TRY(expr)              \
+    do {                          \
+        int r_ = (expr);          \
+        if (r_ != T2_OK) return r_; \
+    } while (0)
+
+extern "C" int t2_version(void) { return T2_ABI_VERSION; }
+extern "C" const char* t2_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct t2_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+};
+
+struct HostWeight {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct Packed {            // skinny-GEMM operand
+    float* w = nullptr;    // [n_wg][kbtot][64][4]
+    float* bias = nullptr; // LSTM: [n_wg][16]; dense: [N]
+    int n_wg = 0, kbtot = 0, nseg = 0;
+    int seg_kb[T2_MAX_SEG] = {0, 0, 0};
+    int N = 0;             // LSTM: hidden units; dense: columns
+};
+
+struct ConvLayer {
+    float* w = nullptr;     // [k*cin][cout]
+    float* scale = nullptr; // [cout] or null
+    float* shift = nullptr; // [cout] or null
+    int k = 0, cin = 0, cout = 0;
+};
+
+struct t2_model {
+    t2_ctx* ctx = nullptr;
+    t2_dims d{};
+    std::map<std::string, HostWeight> hw;
+    bool finalized = false;
+    std::vector<void*> allocs;     // everything hipMalloc'ed for weights
+    // device weights
+    float* embedding = nullptr;
+    std::vector<ConvLayer> enc_convs, post_convs;
+    ConvLayer post_proj, memory_layer;
+    Packed enc_lstm[2];
+    Packed prenet[T2_MAX_PRENET_LAYERS];
+    Packed att_lstm, lstm1, lstm2, query, proj;
+    float *conv_w = nullptr, *conv_b = nullptr, *wloc = nullptr, *v_a = nullptr, *b_a = nullptr;
+    // cached workspaces
+    std::vector<t2_state*> states;      // decode states owned by the model (cache)
+    t2_state* pending = nullptr;        // free-run decode in flight
+    float* pend_mel = nullptr; float* pend_stop = nullptr; float* pend_align = nullptr;
+    void* enc_ws = nullptr; size_t enc_ws_bytes = 0;
+    void* post_ws = nullptr; size_t post_ws_bytes = 0;
+    int* h_ctl = nullptr;               // pinned host mirror of a ctl block
+    int opt_graph = 1;                  // use hipGraph chunks for decode loops
+    int opt_chunk = 16;                 // steps per graph
+};
+
+struct t2_state {
+    t2_model* m = nullptr;
+    int B = 0, T = 0, MB = 0, cap = 1;
+    bool owned_by_model = false;
+    void* slab = nullptr;        // zeroable state slab
+    size_t slab_bytes = 0;
+    void* fixed = nullptr;       // values, keys, lens
+    // fixed
+    float *values = nullptr, *keys = nullptr;
+    int* lens = nullptr;
+    // zeroable
+    float *att_state = nullptr, *alignments = nullptr, *ctx_frag = nullptr, *ctx_plain = nullptr, *q = nullptr;
+    float *c_att = nullptr, *c1 = nullptr, *c2 = nullptr;
+    float *h_att = nullptr, *h1 = nullptr, *h2 = nullptr;        // frag16 ping-pong (2x)
+    float *h_att_raw = nullptr, *y1_raw = nullptr, *y2_raw = nullptr;
+    float* xin = nullptr;                                        // prev frames frag16
+    float* xp[T2_MAX_PRENET_LAYERS] = {nullptr, nullptr, nullptr, nullptr};
+    int h_att_sz = 0, h1_sz = 0, h2_sz = 0;
+    int* ctl = nullptr;
+    // output staging (graph-stable addresses)
+    float *o_mel = nullptr, *o_stop = nullptr, *o_hist = nullptr, *i_targets = nullptr;
+    void* outbuf = nullptr;
+    // cached graphs: [mode] 0 = teacher forcing, 1 = feed own output (free / validation)
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    int gchunk[2] = {0, 0};
+};
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int pad16(int k) { return (k + 15) & ~15; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int dev_alloc(t2_model* m, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    m->allocs.push_back(*p);
+    return T2_OK;
+}
+
+static int upload(t2_model* m, float** dst, const std::vector<float>& v) {
+    T2_TRY(dev_alloc(m, (void**)dst, v.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return T2_OK;
+}
+
+static int get_w(t2_model* m, const std::string& name, const HostWeight** out, std::vector<int64_t> shape) {
+    auto it = m->hw.find(name);
+    if (it == m->hw.end()) return fail(T2_ESTATE, "weight '%s' was never set", name.c_str());
+    if (it->second.shape != shape) return fail(T2_EINVAL, "weight '%s' has the wrong shape", name.c_str());
+    *out = &it->second;
+    return T2_OK;
+}
+
+// Pack W (TF layout [rows][ncol_src]) for the skinny kernels.  segs = (first source row, rows) of each
+// K segment (each padded to a multiple of 16 with zero rows).  lstm_units > 0: workgroup g owns
+// hidden units 4g..4g+3, column c = gate*4 + u  <->  source column gate*H + 4g + u.
+// lstm_units == 0: workgroup g owns source columns 16g..16g+15.
+static int pack_skinny(t2_model* m, Packed* p, const float* W, int ncol_src, const std::vector<std::pair<int, int>>& segs,
+                       int lstm_units, int ncols, const float* bias) {
+    const bool lstm = lstm_units > 0;
+    p->N = lstm ? lstm_units : ncols;
+    p->n_wg = lstm ? ceil_div(lstm_units, 4) : ceil_div(ncols, 16);
+    p->nseg = (int)segs.size();
+    p->kbtot = 0;
+    for (int s = 0; s < p->nseg; ++s) {
+        p->seg_kb[s] = pad16(segs[s].second) / 16;
+        p->kbtot += p->seg_kb[s];
+    }
+    std::vector<float> out((size_t)p->n_wg * p->kbtot * 256, 0.f);
+    auto colmap = [&](int g, int c) -> int {
+        if (lstm) {
+            const int gate = c >> 2, u = 4 * g + (c & 3);
+            return u < lstm_units ? gate * lstm_units + u : -1;
+        }
+        const int col = 16 * g + c;
+        return col < ncols ? col : -1;
+    };
+    for (int g = 0; g < p->n_wg; ++g) {
+        int kb0 = 0;
+        for (int s = 0; s < p->nseg; ++s) {
+            for (int kbl = 0; kbl < p->seg_kb[s]; ++kbl)
+                for (int kg = 0; kg < 4; ++kg)
+                    for (int c = 0; c < 16; ++c) {
+                        const int col = colmap(g, c);
+                        if (col < 0) continue;
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = kbl * 16 + kg * 4 + j;
+                            if (k >= segs[s].second) continue;
+                            out[(((size_t)g * p->kbtot + kb0 + kbl) * 64 + kg * 16 + c) * 4 + j] =
+                                W[(size_t)(segs[s].first + k) * ncol_src + col];
+                        }
+                    }
+            kb0 += p->seg_kb[s];
+        }
+    }
+    T2_TRY(upload(m, &p->w, out));
+    if (bias != nullptr) {
+        if (lstm) {
+            std::vector<float> pb((size_t)p->n_wg * 16, 0.f);
+            for (int g = 0; g < p->n_wg; ++g)
+                for (int c = 0; c < 16; ++c) {
+                    const int col = colmap(g, c);
+                    if (col >= 0) pb[(size_t)g * 16 + c] = bias[col];
+                }
+            T2_TRY(upload(m, &p->bias, pb));
+        } else {
+            std::vector<float> pb(bias, bias + ncols);
+            T2_TRY(upload(m, &p->bias, pb));
+        }
+    }
+    return T2_OK;
+}
+
+static int make_conv(t2_model* m, ConvLayer* L, const std::string& prefix, int k, int cin, int cout, bool bn) {
+    const HostWeight* w;
+    T2_TRY(get_w(m, prefix + "/kernel", &w, {k, cin, cout}));
+    L->k = k; L->cin = cin; L->cout = cout;
+    T2_TRY(upload(m, &L->w, w->data));
+    if (bn) {
+        const HostWeight *g, *b, *mu, *var;
+        const std::string p = prefix + "/batch_normalization/";
+        T2_TRY(get_w(m, p + "gamma", &g, {cout}));
+        T2_TRY(get_w(m, p + "beta", &b, {cout}));
+        T2_TRY(get_w(m, p + "moving_mean", &mu, {cout}));
+        T2_TRY(get_w(m, p + "moving_variance", &var, {cout}));
+        std::vector<float> sc(cout), sh(cout);
+        for (int i = 0; i < cout; ++i) {
+            // inference batch norm folded to one affine: y = x*scale + shift
+            sc[i] = g->data[i] / sqrtf(var->data[i] + m->d.bn_eps);
+            sh[i] = b->data[i] - mu->data[i] * sc[i];
+        }
+        T2_TRY(upload(m, &L->scale, sc));
+        T2_TRY(upload(m, &L->shift, sh));
+    }
+    return T2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ctx / model
+// ------------------------------------------------------------------------------------------------
+extern "C" int t2_ctx_create(int device, void* hip_stream, t2_ctx** out) {
+    if (!out) return fail(T2_EINVAL, "out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(T2_EINVAL, "device %d out of range (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(T2_EHIP, "device %d is %s; libt2mi is built for gfx950 only", device, prop.gcnArchName);
+    t2_ctx* c = new t2_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(T2_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    *out = c;
+    return T2_OK;
+}
+
+extern "C" int t2_ctx_destroy(t2_ctx* c) {
+    if (!c) return T2_OK;
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return T2_OK;
+}
+
+extern "C" int t2_ctx_synchronize(t2_ctx* c) {
+    if (!c) return fail(T2_EINVAL, "ctx is null");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return T2_OK;
+}
+
+extern "C" int t2_model_create(t2_ctx* ctx, const t2_dims* d, t2_model** out) {
+    if (!ctx || !d || !out) return fail(T2_EINVAL, "null argument");
+    // same checks the reference constructors make
+    if (d->enc_units <= 0 || d->enc_units % 2 != 0) return fail(T2_EINVAL, "enc_units must be even (tacotron_v2.py:40)");
+    if (d->n_feed_frame < 1 || d->n_feed_frame > d->outputs_per_step) return fail(T2_EINVAL, "n_feed_frame <= r required (helpers.py:55)");
+    const float zm = std::min(d->zoneout_cell, d->zoneout_output), zs = std::max(d->zoneout_cell, d->zoneout_output);
+    if (zm < 0.f || zs > 1.f) return fail(T2_EINVAL, "One/both provided Zoneout factors are not in [0, 1]");
+    if (d->num_prenet_layers < 1 || d->num_prenet_layers > T2_MAX_PRENET_LAYERS) return fail(T2_EINVAL, "1..%d prenet layers supported", T2_MAX_PRENET_LAYERS);
+    const int pos[] = {d->num_symbols, d->embedding_dim, d->enc_kernel, d->attention_lstm_units, d->decoder_lstm_units,
+                       d->attention_dim, d->attention_filters, d->attention_kernel, d->num_mels, d->outputs_per_step,
+                       d->postnet_kernel, d->postnet_channels};
+    for (int v : pos) if (v < 1) return fail(T2_EINVAL, "every size must be >= 1");
+    if (d->enc_conv_layers < 0 || d->postnet_layers < 1) return fail(T2_EINVAL, "bad layer count");
+    for (int i = 0; i < d->num_prenet_layers; ++i) if (d->prenet_units[i] < 1) return fail(T2_EINVAL, "bad prenet size");
+    t2_model* m = new t2_model();
+    m->ctx = ctx;
+    m->d = *d;
+    *out = m;
+    return T2_OK;
+}
+
+extern "C" int t2_model_set_weight(t2_model* m, const char* name, const float* host_ptr, const int64_t* shape, int rank) {
+    if (!m || !name || !host_ptr || !shape || rank < 1 || rank > 4) return fail(T2_EINVAL, "bad argument");
+    if (m->finalized) return fail(T2_ESTATE, "model already finalized");
+    HostWeight w;
+    size_t n = 1;
+    for (int i = 0; i < rank; ++i) {
+        if (shape[i] < 1) return fail(T2_EINVAL, "bad shape");
+        w.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    w.data.assign(host_ptr, host_ptr + n);
+    m->hw[name] = std::move(w);
+    return T2_OK;
+}
+
+extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
+    if (!m || !name) return fail(T2_EINVAL, "null argument");
+    if (!strcmp(name, "graph")) m->opt_graph = value;
+    else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
+    else return fail(T2_EINVAL, "unknown option %s", name);
+    return T2_OK;
+}
+
+extern "C" int t2_model_finalize(t2_model* m) {
+    if (!m) return fail(T2_EINVAL, "null model");
+    if (m->finalized) return T2_OK;
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const t2_dims& d = m->d;
+    const HostWeight* w;
+    const HostWeight* b;
+    T2_TRY(get_w(m, "embedding", &w, {d.num_symbols, d.embedding_dim}));
+    T2_TRY(upload(m, &m->embedding, w->data));
+    int cin = d.embedding_dim;
+    m->enc_convs.resize(d.enc_conv_layers);
+    for (int i = 0; i < d.enc_conv_layers; ++i) {
+        T2_TRY(make_conv(m, &m->enc_convs[i], "encoder/conv1d_" + std::to_string(i), d.enc_kernel, cin, d.enc_units, true));
+        cin = d.enc_units;
+    }
+    const int He = d.enc_units / 2;
+    const char* dirs[2] = {"fw", "bw"};
+    for (int dir = 0; dir < 2; ++dir) {
+        const std::string p = std::string("encoder/bidirectional_rnn/") + dirs[dir] + "/lstm_cell/";
+        T2_TRY(get_w(m, p + "kernel", &w, {cin + He, 4 * He}));
+        T2_TRY(get_w(m, p + "bias", &b, {4 * He}));
+        T2_TRY(pack_skinny(m, &m->enc_lstm[dir], w->data.data(), 4 * He, {{0, cin}, {cin, He}}, He, 0, b->data.data()));
+    }
+    const int E = d.enc_units, U = d.attention_dim, A = d.attention_lstm_units, D = d.decoder_lstm_units;
+    const int F = d.attention_filters, K = d.attention_kernel, M = d.num_mels, r = d.outputs_per_step;
+    T2_TRY(get_w(m, "attention/memory_layer/kernel", &w, {E, U}));
+    m->memory_layer.k = 1; m->memory_layer.cin = E; m->memory_layer.cout = U;
+    T2_TRY(upload(m, &m->memory_layer.w, w->data));
+    T2_TRY(get_w(m, "attention/query_layer/kernel", &w, {A, U}));
+    T2_TRY(pack_skinny(m, &m->query, w->data.data(), U, {{0, A}}, 0, U, nullptr));
+    T2_TRY(get_w(m, "attention/location_features_convolution/kernel", &w, {K, 1, F}));
+    T2_TRY(upload(m, &m->conv_w, w->data));
+    T2_TRY(get_w(m, "attention/location_features_convolution/bias", &w, {F}));
+    T2_TRY(upload(m, &m->conv_b, w->data));
+    T2_TRY(get_w(m, "attention/location_features_layer/kernel", &w, {F, U}));
+    T2_TRY(upload(m, &m->wloc, w->data));
+    T2_TRY(get_w(m, "attention/attention_variable", &w, {U}));
+    T2_TRY(upload(m, &m->v_a, w->data));
+    T2_TRY(get_w(m, "attention/attention_bias", &w, {U}));
+    T2_TRY(upload(m, &m->b_a, w->data));
+    int pin = M * d.n_feed_frame;
+    for (int i = 0; i < d.num_prenet_layers; ++i) {
+        const std::string p = "decoder/prenet_" + std::to_string(i) + "/dense/";
+        T2_TRY(get_w(m, p + "kernel", &w, {pin, d.prenet_units[i]}));
+        T2_TRY(get_w(m, p + "bias", &b, {d.prenet_units[i]}));
+        T2_TRY(pack_skinny(m, &m->prenet[i], w->data.data(), d.prenet_units[i], {{0, pin}}, 0, d.prenet_units[i], b->data.data()));
+        pin = d.prenet_units[i];
+    }
+    T2_TRY(get_w(m, "decoder/attention_lstm/kernel", &w, {pin + E + A, 4 * A}));
+    T2_TRY(get_w(m, "decoder/attention_lstm/bias", &b, {4 * A}));
+    T2_TRY(pack_skinny(m, &m->att_lstm, w->data.data(), 4 * A, {{0, pin}, {pin, E}, {pin + E, A}}, A, 0, b->data.data()));
+    T2_TRY(get_w(m, "decoder/lstm_1/kernel", &w, {A + E + D, 4 * D}));
+    T2_TRY(get_w(m, "decoder/lstm_1/bias", &b, {4 * D}));
+    T2_TRY(pack_skinny(m, &m->lstm1, w->data.data(), 4 * D, {{0, A}, {A, E}, {A + E, D}}, D, 0, b->data.data()));
+    T2_TRY(get_w(m, "decoder/lstm_2/kernel", &w, {D + D, 4 * D}));
+    T2_TRY(get_w(m, "decoder/lstm_2/bias", &b, {4 * D}));
+    T2_TRY(pack_skinny(m, &m->lstm2, w->data.data(), 4 * D, {{0, D}, {D, D}}, D, 0, b->data.data()));
+    {   // mel and stop projections share one kernel: columns [0, M*r) mel, column M*r the stop logit
+        const HostWeight *wm, *bm, *wsn, *bs;
+        T2_TRY(get_w(m, "decoder/out_projection/kernel", &wm, {D, M * r}));
+        T2_TRY(get_w(m, "decoder/out_projection/bias", &bm, {M * r}));
+        T2_TRY(get_w(m, "decoder/stop_token_projection/kernel", &wsn, {D, 1}));
+        T2_TRY(get_w(m, "decoder/stop_token_projection/bias", &bs, {1}));
+        const int N = M * r + 1;
+        std::vector<float> wc((size_t)D * N), bc(N);
+        for (int k = 0; k < D; ++k) {
+            for (int c = 0; c < M * r; ++c) wc[(size_t)k * N + c] = wm->data[(size_t)k * M * r + c];
+            wc[(size_t)k * N + M * r] = wsn->data[k];
+        }
+        for (int c = 0; c < M * r; ++c) bc[c] = bm->data[c];
+        bc[M * r] = bs->data[0];
+        T2_TRY(pack_skinny(m, &m->proj, wc.data(), N, {{0, D}}, 0, N, bc.data()));
+    }
+    cin = M;
+    m->post_convs.resize(d.postnet_layers);
+    for (int i = 1; i <= d.postnet_layers; ++i) {
+        T2_TRY(make_conv(m, &m->post_convs[i - 1], "postnet/conv1d_" + std::to_string(i), d.postnet_kernel, cin, d.postnet_channels, true));
+        cin = d.postnet_channels;
+    }
+    T2_TRY(get_w(m, "postnet/projection/kernel", &w, {d.postnet_channels, M}));
+    T2_TRY(get_w(m, "postnet/projection/bias", &b, {M}));
+    m->post_proj.k = 1; m->post_proj.cin = d.postnet_channels; m->post_proj.cout = M;
+    T2_TRY(upload(m, &m->post_proj.w, w->data));
+    T2_TRY(upload(m, &m->post_proj.shift, b->data));
+    HIP_TRY(hipHostMalloc((void**)&m->h_ctl, 8 * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    m->hw.clear();
+    m->finalized = true;
+    return T2_OK;
+}
+
+static void state_free(t2_state* s);
+
+extern "C" int t2_model_destroy(t2_model* m) {
+    if (!m) return T2_OK;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    for (t2_state* s : m->states) state_free(s);
+    for (void* p : m->allocs) hipFree(p);
+    if (m->enc_ws) hipFree(m->enc_ws);
+    if (m->post_ws) hipFree(m->post_ws);
+    if (m->h_ctl) hipHostFree(m->h_ctl);
+    delete m;
+    return T2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv / dense on large M
+// ------------------------------------------------------------------------------------------------
+static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx, float* y, int ldy, int Mtot, int T,
+                       int act, const float* res, int ldr) {
+    ConvArgs a{};
+    a.x = x; a.ldx = ldx; a.w = L.w; a.scale = L.scale; a.shift = L.shift; a.res = res; a.ldr = ldr; a.y = y; a.ldy = ldy;
+    a.Mtot = Mtot; a.T = T; a.Cin = L.cin; a.N = L.cout; a.ktaps = L.k; a.pad_l = (L.k - 1) / 2; a.act = act;
+    a.vec_a = (L.cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0);
+    a.vec_b = (L.cout % 4 == 0) && (((uintptr_t)L.w) % 16 == 0);
+    dim3 grid(ceil_div(L.cout, CG_BN), ceil_div(Mtot, CG_BM));
+    hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, m->ctx->stream, a);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+static int ensure_ws(void** ws, size_t* have, size_t need) {
+    if (*have >= need) return T2_OK;
+    if (*ws) HIP_TRY(hipFree(*ws));
+    *ws = nullptr; *have = 0;
+    HIP_TRY(hipMalloc(ws, need));
+    *have = need;
+    return T2_OK;
+}
+
+static int check_batch(int B, int T) {
+    if (B < 1 || B > T2_MAX_BATCH) return fail(T2_EINVAL, "batch %d outside 1..%d", B, T2_MAX_BATCH);
+    if (T < 1) return fail(T2_EINVAL, "sequence length must be >= 1");
+    return T2_OK;
+}
+
+static inline int mb_for(int B) { const int mb = ceil_div(B, 16); return mb == 3 ? 4 : mb; }
+
+static inline void launch_lstm(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const LstmEpi& e) {
+    if (MB == 1) hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+    else if (MB == 2) hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+    else hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+}
+static inline void launch_dense(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const DenseEpi& e) {
+    if (MB == 1) hipLaunchKernelGGL(dense_step_kernel<1>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+    else if (MB == 2) hipLaunchKernelGGL(dense_step_kernel<2>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+    else hipLaunchKernelGGL(dense_step_kernel<4>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, const int64_t* lens, int B, int T, float* memory_out) {
+    if (!m || !memory_out) return fail(T2_EINVAL, "null argument");
+    if (!m->finalized) return fail(T2_ESTATE, "model not finalized");
+    T2_TRY(check_batch(B, T));
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int MB = mb_for(B), E = d.enc_units, He = E / 2, emb = d.embedding_dim;
+    const int Mtot = B * T;
+    std::vector<int> h_lens(B), h_ids;
+    for (int b = 0; b < B; ++b) {
+        const int64_t l = lens ? lens[b] : T;
+        if (l < 0 || l > T) return fail(T2_EINVAL, "sequence length %lld outside 0..%d", (long long)l, T);
+        h_lens[b] = (int)l;
+    }
+    if (ids) {
+        h_ids.resize(Mtot);
+        for (int i = 0; i < Mtot; ++i) {
+            if (ids[i] < 0 || ids[i] >= d.num_symbols)
+                return fail(T2_ERANGE, "embedding id %lld outside [0, %d) (modules.py:65-66)", (long long)ids[i], d.num_symbols);
+            h_ids[i] = (int)ids[i];
+        }
+    }
+    const int cw = std::max(emb, E);
+    const int KPx = pad16(std::max(emb, E)), KPh = pad16(He);
+    const size_t per_step = (size_t)MB * 16 * KPx;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_ids = carve((size_t)Mtot * 4), o_lens = carve((size_t)B * 4);
+    const size_t o_x0 = carve((size_t)Mtot * cw * 4), o_x1 = carve((size_t)Mtot * cw * 4);
+    const size_t o_xf = carve(2 * (size_t)T * per_step * 4);
+    const size_t o_zero = off;
+    const size_t o_c = carve(2 * (size_t)MB * 16 * He * 4);
+    const size_t o_h = carve(2 * 2 * (size_t)MB * 16 * KPh * 4);
+    const size_t o_ctl = carve(8 * 4);
+    const size_t zero_bytes = off - o_zero;
+    T2_TRY(ensure_ws(&m->enc_ws, &m->enc_ws_bytes, off));
+    char* ws = (char*)m->enc_ws;
+    int* d_ids = (int*)(ws + o_ids);
+    int* d_lens = (int*)(ws + o_lens);
+    float* x0 = (float*)(ws + o_x0);
+    float* x1 = (float*)(ws + o_x1);
+    float* xf = (float*)(ws + o_xf);
+    float* cst = (float*)(ws + o_c);
+    float* hst = (float*)(ws + o_h);
+    int* ctl = (int*)(ws + o_ctl);
+    // stream-ordered uploads from pageable memory are synchronous w.r.t. the host copy
+    HIP_TRY(hipMemcpyAsync(d_lens, h_lens.data(), B * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ws + o_zero, 0, zero_bytes, st));
+    const float* cur;
+    int cur_c;
+    if (ids) {
+        HIP_TRY(hipMemcpyAsync(d_ids, h_ids.data(), (size_t)Mtot * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(embedding_kernel, dim3(std::min(1024, ceil_div(Mtot * emb, 256))), dim3(256), 0, st, d_ids, m->embedding, x0, Mtot, emb);
+        cur = x0;
+    } else {
+        cur = emb_in;
+    }
+    cur_c = emb;
+    float* bufs[2] = {x1, x0};
+    for (int i = 0; i < d.enc_conv_layers; ++i) {
+        float* dst = bufs[i & 1];
+        T2_TRY(launch_conv(m, m->enc_convs[i], cur, cur_c, dst, E, Mtot, T, 1, nullptr, 0));
+        cur = dst;
+        cur_c = E;
+    }
+    const int Cx = cur_c;   // BiLSTM input width
+    const int KPc = pad16(Cx);
+    if (KPc > KPx) return fail(T2_EINVAL, "internal: lstm input wider than workspace");
+    const size_t per_step_c = (size_t)MB * 16 * KPc;
+    {
+        const long long n = 2LL * T * per_step_c;
+        hipLaunchKernelGGL(seq_to_frag_kernel, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, st,
+                           cur, d_lens, xf, B, T, Cx, MB);
+    }
+    HIP_TRY(hipMemsetAsync(memory_out, 0, (size_t)Mtot * E * 4, st));
+    const int h_ctl[8] = {0, 0, T, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(ctl, h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, st));
+    const int hsz = MB * 16 * KPh;
+    for (int s = 0; s < T; ++s) {
+        SkinnyCore c{};
+        LstmEpi e{};
+        for (int dir = 0; dir < 2; ++dir) {
+            c.w[dir] = m->enc_lstm[dir].w;
+            c.bias[dir] = m->enc_lstm[dir].bias;
+            c.seg[dir][0] = SegDesc{xf + (size_t)dir * T * per_step_c, KPc / 16, 0, (int)per_step_c, 0};
+            c.seg[dir][1] = SegDesc{hst + (size_t)dir * 2 * hsz, KPh / 16, hsz, 0, 0};
+            e.c[dir] = cst + (size_t)dir * MB * 16 * He;
+            e.hstate[dir] = hst + (size_t)dir * 2 * hsz;
+            e.hraw[dir] = nullptr;
+            e.plain_off[dir] = dir * He;
+            e.reverse[dir] = dir;
+        }
+        c.nseg = 2; c.kbtot = m->enc_lstm[0].kbtot; c.ctl = ctl; c.step_off = s; c.B = B;
+        e.H = He; e.Hld = He; e.hstate_pp_stride = hsz; e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+        e.lens = d_lens; e.plain_out = memory_out; e.plain_bs = T * E; e.plain_ts = E;
+        launch_lstm(MB, dim3(m->enc_lstm[0].n_wg, 2), st, c, e);
+    }
+    HIP_TRY(hipGetLastError());
+    // h_lens / h_ids are host temporaries: make sure the async copies consumed them
+    HIP_TRY(hipStreamSynchronize(st));
+    return T2_OK;
+}
+
+extern "C" int t2_encode(t2_model* m, const int64_t* ids, const int64_t* lens, int B, int T_in, float* memory_out) {
+    if (!ids) return fail(T2_EINVAL, "ids is null");
+    return encode_impl(m, ids, nullptr, lens, B, T_in, memory_out);
+}
+
+extern "C" int t2_encode_embedded(t2_model* m, const float* emb, const int64_t* lens, int B, int T_in, float* memory_out) {
+    if (!emb) return fail(T2_EINVAL, "emb is null");
+    return encode_impl(m, nullptr, emb, lens, B, T_in, memory_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// postnet
+// ------------------------------------------------------------------------------------------------
+extern "C" int t2_postnet(t2_model* m, const float* mel, int B, int T_out, float* mel_post) {
+    if (!m || !mel || !mel_post) return fail(T2_EINVAL, "null argument");
+    if (!m->finalized) return fail(T2_ESTATE, "model not finalized");
+    if (B < 1 || T_out < 1) return fail(T2_EINVAL, "bad shape");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const t2_dims& d = m->d;
+    const int Mtot = B * T_out, C = d.postnet_channels, M = d.num_mels;
+    const size_t one = align_up((size_t)Mtot * C * 4, 256);
+    T2_TRY(ensure_ws(&m->post_ws, &m->post_ws_bytes, 2 * one));
+    float* bufs[2] = {(float*)m->post_ws, (float*)((char*)m->post_ws + one)};
+    const float* cur = mel;
+    int cur_c = M;
+    for (int i = 0; i < d.postnet_layers; ++i) {
+        float* dst = bufs[i & 1];
+        const int act = (i + 1 < d.postnet_layers) ? 2 : 0;   // tanh, last layer linear (tacotron_v2.py:187-196)
+        T2_TRY(launch_conv(m, m->post_convs[i], cur, cur_c, dst, C, Mtot, T_out, act, nullptr, 0));
+        cur = dst;
+        cur_c = C;
+    }
+    // Dense(out_units) + residual on the raw input (tacotron_v2.py:202-203)
+    T2_TRY(launch_conv(m, m->post_proj, cur, C, mel_post, M, Mtot, Mtot, 0, mel, M));
+    return T2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder state
+// ------------------------------------------------------------------------------------------------
+static void state_free(t2_state* s) {
+    if (!s) return;
+    for (int i = 0; i < 2; ++i) if (s->gexec[i]) hipGraphExecDestroy(s->gexec[i]);
+    if (s->slab) hipFree(s->slab);
+    if (s->fixed) hipFree(s->fixed);
+    if (s->outbuf) hipFree(s->outbuf);
+    delete s;
+}
+
+static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2_state** out) {
+    const t2_dims& d = m->d;
+    t2_state* s = new t2_state();
+    s->m = m; s->B = B; s->T = T; s->MB = mb_for(B); s->cap = cap;
+    const int MB = s->MB, R = MB * 16;
+    const int E = d.enc_units, U = d.attention_dim, A = d.attention_lstm_units, D = d.decoder_lstm_units;
+    const int M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    // fixed part
+    const size_t o_val = carve((size_t)B * T * E * 4), o_keys = carve((size_t)B * T * U * 4), o_lens = carve((size_t)B * 4);
+    hipError_t e1 = hipMalloc(&s->fixed, off);
+    if (e1 != hipSuccess) { state_free(s); return fail(T2_ENOMEM, "hipMalloc(state fixed) failed: %s", hipGetErrorString(e1)); }
+    s->values = (float*)((char*)s->fixed + o_val);
+    s->keys = (float*)((char*)s->fixed + o_keys);
+    s->lens = (int*)((char*)s->fixed + o_lens);
+    // zeroable part
+    off = 0;
+    s->h_att_sz = R * pad16(A); s->h1_sz = R * pad16(D); s->h2_sz = R * pad16(D);
+    const size_t o_ctl = carve(8 * 4);
+    const size_t o_as = carve((size_t)B * T * 4), o_al = carve((size_t)B * T * 4);
+    const size_t o_cf = carve((size_t)R * pad16(E) * 4), o_cp = carve((size_t)B * E * 4), o_q = carve((size_t)R * U * 4);
+    const size_t o_ca = carve((size_t)R * A * 4), o_c1 = carve((size_t)R * D * 4), o_c2 = carve((size_t)R * D * 4);
+    const size_t o_ha = carve(2 * (size_t)s->h_att_sz * 4), o_h1 = carve(2 * (size_t)s->h1_sz * 4), o_h2 = carve(2 * (size_t)s->h2_sz * 4);
+    const size_t o_har = carve((size_t)s->h_att_sz * 4), o_y1 = carve((size_t)s->h1_sz * 4), o_y2 = carve((size_t)s->h2_sz * 4);
+    const size_t o_xin = carve((size_t)R * pad16(M * nf) * 4);
+    size_t o_xp[T2_MAX_PRENET_LAYERS];
+    for (int i = 0; i < d.num_prenet_layers; ++i) o_xp[i] = carve((size_t)R * pad16(d.prenet_units[i]) * 4);
+    s->slab_bytes = off;
+    e1 = hipMalloc(&s->slab, off);
+    if (e1 != hipSuccess) { state_free(s); return fail(T2_ENOMEM, "hipMalloc(state slab) failed: %s", hipGetErrorString(e1)); }
+    char* p = (char*)s->slab;
+    s->ctl = (int*)(p + o_ctl);
+    s->att_state = (float*)(p + o_as); s->alignments = (float*)(p + o_al);
+    s->ctx_frag = (float*)(p + o_cf); s->ctx_plain = (float*)(p + o_cp); s->q = (float*)(p + o_q);
+    s->c_att = (float*)(p + o_ca); s->c1 = (float*)(p + o_c1); s->c2 = (float*)(p + o_c2);
+    s->h_att = (float*)(p + o_ha); s->h1 = (float*)(p + o_h1); s->h2 = (float*)(p + o_h2);
+    s->h_att_raw = (float*)(p + o_har); s->y1_raw = (float*)(p + o_y1); s->y2_raw = (float*)(p + o_y2);
+    s->xin = (float*)(p + o_xin);
+    for (int i = 0; i < d.num_prenet_layers; ++i) s->xp[i] = (float*)(p + o_xp[i]);
+    // output staging
+    off = 0;
+    const size_t o_mel = carve((size_t)B * cap * r * M * 4), o_stop = carve((size_t)B * cap * 4);
+    const size_t o_hist = carve((size_t)cap * B * T * 4);
+    const size_t o_tgt = with_targets ? carve((size_t)B * cap * r * M * 4) : 0;
+    e1 = hipMalloc(&s->outbuf, off);
+    if (e1 != hipSuccess) { state_free(s); return fail(T2_ENOMEM, "hipMalloc(state out) failed: %s", hipGetErrorString(e1)); }
+    p = (char*)s->outbuf;
+    s->o_mel = (float*)(p + o_mel); s->o_stop = (float*)(p + o_stop); s->o_hist = (float*)(p + o_hist);
+    s->i_targets = with_targets ? (float*)(p + o_tgt) : nullptr;
+    *out = s;
+    return T2_OK;
+}
+
+static size_t attn_lds_bytes(const t2_dims& d, int T) {
+    const int F = d.attention_filters, U = d.attention_dim, K = d.attention_kernel;
+    size_t n = ((T + K + 3) & ~3) + ((T * F + 3) & ~3) + ((F * U + 3) & ~3) + ((T + 3) & ~3) + 32;
+    return n * 4;
+}
+
+// attention mechanism constructor side effects + zero state
+static int state_init(t2_state* s, const float* memory, const int64_t* lens) {
+    t2_model* m = s->m;
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int B = s->B, T = s->T, E = d.enc_units;
+    std::vector<int> h_lens(B);
+    for (int b = 0; b < B; ++b) {
+        const int64_t l = lens ? lens[b] : T;
+        if (l < 1 || l > T) return fail(T2_EINVAL, "memory_sequence_length %lld outside 1..%d", (long long)l, T);
+        h_lens[b] = (int)l;
+    }
+    HIP_TRY(hipMemcpyAsync(s->lens, h_lens.data(), B * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // h_lens is a host temporary
+    const long long n = (long long)B * T * E;
+    hipLaunchKernelGGL(mask_memory_kernel, dim3((unsigned)std::min<long long>(2048, (n + 255) / 256)), dim3(256), 0, st,
+                       memory, s->lens, s->values, B, T, E);
+    T2_TRY(launch_conv(m, m->memory_layer, s->values, E, s->keys, d.attention_dim, B * T, B * T, 0, nullptr, 0));
+    return T2_OK;
+}
+
+static int state_zero(t2_state* s, int max_steps, int min_iters, int stop_enabled) {
+    hipStream_t st = s->m->ctx->stream;
+    HIP_TRY(hipMemsetAsync(s->slab, 0, s->slab_bytes, st));
+    int* h = s->m->h_ctl;
+    HIP_TRY(hipStreamSynchronize(st));   // pinned mirror may still be in use by an earlier copy
+    h[0] = 0; h[1] = 0; h[2] = max_steps; h[3] = min_iters; h[4] = stop_enabled; h[5] = h[6] = h[7] = 0;
+    HIP_TRY(hipMemcpyAsync(s->ctl, h, 8 * sizeof(int), hipMemcpyHostToDevice, st));
+    return T2_OK;
+}
+
+extern "C" int t2_state_create(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in, t2_state** out) {
+    if (!m || !memory || !out) return fail(T2_EINVAL, "null argument");
+    if (!m->finalized) return fail(T2_ESTATE, "model not finalized");
+    T2_TRY(check_batch(B, T_in));
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    if (attn_lds_bytes(m->d, T_in) > 160 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention kernel's LDS", T_in);
+    t2_state* s = nullptr;
+    T2_TRY(state_alloc(m, B, T_in, 1, false, &s));
+    int r = state_init(s, memory, lens);
+    if (r == T2_OK) r = state_zero(s, 0x7fffffff, 0, 0);
+    if (r != T2_OK) { state_free(s); return r; }
+    *out = s;
+    return T2_OK;
+}
+
+extern "C" int t2_state_reset(t2_state* s) {
+    if (!s) return fail(T2_EINVAL, "null state");
+    return state_zero(s, 0x7fffffff, 0, 0);
+}
+
+extern "C" int t2_state_destroy(t2_state* s) {
+    if (!s) return T2_OK;
+    if (s->owned_by_model) return fail(T2_EINVAL, "state is owned by the model");
+    hipStreamSynchronize(s->m->ctx->stream);
+    state_free(s);
+    return T2_OK;
+}
+
+static int current_parity(t2_state* s, int* par) {
+    hipStream_t st = s->m->ctx->stream;
+    int h[8];
+    HIP_TRY(hipMemcpyAsync(h, s->ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int t = h[CTL_BASE];
+    if (h[CTL_FINAL] != 0) t = std::min(t, h[CTL_FINAL]);
+    t = std::min(t, h[CTL_MAX]);
+    *par = t & 1;
+    return T2_OK;
+}
+
+extern "C" int t2_state_get(t2_state* s, const char* name, float* out) {
+    if (!s || !name || !out) return fail(T2_EINVAL, "null argument");
+    const t2_dims& d = s->m->d;
+    hipStream_t st = s->m->ctx->stream;
+    const int B = s->B, T = s->T;
+    auto copy_plain = [&](const float* src, size_t rows, size_t ld_src, size_t cols) -> int {
+        HIP_TRY(hipMemcpy2DAsync(out, cols * 4, src, ld_src * 4, cols * 4, rows, hipMemcpyDeviceToDevice, st));
+        return T2_OK;
+    };
+    auto copy_frag = [&](const float* src, int K) -> int {
+        hipLaunchKernelGGL(frag_to_plain_kernel, dim3(ceil_div(B * K, 256)), dim3(256), 0, st, src, out, B, K, s->MB);
+        HIP_TRY(hipGetLastError());
+        return T2_OK;
+    };
+    int par = 0;
+    if (!strcmp(name, "attention_c")) return copy_plain(s->c_att, B, d.attention_lstm_units, d.attention_lstm_units);
+    if (!strcmp(name, "lstm1_c")) return copy_plain(s->c1, B, d.decoder_lstm_units, d.decoder_lstm_units);
+    if (!strcmp(name, "lstm2_c")) return copy_plain(s->c2, B, d.decoder_lstm_units, d.decoder_lstm_units);
+    if (!strcmp(name, "attention_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->h_att + (size_t)par * s->h_att_sz, d.attention_lstm_units); }
+    if (!strcmp(name, "lstm1_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->h1 + (size_t)par * s->h1_sz, d.decoder_lstm_units); }
+    if (!strcmp(name, "lstm2_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->h2 + (size_t)par * s->h2_sz, d.decoder_lstm_units); }
+    if (!strcmp(name, "attention")) return copy_plain(s->ctx_plain, B, d.enc_units, d.enc_units);
+    if (!strcmp(name, "alignments")) return copy_plain(s->alignments, B, T, T);
+    if (!strcmp(name, "attention_state")) return copy_plain(s->att_state, B, T, T);
+    if (!strcmp(name, "keys")) return copy_plain(s->keys, (size_t)B * T, d.attention_dim, d.attention_dim);
+    return fail(T2_EINVAL, "unknown state tensor '%s'", name);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one decoder step = the launch sequence below
+// ------------------------------------------------------------------------------------------------
+struct StepIO {
+    int feed_mode;              // 0: teacher (targets), 1: own output (proj writes xin), 2: caller frames (API)
+    const float* feed_src;      // mode 0: targets + M*(r-nf) ; mode 2: prev_frames
+    long long feed_row_stride;  // floats
+    long long feed_t_stride;
+    float* mel; int mel_ld; long long mel_t_stride;
+    float* stop; int stop_ld; int stop_t_mul;
+    float* hist;
+};
+
+static int launch_step(t2_state* s, int step_off, const StepIO& io) {
+    t2_model* m = s->m;
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int B = s->B, MB = s->MB;
+    const int E = d.enc_units, U = d.attention_dim, A = d.attention_lstm_units, D = d.decoder_lstm_units;
+    const int M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame;
+    auto core = [&](const Packed& p) {
+        SkinnyCore c{};
+        c.w[0] = c.w[1] = p.w; c.bias[0] = c.bias[1] = p.bias;
+        c.nseg = p.nseg; c.kbtot = p.kbtot; c.ctl = s->ctl; c.step_off = step_off; c.B = B;
+        return c;
+    };
+    auto seg = [&](const float* base, int kb, int pp) { return SegDesc{base, kb, pp, 0, 0}; };
+    // 1. decoder input frames (helpers.py:86 / :182 / go frame :187-188)
+    if (io.feed_mode == 0 || io.feed_mode == 2) {
+        FeedArgs f{};
+        f.src = io.feed_src; f.row_stride = io.feed_row_stride; f.t_stride = io.feed_t_stride; f.dst = s->xin;
+        f.B = B; f.K = M * nf; f.MB = MB; f.go_zero = io.feed_mode == 0; f.ctl = s->ctl; f.step_off = step_off;
+        hipLaunchKernelGGL(feed_frames_kernel, dim3(ceil_div(MB * 16 * pad16(M * nf), 256)), dim3(256), 0, st, f);
+    }
+    // 2. prenets (rnn_wrappers.py:51-53)
+    const float* x = s->xin;
+    for (int i = 0; i < d.num_prenet_layers; ++i) {
+        SkinnyCore c = core(m->prenet[i]);
+        c.seg[0][0] = seg(x, m->prenet[i].seg_kb[0], 0);
+        DenseEpi e{};
+        e.N = d.prenet_units[i]; e.relu = 1; e.out_frag = s->xp[i]; e.frag_col0 = 0; e.stop_col = -1;
+        launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e);
+        x = s->xp[i];
+    }
+    // 3. attention LSTM on concat(prenet out, previous context)  (AttentionWrapper, App. A6)
+    {
+        SkinnyCore c = core(m->att_lstm);
+        c.seg[0][0] = seg(x, m->att_lstm.seg_kb[0], 0);
+        c.seg[0][1] = seg(s->ctx_frag, m->att_lstm.seg_kb[1], 0);
+        c.seg[0][2] = seg(s->h_att, m->att_lstm.seg_kb[2], s->h_att_sz);
+        LstmEpi e{};
+        e.H = A; e.c[0] = s->c_att; e.Hld = A; e.hstate[0] = s->h_att; e.hstate_pp_stride = s->h_att_sz; e.hraw[0] = s->h_att_raw;
+        e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+        launch_lstm(MB, dim3(m->att_lstm.n_wg, 1), st, c, e);
+    }
+    // 4. processed query (tacotron_v2.py:122)
+    {
+        SkinnyCore c = core(m->query);
+        c.seg[0][0] = seg(s->h_att_raw, m->query.seg_kb[0], 0);
+        DenseEpi e{};
+        e.N = U; e.out_plain = s->q; e.plain_ld = U; e.plain_t_stride = 0; e.plain_ncol = U; e.stop_col = -1;
+        launch_dense(MB, dim3(m->query.n_wg), st, c, e);
+    }
+    // 5. location-sensitive attention + context
+    {
+        AttnArgs a{};
+        a.keys = s->keys; a.values = s->values; a.lens = s->lens; a.att_state = s->att_state; a.alignments = s->alignments;
+        a.history = io.hist; a.q = s->q; a.ctx_frag = s->ctx_frag; a.ctx_plain = s->ctx_plain;
+        a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
+        a.B = B; a.T = s->T; a.U = U; a.E = E; a.F = d.attention_filters; a.K = d.attention_kernel; a.MB = MB;
+        a.cumulative = d.cumulative_weights; a.ctl = s->ctl; a.step_off = step_off;
+        hipLaunchKernelGGL(attention_step_kernel, dim3(B), dim3(T2_ATTN_THREADS), attn_lds_bytes(d, s->T), st, a);
+    }
+    // 6./7. decoder LSTMs on concat(attention cell output, new context)  (rnn_wrappers.py:76-78, tacotron_v2.py:155-161)
+    {
+        SkinnyCore c = core(m->lstm1);
+        c.seg[0][0] = seg(s->h_att_raw, m->lstm1.seg_kb[0], 0);
+        c.seg[0][1] = seg(s->ctx_frag, m->lstm1.seg_kb[1], 0);
+        c.seg[0][2] = seg(s->h1, m->lstm1.seg_kb[2], s->h1_sz);
+        LstmEpi e{};
+        e.H = D; e.c[0] = s->c1; e.Hld = D; e.hstate[0] = s->h1; e.hstate_pp_stride = s->h1_sz; e.hraw[0] = s->y1_raw;
+        e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+        launch_lstm(MB, dim3(m->lstm1.n_wg, 1), st, c, e);
+    }
+    {
+        SkinnyCore c = core(m->lstm2);
+        c.seg[0][0] = seg(s->y1_raw, m->lstm2.seg_kb[0], 0);
+        c.seg[0][1] = seg(s->h2, m->lstm2.seg_kb[1], s->h2_sz);
+        LstmEpi e{};
+        e.H = D; e.c[0] = s->c2; e.Hld = D; e.hstate[0] = s->h2; e.hstate_pp_stride = s->h2_sz; e.hraw[0] = s->y2_raw;
+        e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+        launch_lstm(MB, dim3(m->lstm2.n_wg, 1), st, c, e);
+    }
+    // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
+    {
+        SkinnyCore c = core(m->proj);
+        c.seg[0][0] = seg(s->y2_raw, m->proj.seg_kb[0], 0);
+        DenseEpi e{};
+        e.N = M * r + 1; e.relu = 0;
+        e.out_plain = io.mel; e.plain_ld = io.mel_ld; e.plain_t_stride = io.mel_t_stride; e.plain_ncol = M * r;
+        e.out_frag = io.feed_mode == 1 ? s->xin : nullptr; e.frag_col0 = M * (r - nf);
+        e.stop_col = M * r; e.out_stop = io.stop; e.stop_ld = io.stop_ld; e.stop_t_mul = io.stop_t_mul; e.ctl_w = s->ctl;
+        launch_dense(MB, dim3(m->proj.n_wg), st, c, e);
+    }
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+extern "C" int t2_decode_step(t2_model* m, t2_state* s, const float* prev_frames, float* mel_r, float* stop) {
+    if (!m || !s || !prev_frames || !mel_r || !stop) return fail(T2_EINVAL, "null argument");
+    if (s->m != m) return fail(T2_EINVAL, "state belongs to another model");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    StepIO io{};
+    io.feed_mode = 2; io.feed_src = prev_frames; io.feed_row_stride = d.num_mels * d.n_feed_frame; io.feed_t_stride = 0;
+    io.mel = s->o_mel; io.mel_ld = d.num_mels * d.outputs_per_step; io.mel_t_stride = 0;
+    io.stop = s->o_stop; io.stop_ld = 1; io.stop_t_mul = 0; io.hist = nullptr;
+    T2_TRY(launch_step(s, 0, io));
+    hipLaunchKernelGGL(advance_ctl_kernel, dim3(1), dim3(64), 0, st, s->ctl, 1);
+    const size_t nmel = (size_t)s->B * d.num_mels * d.outputs_per_step;
+    HIP_TRY(hipMemcpyAsync(mel_r, s->o_mel, nmel * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)s->B * 4, hipMemcpyDeviceToDevice, st));
+    return T2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode loops
+// ------------------------------------------------------------------------------------------------
+static int get_loop_state(t2_model* m, int B, int T, int cap, t2_state** out) {
+    for (t2_state* s : m->states)
+        if (s->B == B && s->T == T && s->cap == cap) { *out = s; return T2_OK; }
+    if (attn_lds_bytes(m->d, T) > 160 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention kernel's LDS", T);
+    // keep the cache small: drop everything when it grows
+    if (m->states.size() >= 4) {
+        HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+        for (t2_state* s : m->states) state_free(s);
+        m->states.clear();
+        m->pending = nullptr;
+    }
+    t2_state* s = nullptr;
+    T2_TRY(state_alloc(m, B, T, cap, true, &s));
+    s->owned_by_model = true;
+    m->states.push_back(s);
+    *out = s;
+    return T2_OK;
+}
+
+static StepIO loop_io(t2_state* s, int mode) {
+    const t2_dims& d = s->m->d;
+    const int M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame;
+    StepIO io{};
+    io.feed_mode = mode;
+    io.feed_src = s->i_targets ? s->i_targets + (size_t)M * (r - nf) : nullptr;
+    io.feed_row_stride = (long long)s->cap * r * M;
+    io.feed_t_stride = (long long)r * M;
+    io.mel = s->o_mel; io.mel_ld = s->cap * r * M; io.mel_t_stride = (long long)r * M;
+    io.stop = s->o_stop; io.stop_ld = s->cap; io.stop_t_mul = 1;
+    io.hist = s->o_hist;
+    return io;
+}
+
+// Enqueue one chunk of `chunk` steps followed by the base-step advance.
+static int enqueue_chunk(t2_state* s, int mode, int chunk) {
+    hipStream_t st = s->m->ctx->stream;
+    const StepIO io = loop_io(s, mode);
+    for (int i = 0; i < chunk; ++i) T2_TRY(launch_step(s, i, io));
+    hipLaunchKernelGGL(advance_ctl_kernel, dim3(1), dim3(64), 0, st, s->ctl, chunk);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+static int run_chunk(t2_state* s, int mode) {
+    t2_model* m = s->m;
+    hipStream_t st = m->ctx->stream;
+    const int chunk = m->opt_chunk;
+    if (!m->opt_graph) return enqueue_chunk(s, mode, chunk);
+    if (s->gexec[mode] == nullptr || s->gchunk[mode] != chunk) {
+        if (s->gexec[mode]) { hipGraphExecDestroy(s->gexec[mode]); s->gexec[mode] = nullptr; }
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        int r = enqueue_chunk(s, mode, chunk);
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (r != T2_OK) { if (g) hipGraphDestroy(g); return r; }
+        if (e != hipSuccess) return fail(T2_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&s->gexec[mode], g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) { s->gexec[mode] = nullptr; return fail(T2_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+        s->gchunk[mode] = chunk;
+    }
+    HIP_TRY(hipGraphLaunch(s->gexec[mode], st));
+    return T2_OK;
+}
+
+extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t* lens, const float* targets,
+                                 int B, int T_in, int T_out, int teacher_forcing,
+                                 float* mel, float* stop, float* align) {
+    if (!m || !memory || !targets || !mel || !stop || !align) return fail(T2_EINVAL, "null argument");
+    if (!m->finalized) return fail(T2_ESTATE, "model not finalized");
+    T2_TRY(check_batch(B, T_in));
+    const t2_dims& d = m->d;
+    const int M = d.num_mels, r = d.outputs_per_step;
+    if (T_out < r || T_out % r != 0) return fail(T2_EINVAL, "T_out must be a positive multiple of outputs_per_step");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    const int S = T_out / r;
+    t2_state* s = nullptr;
+    T2_TRY(get_loop_state(m, B, T_in, S, &s));
+    T2_TRY(state_init(s, memory, lens));
+    T2_TRY(state_zero(s, S, 0, 0));
+    HIP_TRY(hipMemcpyAsync(s->i_targets, targets, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
+    const int mode = teacher_forcing ? 0 : 1;
+    for (int done = 0; done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
+    HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(align, s->o_hist, (size_t)S * B * T_in * 4, hipMemcpyDeviceToDevice, st));
+    return T2_OK;
+}
+
+static int free_prepare(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in, int max_iters, int min_iters,
+                        float* mel, float* stop, float* align, t2_state** out) {
+    if (!m || !memory || !mel || !stop || !align) return fail(T2_EINVAL, "null argument");
+    if (!m->finalized) return fail(T2_ESTATE, "model not finalized");
+    T2_TRY(check_batch(B, T_in));
+    if (max_iters < 1) return fail(T2_EINVAL, "max_iters must be >= 1");
+    if (m->pending) return fail(T2_ESTATE, "a free-running decode is already in flight; call t2_decode_free_finish");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    t2_state* s = nullptr;
+    T2_TRY(get_loop_state(m, B, T_in, max_iters, &s));
+    T2_TRY(state_init(s, memory, lens));
+    T2_TRY(state_zero(s, max_iters, min_iters, 1));
+    *out = s;
+    return T2_OK;
+}
+
+static int free_copy_out(t2_state* s, float* mel, float* stop, float* align) {
+    const t2_dims& d = s->m->d;
+    hipStream_t st = s->m->ctx->stream;
+    const size_t cap = s->cap;
+    HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)s->B * cap * d.outputs_per_step * d.num_mels * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)s->B * cap * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(align, s->o_hist, cap * s->B * s->T * 4, hipMemcpyDeviceToDevice, st));
+    return T2_OK;
+}
+
+static int read_steps(t2_state* s, int* steps_out) {
+    hipStream_t st = s->m->ctx->stream;
+    int* h = s->m->h_ctl;
+    HIP_TRY(hipMemcpyAsync(h, s->ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *steps_out = h[CTL_FINAL] != 0 ? h[CTL_FINAL] : h[CTL_MAX];
+    return T2_OK;
+}
+
+extern "C" int t2_decode_free_launch(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
+                                     int max_iters, int min_iters, float* mel, float* stop, float* align) {
+    t2_state* s = nullptr;
+    T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
+    for (int done = 0; done < max_iters; done += m->opt_chunk) T2_TRY(run_chunk(s, 1));
+    T2_TRY(free_copy_out(s, mel, stop, align));
+    m->pending = s;
+    return T2_OK;
+}
+
+extern "C" int t2_decode_free_finish(t2_model* m, int* steps_out) {
+    if (!m || !steps_out) return fail(T2_EINVAL, "null argument");
+    if (!m->pending) return fail(T2_ESTATE, "no free-running decode in flight");
+    t2_state* s = m->pending;
+    m->pending = nullptr;
+    return read_steps(s, steps_out);
+}
+
+extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
+                              int max_iters, int min_iters, float* mel, float* stop, float* align, int* steps_out) {
+    if (!steps_out) return fail(T2_EINVAL, "steps_out is null");
+    t2_state* s = nullptr;
+    T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
+    hipStream_t st = m->ctx->stream;
+    // chunks are enqueued two ahead of the host's view of the finished flag: chunks after the stop
+    // step are no-ops on the device, so over-enqueueing is harmless and the host never stalls the GPU.
+    hipEvent_t ev[2];
+    int* h_flag = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&h_flag, 2 * 8 * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    int rc = T2_OK, n = 0;
+    bool finished = false;
+    for (int done = 0; done < max_iters && !finished; done += m->opt_chunk, ++n) {
+        if (n >= 2) {
+            hipEventSynchronize(ev[n & 1]);
+            if (h_flag[(n & 1) * 8 + CTL_FINAL] != 0) { finished = true; break; }
+        }
+        rc = run_chunk(s, 1);
+        if (rc != T2_OK) break;
+        hipMemcpyAsync(h_flag + (n & 1) * 8, s->ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, st);
+        hipEventRecord(ev[n & 1], st);
+    }
+    if (rc == T2_OK) rc = free_copy_out(s, mel, stop, align);
+    if (rc == T2_OK) rc = read_steps(s, steps_out);
+    hipStreamSynchronize(st);
+    for (int i = 0; i < 2; ++i) hipEventDestroy(ev[i]);
+    hipHostFree(h_flag);
+    return rc;
+}
