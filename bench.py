@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- mel frames/sec of Tacotron2 free-running synthesis, B=64 per GPU (BASELINE.json
+config 3), on N GPUs of one node (utterances batch-sharded, no data-path collective), plus the
+batch-1 RTF (config 2) and a bounded CPU baseline (the NumPy oracle) at N=1.
+
+One "step" = one pass of the hot path over one batch of 64 synthetic utterances per GPU:
+Embedding + EncoderV2 -> free-running decode (stop rule evaluated on the device every step) ->
+PostNetV2.  Weights are random-initialised at the Tacotron2-paper sizes (profile P);
+the stop bias is set so that the rule never fires and every decode runs to max_iters = 400 steps
+(800 mel frames per utterance): the amount of work is fixed and stated.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md, HBM3E spec
+FRAME_SHIFT_S = 0.0125             # reference hparams.py:18
+
+
+def make_inputs(B, t_lo, t_hi, seed):
+    """BASELINE.json config 3: T_in ~ uniform{t_lo..t_hi}, ids upper-case ASCII + eos=1
+    (reference datasets/ljspeech.py:154-156, datasets/corpus.py:80), padded per shard."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(t_lo, t_hi + 1, size=B)
+    T = int(lens.max())
+    ids = np.zeros((B, T), dtype=np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n - 1] = rng.integers(32, 91, size=n - 1)
+        ids[b, n - 1] = 1
+    return ids, lens.astype(np.int64)
+
+
+def lstm_algorithmic(d, B):
+    """Algorithmic FLOPs / bytes of ONE decoder-LSTM launch, averaged over the three launches of a
+    decoder step (attention LSTM, LSTM 1, LSTM 2) -- DESIGN.md "Roofline accounting"."""
+    P2, E, A, D = d.prenet_units[-1], d.enc_units, d.attention_lstm_units, d.decoder_lstm_units
+    ks = [(P2 + E + A, A), (A + E + D, D), (D + D, D)]
+    flops = np.mean([2.0 * B * k * 4 * h for k, h in ks])
+    # weights + bias read once, activations read once, c r/w, h state r + w, raw h w
+    byts = np.mean([4.0 * (k * 4 * h + 4 * h + B * k + B * h * 5) for k, h in ks])
+    return float(flops), float(byts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--max-iters", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch1", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from tacotron2_amd.engine import Engine
+    from tacotron2_amd.hparams import PROFILE_P
+    from tacotron2_amd.weights import init_weights
+
+    d = PROFILE_P.replace(max_iters=args.max_iters)
+    w = init_weights(d, seed=1234)                       # same weights on every GPU
+    w["decoder/stop_token_projection/bias"] = np.array([-1e3], np.float32)   # decode runs to the cap
+    eng = Engine(d, w, device=local_rank)
+    B, S, r, M = args.batch, args.max_iters, d.outputs_per_step, d.num_mels
+    ids, lens = make_inputs(B, 60, 140, seed=1234 + 3 + 1000 * rank)       # each rank its own shard
+    T_in = ids.shape[1]
+    bufs = eng.decode_free_buffers(B, T_in, S)
+
+    def synth():
+        memory = eng.encode(ids, lens)
+        eng.decode_free_launch(memory, lens, S, d.min_iters, bufs)
+        n = eng.decode_free_finish()
+        mel = bufs[0][:, :n * r]
+        post = eng.postnet(mel)
+        return n, post
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        synth()
+    barrier()
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(args.steps):
+        n, _post = synth()
+        frames += B * n * r
+    barrier()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([dt, float(frames)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max, frames_all = float(tmax[0]), float(tot[1])
+    else:
+        dt_max, frames_all = dt, float(frames)
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "mel frames/sec (node), Tacotron2 free-running synthesis B=64 per GPU",
+            "value": frames_all / dt_max, "unit": "mel frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: Tacotron2 free-running synthesis, B=64 per GPU, "
+                                   "profile P (paper sizes), T_in~U{60..140}, decode to max_iters=%d steps (r=2 -> %d "
+                                   "frames/utterance), encoder + decoder + PostNetV2, random-init weights" % (S, S * r),
+                       "batch_per_gpu": B, "T_in": int(T_in), "decoder_steps": S,
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
+        }
+
+    # ---- roofline of the dominant kernel (decoder LSTM step) : live HIP-event timing, N=1 leg ----
+    if rank == 0:
+        memory = eng.encode(ids, lens)
+        eng.set_option("graph", 0)
+        eng.set_option("time_lstm", 1)
+        eng.decode_free_launch(memory, lens, min(S, 96), d.min_iters, eng.decode_free_buffers(B, T_in, min(S, 96)))
+        eng.decode_free_finish()
+        n_l, ms = eng.get_stat("lstm_launches"), eng.get_stat("lstm_ms")
+        eng.set_option("time_lstm", 0)
+        eng.set_option("graph", 1)
+        flops, byts = lstm_algorithmic(d, B)
+        avg_s = ms * 1e-3 / max(n_l, 1)
+        achieved = flops / avg_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("lstm_step_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"kernel": "lstm_step_kernel<4,false> (decoder LSTM step, B=64)", "bound": "mfma",
+                           "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                           "avg_launch_us": avg_s * 1e6, "launches_timed": int(n_l),
+                           "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
+                           "hbm_side": {"achieved_GBs": byts / avg_s / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                                        "frac": byts / avg_s / 1e9 / HBM_PEAK_GBS}}
+
+    # ---- batch-1 latency / RTF (BASELINE.json configs[1]) ----
+    if rank == 0 and not args.no_batch1:
+        ids1, lens1 = make_inputs(1, 100, 100, seed=1235)
+        b1 = eng.decode_free_buffers(1, 100, S)
+
+        def synth1():
+            mem = eng.encode(ids1, lens1)
+            eng.decode_free_launch(mem, lens1, S, d.min_iters, b1)
+            n = eng.decode_free_finish()
+            eng.postnet(b1[0][:, :n * r])
+            return n
+        synth1()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            n1 = synth1()
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / reps
+        out["batch1"] = {"frames": n1 * r, "ms": dt1 * 1e3, "frames_per_s": n1 * r / dt1,
+                         "rtf": dt1 / (n1 * r * FRAME_SHIFT_S), "us_per_decoder_step_incl_enc_post": dt1 * 1e6 / n1}
+
+    # ---- CPU baseline: the NumPy oracle on this box's host cores, bounded sample (N=1 only) ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import t2_oracle as O
+        try:
+            from threadpoolctl import threadpool_info
+            cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        except Exception:
+            cores = os.cpu_count() or 1
+        cores = min(cores, 16)
+        sample_steps = 20
+        t_a = time.perf_counter()
+        mem_o = O.encoder_v2(d, w, O.embedding_lookup(ids, w["embedding"]), lens)
+        t_b = time.perf_counter()
+        mel_o, _, _ = O.decoder_v2(d, w, mem_o, memory_sequence_length=lens, max_iters=sample_steps)
+        t_c = time.perf_counter()
+        O.postnet_v2(d, w, mel_o)
+        t_d = time.perf_counter()
+        scale = S / sample_steps
+        cpu_total = (t_b - t_a) + ((t_c - t_b) + (t_d - t_c)) * scale
+        out["cpu_baseline"] = {"value": B * S * r / cpu_total, "unit": "mel frames/s", "cores": int(cores),
+                               "kind": "port",
+                               "sample": "NumPy oracle (CPU restatement, not TensorFlow), same B=%d batch: encoder once "
+                                         "(%.2fs) + %d of %d decoder steps (%.2fs) + PostNetV2 on those %d frames/utt "
+                                         "(%.2fs); decoder and postnet time scaled x%.0f to the full %d steps"
+                                         % (B, t_b - t_a, sample_steps, S, t_c - t_b, sample_steps * r, t_d - t_c, scale, S)}
+        # parity spot check of the timed configuration: first sample_steps steps of the GPU decode
+        got = bufs[0][:, :sample_steps * r].cpu().numpy()
+        out["parity_check"] = {"max_abs_mel_diff_first_%d_steps" % sample_steps: float(np.abs(got - mel_o).max())}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,9 +145,12 @@ int t2_decode_free_launch(t2_model* m, const float* memory, const int64_t* lens,
                           int max_iters, int min_iters, float* mel, float* stop, float* align);
 int t2_decode_free_finish(t2_model* m, int* steps_out);
 
-/* Measurement hooks (no reference counterpart): HIP-event time of the last call's dominant
- * kernel class on the ctx stream. */
+/* Tuning / measurement hooks (no reference counterpart).  Options: "graph" (1: decode loops replay
+ * hipGraph chunks, 0: eager launches), "chunk" (decoder steps per graph, 1..64), "time_lstm" (1:
+ * record HIP events around every decoder LSTM launch in eager mode; resets the counters).
+ * Stats: "lstm_launches", "lstm_ms" (sum of event-timed launch durations, synchronises). */
 int t2_model_set_option(t2_model* m, const char* name, int value);
+int t2_model_get_stat(t2_model* m, const char* name, double* out);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ _SIGS = {
     "t2_model_finalize": (C.c_int, [_p]),
     "t2_model_destroy": (C.c_int, [_p]),
     "t2_model_set_option": (C.c_int, [_p, C.c_char_p, C.c_int]),
+    "t2_model_get_stat": (C.c_int, [_p, C.c_char_p, C.POINTER(C.c_double)]),
     "t2_encode": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p]),
     "t2_encode_embedded": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p]),
     "t2_postnet": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
@@ -74,6 +75,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build it with tacotron2_amd/csrc/build.sh "
                           "(there is no CPU fallback for the HIP path)")
+    # torch ships its own libamdhip64; import it first so that this library binds to the same HIP
+    # runtime instance (two runtimes in one process do not share devices, streams or pointers).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

@@ -172,7 +172,7 @@ __device__ __forceinline__ float red_sum(const f32x4* red, int row, int c) {
 // gate*4 + u), fused with the LSTMCell pointwise math and the inference-mode
 // zoneout blend of ZoneoutLSTMCell (reference tacotron/modules.py:261-283).
 // ------------------------------------------------------------------------------------------------
-template <int MB>
+template <int MB, bool ENC>   // ENC: encoder BiLSTM instance (own name in profiles; same code)
 __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore a, LstmEpi e) {
     const int t = step_index(a.ctl, a.step_off);
     if (t < 0) return;

@@ -96,6 +96,7 @@ struct t2_model {
     int* h_ctl = nullptr;               // pinned host mirror of a ctl block
     int opt_graph = 1;                  // use hipGraph chunks for decode loops
     int opt_chunk = 16;                 // steps per graph
+    int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
 };
 
 struct t2_state {
@@ -124,6 +125,14 @@ struct t2_state {
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     int gchunk[2] = {0, 0};
 };
+
+// optional HIP-event timing of the decoder LSTM launches (eager mode only; bench.py's roofline leg)
+struct LstmTimer {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    bool on = false;
+};
+static LstmTimer g_timer;
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -316,6 +325,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     if (!m || !name) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "graph")) m->opt_graph = value;
     else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
+    else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
     else return fail(T2_EINVAL, "unknown option %s", name);
     return T2_OK;
 }
@@ -460,10 +470,25 @@ static int check_batch(int B, int T) {
 
 static inline int mb_for(int B) { const int mb = ceil_div(B, 16); return mb == 3 ? 4 : mb; }
 
+template <bool ENC>
 static inline void launch_lstm(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const LstmEpi& e) {
-    if (MB == 1) hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
-    else if (MB == 2) hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
-    else hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+    if (MB == 1) hipLaunchKernelGGL((lstm_step_kernel<1, ENC>), grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+    else if (MB == 2) hipLaunchKernelGGL((lstm_step_kernel<2, ENC>), grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+    else hipLaunchKernelGGL((lstm_step_kernel<4, ENC>), grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+}
+
+static void timed_lstm(bool timing, int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const LstmEpi& e) {
+    if (timing) {
+        if (g_timer.used + 2 > g_timer.ev.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return; g_timer.ev.push_back(ev); }
+        }
+        (void)hipEventRecord(g_timer.ev[g_timer.used], st);
+        launch_lstm<false>(MB, grid, st, c, e);
+        (void)hipEventRecord(g_timer.ev[g_timer.used + 1], st);
+        g_timer.used += 2;
+    } else {
+        launch_lstm<false>(MB, grid, st, c, e);
+    }
 }
 static inline void launch_dense(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const DenseEpi& e) {
     if (MB == 1) hipLaunchKernelGGL(dense_step_kernel<1>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
@@ -570,7 +595,7 @@ static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, con
         c.nseg = 2; c.kbtot = m->enc_lstm[0].kbtot; c.ctl = ctl; c.step_off = s; c.B = B;
         e.H = He; e.Hld = He; e.hstate_pp_stride = hsz; e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         e.lens = d_lens; e.plain_out = memory_out; e.plain_bs = T * E; e.plain_ts = E;
-        launch_lstm(MB, dim3(m->enc_lstm[0].n_wg, 2), st, c, e);
+        launch_lstm<true>(MB, dim3(m->enc_lstm[0].n_wg, 2), st, c, e);
     }
     HIP_TRY(hipGetLastError());
     // h_lens / h_ids are host temporaries: make sure the async copies consumed them
@@ -839,7 +864,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         LstmEpi e{};
         e.H = A; e.c[0] = s->c_att; e.Hld = A; e.hstate[0] = s->h_att; e.hstate_pp_stride = s->h_att_sz; e.hraw[0] = s->h_att_raw;
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
-        launch_lstm(MB, dim3(m->att_lstm.n_wg, 1), st, c, e);
+        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->att_lstm.n_wg, 1), st, c, e);
     }
     // 4. processed query (tacotron_v2.py:122)
     {
@@ -868,7 +893,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         LstmEpi e{};
         e.H = D; e.c[0] = s->c1; e.Hld = D; e.hstate[0] = s->h1; e.hstate_pp_stride = s->h1_sz; e.hraw[0] = s->y1_raw;
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
-        launch_lstm(MB, dim3(m->lstm1.n_wg, 1), st, c, e);
+        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->lstm1.n_wg, 1), st, c, e);
     }
     {
         SkinnyCore c = core(m->lstm2);
@@ -877,7 +902,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         LstmEpi e{};
         e.H = D; e.c[0] = s->c2; e.Hld = D; e.hstate[0] = s->h2; e.hstate_pp_stride = s->h2_sz; e.hraw[0] = s->y2_raw;
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
-        launch_lstm(MB, dim3(m->lstm2.n_wg, 1), st, c, e);
+        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->lstm2.n_wg, 1), st, c, e);
     }
     // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
     {
@@ -1088,4 +1113,21 @@ extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* l
     for (int i = 0; i < 2; ++i) hipEventDestroy(ev[i]);
     hipHostFree(h_flag);
     return rc;
+}
+
+extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
+    if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
+    if (!strcmp(name, "lstm_launches")) { *out = (double)(g_timer.used / 2); return T2_OK; }
+    if (!strcmp(name, "lstm_ms")) {
+        HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+        double sum = 0;
+        for (size_t i = 0; i + 1 < g_timer.used; i += 2) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, g_timer.ev[i], g_timer.ev[i + 1]));
+            sum += ms;
+        }
+        *out = sum;
+        return T2_OK;
+    }
+    return fail(T2_EINVAL, "unknown stat %s", name);
 }

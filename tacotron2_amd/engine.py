@@ -113,6 +113,11 @@ class Engine:
     def set_option(self, name: str, value: int):
         _lib.check(self.lib.t2_model_set_option(self._model, name.encode(), int(value)))
 
+    def get_stat(self, name: str) -> float:
+        v = C.c_double(0)
+        _lib.check(self.lib.t2_model_get_stat(self._model, name.encode(), C.byref(v)))
+        return v.value
+
     def _f32(self, x) -> torch.Tensor:
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x, dtype=np.float32))
