@@ -45,19 +45,24 @@ __device__ __forceinline__ int step_index(const int* __restrict__ ctl, int step_
     return t;
 }
 
-struct SegDesc {
-    const float* base;   // frag16 buffer
-    int kb;              // k-blocks of 16
-    int pp_stride;       // floats; buffer used = base + (t & 1) * pp_stride   (ping-pong state)
-    int t_stride;        // floats; buffer used += t * t_stride                (time-indexed input)
-    int pp_flip;         // 1: use ((t+1)&1) instead of (t&1)
+// A-operand source: frag16 buffer with time slots.  address = base + ((t + dt) % nslots) * slot_stride
+struct FragBuf {
+    float* base;
+    int slot_stride;     // floats
+    int nslots;          // 1: single buffer, 2: ping-pong state, T: time-indexed input
+    int dt;              // slot = (t + dt) % nslots
+    int koff;            // first k (multiple of 16 for sources; any for destinations)
 };
+
+__device__ __forceinline__ float* frag_slot(const FragBuf& f, int t) {
+    return f.base + (size_t)((t + f.dt) % f.nslots) * f.slot_stride;
+}
 
 struct SkinnyCore {
     const float* w[2];        // packed weights per direction (blockIdx.y)
-    const float* bias[2];     // packed bias [n_wg][16] (may be null)
-    SegDesc seg[2][T2_MAX_SEG];
-    int nseg;
+    const float* bias[2];     // LSTM: packed [n_wg][16]; dense: [N] (may be null)
+    FragBuf seg[2][2];        // per direction: k-blocks [0,kb0) from seg[.][0], [kb0,kbtot) from seg[.][1]
+    int kb0;
     int kbtot;
     const int* ctl;
     int step_off;
@@ -68,21 +73,25 @@ struct LstmEpi {
     int H;                    // hidden units
     float* c[2];              // plain [MB*16][Hld]
     int Hld;
-    float* hstate[2];         // frag16 ping-pong: read (t&1), write ((t+1)&1)
-    int hstate_pp_stride;
-    float* hraw[2];           // frag16 raw output (layer output), may be null
+    FragBuf hprev[2];         // previous state h (for the zoneout blend), per direction
+    FragBuf hstate[2];        // new state h destination
+    FragBuf hraw[2];          // raw output destination (base may be null)
     float zc, zh, fb;
     const int* lens;          // optional sequence lengths (encoder), device int32 [B]
     float* plain_out;         // optional plain output [B][T][ld]
     int plain_bs, plain_ts;   // batch / time strides (floats)
     int plain_off[2];         // column offset per direction
     int reverse[2];           // direction writes to position len-1-t
+    // fused partial query (attention LSTM only): qpart[wg][row][u] = sum_uu h[row][4wg+uu] * wq[4wg+uu][u]
+    const float* wq;          // [A][U] or null
+    float* qpart;             // [n_wg][MB*16][U]
+    int U;
 };
 
 struct DenseEpi {
     int N;                    // valid columns
     int relu;
-    float* out_frag;          // frag16 output (k = col - frag_col0), may be null
+    FragBuf out_frag;         // frag16 destination (k = koff + col - frag_col0), base may be null
     int frag_col0;
     float* out_plain;         // plain [row][ld] (+ t * plain_t_stride), may be null
     int plain_ld;
@@ -90,9 +99,9 @@ struct DenseEpi {
     int plain_ncol;           // columns < plain_ncol go to out_plain
     // stop token handling (projection kernel): column stop_col holds the stop logit
     int stop_col;             // -1: none
-    float* out_stop;          // [row * stop_ld + t]
+    float* out_stop;          // [row * stop_ld + t * stop_t_mul]
     int stop_ld;
-    int stop_t_mul;           // 1: index row*stop_ld + t, 0: index row*stop_ld
+    int stop_t_mul;
     int* ctl_w;               // writable ctl (same block as core.ctl)
 };
 
@@ -100,58 +109,83 @@ struct DenseEpi {
 // skinny GEMM core: acc[rb] (16x16 tile, rows = batch rows of block rb, cols = this workgroup's 16
 // columns) += X[:, k-range of this wave] . W[k-range, cols].  The K range is split over the 8 waves
 // of the workgroup; every wave streams its part of the packed weight slab once, straight to
-// registers (no LDS round trip: the operand is not shared between waves).
+// registers (no LDS round trip: the operand is not shared between waves), in register-double-
+// buffered groups of G k-blocks so that the next group's loads are in flight under the MFMAs.
 // ------------------------------------------------------------------------------------------------
+template <int MB, int G>
+struct KGroup {
+    f32x4 b[G];
+    f32x4 a[G][MB];
+};
+
+template <int MB, int G>
+__device__ __forceinline__ void kg_load(KGroup<MB, G>& g, const f32x4* __restrict__ wp, const f32x4* __restrict__ ap, int kb, int kba) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        g.b[u] = __builtin_nontemporal_load(wp + (size_t)(kb + u) * 64);
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) g.a[u][rb] = ap[(size_t)((kba + u) * MB + rb) * 64];
+    }
+}
+
+template <int MB, int G>
+__device__ __forceinline__ void kg_mma(const KGroup<MB, G>& g, f32x4 (&acc)[MB]) {
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.a[u][rb][j], g.b[u][j], acc[rb], 0, 0, 0);
+}
+
+// k-blocks [lo, hi) of the weight slab; the A operand block index is (kb - ka_off)
+template <int MB, int G>
+__device__ __forceinline__ void skinny_range(const f32x4* __restrict__ wp, const f32x4* __restrict__ ap, int lo, int hi,
+                                             int ka_off, f32x4 (&acc)[MB]) {
+    const int n = hi - lo;
+    if (n <= 0) return;
+    const int nfull = n / G;
+    if (nfull > 0) {
+        KGroup<MB, G> g0, g1;
+        kg_load<MB, G>(g0, wp, ap, lo, lo - ka_off);
+        int g = 0;
+        for (; g + 2 <= nfull; g += 2) {
+            const int k1 = lo + (g + 1) * G;
+            kg_load<MB, G>(g1, wp, ap, k1, k1 - ka_off);
+            kg_mma<MB, G>(g0, acc);
+            // unconditional (clamped) prefetch keeps the wait counts static: the last one re-reads a group
+            const int k2 = lo + min(g + 2, nfull - 1) * G;
+            kg_load<MB, G>(g0, wp, ap, k2, k2 - ka_off);
+            kg_mma<MB, G>(g1, acc);
+        }
+        if (g < nfull) kg_mma<MB, G>(g0, acc);
+    }
+    for (int kb = lo + nfull * G; kb < hi; ++kb) {
+        KGroup<MB, 1> g;
+        kg_load<MB, 1>(g, wp, ap, kb, kb - ka_off);
+        kg_mma<MB, 1>(g, acc);
+    }
+}
+
 template <int MB>
 __device__ __forceinline__ void skinny_core(const SkinnyCore& a, int dir, int t, f32x4 (&acc)[MB]) {
+    constexpr int G = (MB >= 4) ? 2 : 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int per = (a.kbtot + T2_SKINNY_WAVES - 1) / T2_SKINNY_WAVES;
-    const int lo = wave * per;
-    const int hi = min(a.kbtot, lo + per);
+    const int base = a.kbtot / T2_SKINNY_WAVES, rem = a.kbtot % T2_SKINNY_WAVES;
+    const int lo = wave * base + min(wave, rem);
+    const int hi = lo + base + (wave < rem ? 1 : 0);
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.w[dir]) + (size_t)blockIdx.x * a.kbtot * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int kb0 = 0;
-    for (int s = 0; s < a.nseg; ++s) {
-        const SegDesc& sd = a.seg[dir][s];
-        const int s_lo = max(lo, kb0), s_hi = min(hi, kb0 + sd.kb);
-        if (s_lo < s_hi) {
-            const int par = sd.pp_flip ? ((t + 1) & 1) : (t & 1);
-            const f32x4* __restrict__ ap = reinterpret_cast<const f32x4*>(
-                sd.base + (size_t)par * sd.pp_stride + (size_t)t * sd.t_stride) + lane;
-            int kb = s_lo;
-            constexpr int UN = (MB <= 2) ? 8 : 4;
-            for (; kb + UN <= s_hi; kb += UN) {
-                f32x4 b[UN];
-                f32x4 av[UN][MB];
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    b[u] = __builtin_nontemporal_load(wp + (size_t)(kb + u) * 64);
-#pragma unroll
-                    for (int rb = 0; rb < MB; ++rb) av[u][rb] = ap[(size_t)((kb + u - kb0) * MB + rb) * 64];
-                }
-#pragma unroll
-                for (int u = 0; u < UN; ++u)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int rb = 0; rb < MB; ++rb)
-                            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rb][j], b[u][j], acc[rb], 0, 0, 0);
-            }
-            for (; kb < s_hi; ++kb) {
-                const f32x4 b = __builtin_nontemporal_load(wp + (size_t)kb * 64);
-                f32x4 av[MB];
-#pragma unroll
-                for (int rb = 0; rb < MB; ++rb) av[rb] = ap[(size_t)((kb - kb0) * MB + rb) * 64];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int rb = 0; rb < MB; ++rb)
-                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][j], b[j], acc[rb], 0, 0, 0);
-            }
-        }
-        kb0 += sd.kb;
+    if (lo < a.kb0) {
+        const f32x4* ap = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][0], t)) + (size_t)(a.seg[dir][0].koff >> 4) * MB * 64 + lane;
+        skinny_range<MB, G>(wp, ap, lo, min(hi, a.kb0), 0, acc);
+    }
+    if (hi > a.kb0) {
+        const f32x4* ap = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][1], t)) + (size_t)(a.seg[dir][1].koff >> 4) * MB * 64 + lane;
+        skinny_range<MB, G>(wp, ap, max(lo, a.kb0), hi, a.kb0, acc);
     }
 }
 
@@ -168,9 +202,10 @@ __device__ __forceinline__ float red_sum(const f32x4* red, int row, int c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LSTM step: gates = [x-segments | h_prev] . kernel + bias for 4 hidden units per workgroup (columns
-// gate*4 + u), fused with the LSTMCell pointwise math and the inference-mode
-// zoneout blend of ZoneoutLSTMCell (reference tacotron/modules.py:261-283).
+// LSTM step: gates = [x | h_prev] . kernel + bias for 4 hidden units per workgroup (columns
+// gate*4 + u), fused with the LSTMCell pointwise math, the inference-mode
+// zoneout blend of ZoneoutLSTMCell (reference tacotron/modules.py:261-283) and, for the attention
+// LSTM, this workgroup's share of the attention query projection (tacotron_v2.py:122).
 // ------------------------------------------------------------------------------------------------
 template <int MB, bool ENC>   // ENC: encoder BiLSTM instance (own name in profiles; same code)
 __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore a, LstmEpi e) {
@@ -178,6 +213,7 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
     if (t < 0) return;
     const int dir = blockIdx.y;
     __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
+    __shared__ float s_h[MB * 16 * 4];
     f32x4 acc[MB];
     skinny_core<MB>(a, dir, t, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -185,46 +221,60 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
     __syncthreads();
     const int idx = threadIdx.x;
-    if (idx >= MB * 16 * 4) return;
-    const int row = idx >> 2, uu = idx & 3;
-    const int unit = blockIdx.x * 4 + uu;
-    if (row >= a.B || unit >= e.H) return;
-    const float* bias = a.bias[dir] + (size_t)blockIdx.x * 16;
-    const float zi = red_sum<MB>(red, row, 0 * 4 + uu) + bias[0 * 4 + uu];
-    const float zj = red_sum<MB>(red, row, 1 * 4 + uu) + bias[1 * 4 + uu];
-    const float zf = red_sum<MB>(red, row, 2 * 4 + uu) + bias[2 * 4 + uu];
-    const float zo = red_sum<MB>(red, row, 3 * 4 + uu) + bias[3 * 4 + uu];
-    float* cptr = e.c[dir] + (size_t)row * e.Hld + unit;
-    const size_t fi = frag_idx(row, unit, MB);
-    const float* hin = e.hstate[dir] + (size_t)(t & 1) * e.hstate_pp_stride;
-    float* hout = e.hstate[dir] + (size_t)((t + 1) & 1) * e.hstate_pp_stride;
-    const float cp = *cptr;
-    const float hp = hin[fi];
-    const float cn = sigmoidf_(zf + e.fb) * cp + sigmoidf_(zi) * tanhf(zj);
-    float hn = sigmoidf_(zo) * tanhf(cn);
-    float cs = (1.0f - e.zc) * cn + e.zc * cp;
-    float hs = (1.0f - e.zh) * hn + e.zh * hp;
-    bool live = true;
-    int len = 0;
-    if (e.lens != nullptr) {
-        len = e.lens[row];
-        live = t < len;
-        if (!live) { cs = cp; hs = hp; hn = 0.f; }   // dynamic_rnn: zero output, state copied through
+    if (idx < MB * 16 * 4) {
+        const int row = idx >> 2, uu = idx & 3;
+        const int unit = blockIdx.x * 4 + uu;
+        float hn = 0.f;
+        if (row < a.B && unit < e.H) {
+            const float* bias = a.bias[dir] + (size_t)blockIdx.x * 16;
+            const float zi = red_sum<MB>(red, row, 0 * 4 + uu) + bias[0 * 4 + uu];
+            const float zj = red_sum<MB>(red, row, 1 * 4 + uu) + bias[1 * 4 + uu];
+            const float zf = red_sum<MB>(red, row, 2 * 4 + uu) + bias[2 * 4 + uu];
+            const float zo = red_sum<MB>(red, row, 3 * 4 + uu) + bias[3 * 4 + uu];
+            float* cptr = e.c[dir] + (size_t)row * e.Hld + unit;
+            const float cp = *cptr;
+            const float hp = frag_slot(e.hprev[dir], t)[frag_idx(row, e.hprev[dir].koff + unit, MB)];
+            const float cn = sigmoidf_(zf + e.fb) * cp + sigmoidf_(zi) * tanhf(zj);
+            hn = sigmoidf_(zo) * tanhf(cn);
+            float cs = (1.0f - e.zc) * cn + e.zc * cp;
+            float hs = (1.0f - e.zh) * hn + e.zh * hp;
+            bool live = true;
+            int len = 0;
+            if (e.lens != nullptr) {
+                len = e.lens[row];
+                live = t < len;
+                if (!live) { cs = cp; hs = hp; hn = 0.f; }   // dynamic_rnn: zero output, state copied through
+            }
+            *cptr = cs;
+            frag_slot(e.hstate[dir], t)[frag_idx(row, e.hstate[dir].koff + unit, MB)] = hs;
+            if (e.hraw[dir].base != nullptr) frag_slot(e.hraw[dir], t)[frag_idx(row, e.hraw[dir].koff + unit, MB)] = hn;
+            if (e.plain_out != nullptr && live) {
+                const int tpos = e.reverse[dir] ? (len - 1 - t) : t;
+                e.plain_out[(size_t)row * e.plain_bs + (size_t)tpos * e.plain_ts + e.plain_off[dir] + unit] = hn;
+            }
+        }
+        if (!ENC) s_h[idx] = hn;
     }
-    *cptr = cs;
-    hout[fi] = hs;
-    if (e.hraw[dir] != nullptr) e.hraw[dir][fi] = hn;
-    if (e.plain_out != nullptr && live) {
-        const int tpos = e.reverse[dir] ? (len - 1 - t) : t;
-        e.plain_out[(size_t)row * e.plain_bs + (size_t)tpos * e.plain_ts + e.plain_off[dir] + unit] = hn;
+    if (!ENC) {
+        if (e.wq == nullptr) return;
+        __syncthreads();
+        const int U = e.U;
+        const float* wq = e.wq + (size_t)blockIdx.x * 4 * U;
+        const int nvalid = min(4, e.H - (int)blockIdx.x * 4);
+        float* qp = e.qpart + (size_t)blockIdx.x * MB * 16 * U;
+        for (int i = threadIdx.x; i < MB * 16 * U; i += T2_SKINNY_THREADS) {
+            const int row = i / U, u = i - row * U;
+            float s = 0.f;
+            for (int uu = 0; uu < nvalid; ++uu) s = fmaf(s_h[row * 4 + uu], wq[uu * U + u], s);
+            qp[i] = s;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Dense step: y = act(x . W + b) for 16 columns per workgroup.  Used for the PreNet layers
-// (modules.py:88-91), the attention query layer (tacotron_v2.py:122) and the mel / stop projections
-// (rnn_wrappers.py:105-109) together with the stop rule of StopTokenBasedInferenceHelper
-// (helpers.py:90-94) evaluated on the device.
+// (modules.py:88-91) and the mel / stop projections (rnn_wrappers.py:105-109) together with the
+// stop rule of StopTokenBasedInferenceHelper (helpers.py:90-94) evaluated on the device.
 // ------------------------------------------------------------------------------------------------
 template <int MB>
 __global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCore a, DenseEpi e) {
@@ -240,6 +290,7 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCor
     if (threadIdx.x == 0) s_notstop = 0;
     __syncthreads();
     const bool has_stop = e.stop_col >= 0 && (e.stop_col >> 4) == (int)blockIdx.x;
+    float* ofrag = e.out_frag.base ? frag_slot(e.out_frag, t) : nullptr;
     for (int idx = threadIdx.x; idx < MB * 16 * 16; idx += T2_SKINNY_THREADS) {
         const int row = idx >> 4, c = idx & 15;
         const int col = blockIdx.x * 16 + c;
@@ -254,7 +305,7 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCor
         }
         if (e.out_plain != nullptr && col < e.plain_ncol)
             e.out_plain[(size_t)row * e.plain_ld + (size_t)t * e.plain_t_stride + col] = v;
-        if (e.out_frag != nullptr && col >= e.frag_col0) e.out_frag[frag_idx(row, col - e.frag_col0, MB)] = v;
+        if (ofrag != nullptr && col >= e.frag_col0) ofrag[frag_idx(row, e.out_frag.koff + col - e.frag_col0, MB)] = v;
     }
     if (has_stop) {
         __syncthreads();
@@ -270,6 +321,10 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCor
 // Location-sensitive attention step for one batch row per workgroup
 // (reference tacotron/tacotron_v2.py:118-141, _location_sensitive_score :66-78; BahdanauAttention
 // masking / softmax and AttentionWrapper context: SURVEY.md App. A5/A6).
+// Phases: (0) previous (cumulative) alignments, conv kernel and the processed query (sum of the
+// attention LSTM workgroups' partial products) into LDS; (1) location conv with a register sliding
+// window; (2) energies: one wave per position, lanes over attention units, location-layer columns
+// held in registers, wavefront-reduction over units; (3) masked softmax; (4) context.
 // ------------------------------------------------------------------------------------------------
 struct AttnArgs {
     const float* keys;      // [B][T][U]
@@ -278,8 +333,9 @@ struct AttnArgs {
     float* att_state;       // [B][T] in/out: cumulative alignments (or previous alignments)
     float* alignments;      // [B][T] out
     float* history;         // [cap][B][T] or null
-    const float* q;         // [B][U] processed query
-    float* ctx_frag;        // frag16 [E] out
+    const float* qpart;     // [nparts][MB*16][U] partial processed queries
+    int nparts;
+    FragBuf ctx_dst[2];     // frag16 destinations of the context (base may be null)
     float* ctx_plain;       // [B][E] out (state readout), may be null
     const float* conv_w;    // [K][F]
     const float* conv_b;    // [F]
@@ -293,54 +349,144 @@ struct AttnArgs {
 
 #define T2_ATTN_THREADS 512
 
+__host__ __device__ inline int attn_lds_floats(int T, int U, int F, int K) {
+    const int FP = (F + 3) & ~3, KP = (K + 3) & ~3;
+    return ((T + KP + 16 + 3) & ~3) + KP * FP + ((T + 8) * FP) + ((T + 3) & ~3) + 2 * ((U + 3) & ~3) * 4 + 64;
+}
+
+template <int FMAX, int UPL>
 __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArgs a) {
     const int t_step = step_index(a.ctl, a.step_off);
     if (t_step < 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     const int T = a.T, U = a.U, F = a.F, K = a.K, E = a.E;
+    const int FP = (F + 3) & ~3, KP = (K + 3) & ~3;
     const int pad_l = (K - 1) / 2;
-    // LDS carve
-    float* s_prev = smem;                       // [T + K] with halo (index i <-> position i - pad_l)
-    float* s_f = s_prev + ((T + K + 3) & ~3);   // [T][F]
-    float* s_wloc = s_f + ((T * F + 3) & ~3);   // [F][U]
-    float* s_e = s_wloc + ((F * U + 3) & ~3);   // [T] energies -> alignments
-    float* s_red = s_e + ((T + 3) & ~3);        // [32]
+    const int UP = (U + 3) & ~3;
+    float* s_prev = smem;                               // [T + KP + 16]: index i <-> position i - pad_l
+    float* s_cw = s_prev + ((T + KP + 16 + 3) & ~3);    // [KP][FP] conv kernel, zero padded
+    float* s_f = s_cw + KP * FP;                        // [T + 8][FP]
+    float* s_e = s_f + (T + 8) * FP;                    // [T]
+    float* s_q = s_e + ((T + 3) & ~3);                  // [4][UP] partial sums, then [0][:] = q + b_a
+    float* s_red = s_q + 8 * UP;                        // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NW = T2_ATTN_THREADS / 64;
+    constexpr int NW = T2_ATTN_THREADS / 64;
     const int len = a.lens[b];
     float* state = a.att_state + (size_t)b * T;
-    for (int i = tid; i < T + K; i += T2_ATTN_THREADS) {
+    // ---- phase 0 ----
+    for (int i = tid; i < T + KP + 16; i += T2_ATTN_THREADS) {
         const int p = i - pad_l;
         s_prev[i] = (p >= 0 && p < T) ? state[p] : 0.f;
     }
-    for (int i = tid; i < F * U; i += T2_ATTN_THREADS) s_wloc[i] = a.wloc[i];
-    __syncthreads();
-    // location features f[t][c] = sum_j w[j][c] * prev[t + j - pad_l] + b[c]   (:128-130)
-    for (int i = tid; i < T * F; i += T2_ATTN_THREADS) {
-        const int tt = i / F, c = i - tt * F;
-        float s = 0.f;
-        for (int j = 0; j < K; ++j) s = fmaf(a.conv_w[j * F + c], s_prev[tt + j], s);
-        s_f[i] = s + a.conv_b[c];
+    for (int i = tid; i < KP * FP; i += T2_ATTN_THREADS) {
+        const int j = i / FP, c = i - j * FP;
+        s_cw[i] = (j < K && c < F) ? a.conv_w[j * F + c] : 0.f;
     }
-    __syncthreads();
-    // energies: one wave per position, lanes over attention units   (:131-133, :66-78)
-    const float* keys = a.keys + (size_t)b * T * U;
-    const float* q = a.q + (size_t)b * U;
-    for (int tt = wave; tt < T; tt += NW) {
-        float part = 0.f;
-        const float* ft = s_f + tt * F;
-        for (int u = lane; u < U; u += 64) {
-            float pf = 0.f;
-            for (int c = 0; c < F; ++c) pf = fmaf(ft[c], s_wloc[c * U + u], pf);
-            part += a.v_a[u] * tanhf(keys[(size_t)tt * U + u] + q[u] + pf + a.b_a[u]);
+    {   // processed query: sum over the attention-LSTM workgroups' partial products
+        const int QG = min(4, T2_ATTN_THREADS / U);
+        if (tid < QG * U) {
+            const int g = tid / U, u = tid - g * U;
+            const float* qp = a.qpart + (size_t)b * U + u;
+            const size_t pstride = (size_t)a.MB * 16 * U;
+            float s0 = 0.f, s1 = 0.f;
+            int p = g;
+            for (; p + QG < a.nparts; p += 2 * QG) {
+                s0 += qp[(size_t)p * pstride];
+                s1 += qp[(size_t)(p + QG) * pstride];
+            }
+            if (p < a.nparts) s0 += qp[(size_t)p * pstride];
+            s_q[g * UP + u] = s0 + s1;
         }
+    }
+    // location-layer columns of this lane's attention units, in registers
+    float wl[FMAX][UPL];
+    float va[UPL], kq[UPL];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-        if (lane == 0) s_e[tt] = part;
+    for (int i = 0; i < UPL; ++i) {
+        const int u = lane + 64 * i;
+        va[i] = (u < U) ? a.v_a[u] : 0.f;
+#pragma unroll
+        for (int c = 0; c < FMAX; ++c) wl[c][i] = (c < F && u < U) ? a.wloc[c * U + u] : 0.f;
     }
     __syncthreads();
-    // masked softmax over positions < len (score mask value -inf -> probability exactly 0)
+    {
+        const int QG = min(4, T2_ATTN_THREADS / U);
+        if (tid < U) {
+            float s = a.b_a[tid];
+            for (int g = 0; g < QG; ++g) s += s_q[g * UP + tid];
+            s_q[4 * UP + tid] = s;          // q[u] + b_a[u]
+        }
+    }
+    // ---- phase 1: location features f[t][c] = sum_j w[j][c] * prev[t + j - pad_l] + b[c]   (:128-130)
+    {
+        const int nblk = (T + 7) >> 3;
+        for (int item = tid; item < nblk * F; item += T2_ATTN_THREADS) {
+            const int c = item % F, t0 = (item / F) << 3;
+            float accv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) accv[i] = 0.f;
+            float win[12];
+            {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_prev + t0);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_prev + t0 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { win[i] = w0[i]; win[4 + i] = w1[i]; }
+            }
+            for (int j0 = 0; j0 < KP; j0 += 4) {
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_prev + t0 + j0 + 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) win[8 + i] = w2[i];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float w = s_cw[(j0 + jj) * FP + c];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) accv[i] = fmaf(w, win[i + jj], accv[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) win[i] = win[i + 4];
+            }
+            const float bc = a.conv_b[c];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s_f[(t0 + i) * FP + c] = accv[i] + bc;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: energies   (:131-133, :66-78)
+    {
+        const float* keys = a.keys + (size_t)b * T * U;
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) { const int u = lane + 64 * i; kq[i] = (u < U) ? s_q[4 * UP + u] : 0.f; }
+        for (int tt = wave; tt < T; tt += NW) {
+            float pf[UPL];
+            float kv[UPL];
+#pragma unroll
+            for (int i = 0; i < UPL; ++i) {
+                const int u = lane + 64 * i;
+                pf[i] = 0.f;
+                kv[i] = (u < U) ? keys[(size_t)tt * U + u] : 0.f;
+            }
+            const float* ft = s_f + tt * FP;
+#pragma unroll
+            for (int c4 = 0; c4 < FMAX; c4 += 4) {
+                if (c4 < FP) {
+                    const f32x4 fv = *reinterpret_cast<const f32x4*>(ft + c4);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                        for (int i = 0; i < UPL; ++i) pf[i] = fmaf(fv[cc], wl[c4 + cc][i], pf[i]);
+                }
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < UPL; ++i) part += va[i] * tanhf(kv[i] + kq[i] + pf[i]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) s_e[tt] = part;
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: masked softmax over positions < len (score mask value -inf -> probability exactly 0)
     float m = -INFINITY;
     for (int i = tid; i < len; i += T2_ATTN_THREADS) m = fmaxf(m, s_e[i]);
 #pragma unroll
@@ -349,7 +495,6 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
     __syncthreads();
     m = s_red[0];
     for (int w = 1; w < NW; ++w) m = fmaxf(m, s_red[w]);
-    __syncthreads();
     float sum = 0.f;
     for (int i = tid; i < T; i += T2_ATTN_THREADS) {
         const float ex = (i < len) ? expf(s_e[i] - m) : 0.f;
@@ -358,10 +503,10 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    if (lane == 0) s_red[wave] = sum;
+    if (lane == 0) s_red[32 + wave] = sum;
     __syncthreads();
     sum = 0.f;
-    for (int w = 0; w < NW; ++w) sum += s_red[w];
+    for (int w = 0; w < NW; ++w) sum += s_red[32 + w];
     float* al = a.alignments + (size_t)b * T;
     float* hist = a.history ? a.history + ((size_t)t_step * a.B + b) * T : nullptr;
     for (int i = tid; i < T; i += T2_ATTN_THREADS) {
@@ -372,18 +517,23 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         state[i] = a.cumulative ? (p + s_prev[i + pad_l]) : p;      // :137-140
     }
     __syncthreads();
-    // context = alignments . values   (AttentionWrapper._compute_attention)
+    // ---- phase 4: context = alignments . values   (AttentionWrapper._compute_attention)
     const float* vals = a.values + (size_t)b * T * E;
+    float* d0 = a.ctx_dst[0].base ? frag_slot(a.ctx_dst[0], t_step) : nullptr;
+    float* d1 = a.ctx_dst[1].base ? frag_slot(a.ctx_dst[1], t_step) : nullptr;
     for (int c = tid; c < E; c += T2_ATTN_THREADS) {
-        float s0 = 0.f, s1 = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int i = 0;
-        for (; i + 1 < len; i += 2) {
+        for (; i + 3 < len; i += 4) {
             s0 = fmaf(s_e[i], vals[(size_t)i * E + c], s0);
             s1 = fmaf(s_e[i + 1], vals[(size_t)(i + 1) * E + c], s1);
+            s2 = fmaf(s_e[i + 2], vals[(size_t)(i + 2) * E + c], s2);
+            s3 = fmaf(s_e[i + 3], vals[(size_t)(i + 3) * E + c], s3);
         }
-        if (i < len) s0 = fmaf(s_e[i], vals[(size_t)i * E + c], s0);
-        const float s = s0 + s1;
-        a.ctx_frag[frag_idx(b, c, a.MB)] = s;
+        for (; i < len; ++i) s0 = fmaf(s_e[i], vals[(size_t)i * E + c], s0);
+        const float s = (s0 + s1) + (s2 + s3);
+        if (d0) d0[frag_idx(b, a.ctx_dst[0].koff + c, a.MB)] = s;
+        if (d1) d1[frag_idx(b, a.ctx_dst[1].koff + c, a.MB)] = s;
         if (a.ctx_plain) a.ctx_plain[(size_t)b * E + c] = s;
     }
 }
@@ -396,7 +546,7 @@ struct FeedArgs {
     const float* src;         // plain base
     long long row_stride;     // floats between batch rows
     long long t_stride;       // floats between steps: source of step t is src + (t-1) * t_stride
-    float* dst;               // frag16 [K]
+    FragBuf dst;              // frag16 destination
     int B, K, MB;
     int go_zero;              // 1: step 0 writes zeros (go frame), steps t >= 1 read step t-1's slice
     const int* ctl;
@@ -418,7 +568,7 @@ __global__ void feed_frames_kernel(FeedArgs a) {
                 v = a.src[(size_t)row * a.row_stride + (size_t)t * a.t_stride + k];
             }
         }
-        a.dst[frag_idx(row, k, a.MB)] = v;
+        frag_slot(a.dst, t)[frag_idx(row, a.dst.koff + k, a.MB)] = v;
     }
 }
 
@@ -471,10 +621,10 @@ __global__ void seq_to_frag_kernel(const float* __restrict__ x, const int* __res
 }
 
 // frag16 -> plain [B][K] (state readout for tests / RNNCell-protocol callers)
-__global__ void frag_to_plain_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int K, int MB) {
+__global__ void frag_to_plain_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int K, int MB, int koff) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * K; i += gridDim.x * blockDim.x) {
         const int row = i / K, k = i - row * K;
-        dst[i] = src[frag_idx(row, k, MB)];
+        dst[i] = src[frag_idx(row, koff + k, MB)];
     }
 }
 

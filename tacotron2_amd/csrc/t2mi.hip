@@ -85,7 +85,8 @@ struct t2_model {
     ConvLayer post_proj, memory_layer;
     Packed enc_lstm[2];
     Packed prenet[T2_MAX_PRENET_LAYERS];
-    Packed att_lstm, lstm1, lstm2, query, proj;
+    Packed att_lstm, lstm1, lstm2, proj;
+    float *wq = nullptr;                // query layer kernel [A][U], plain
     float *conv_w = nullptr, *conv_b = nullptr, *wloc = nullptr, *v_a = nullptr, *b_a = nullptr;
     // cached workspaces
     std::vector<t2_state*> states;      // decode states owned by the model (cache)
@@ -110,13 +111,14 @@ struct t2_state {
     float *values = nullptr, *keys = nullptr;
     int* lens = nullptr;
     // zeroable
-    float *att_state = nullptr, *alignments = nullptr, *ctx_frag = nullptr, *ctx_plain = nullptr, *q = nullptr;
+    float *att_state = nullptr, *alignments = nullptr, *ctx_plain = nullptr, *qpart = nullptr;
     float *c_att = nullptr, *c1 = nullptr, *c2 = nullptr;
-    float *h_att = nullptr, *h1 = nullptr, *h2 = nullptr;        // frag16 ping-pong (2x)
-    float *h_att_raw = nullptr, *y1_raw = nullptr, *y2_raw = nullptr;
-    float* xin = nullptr;                                        // prev frames frag16
+    // frag16 operand buffers (see launch_step): XA = [ctx | h_att] x2 slots, X1 = [h_att_raw | ctx | h1] x2,
+    // X2 = [y1_raw | h2] x2, XY = y2_raw, xf = decoder input frames, xp[i] = prenet outputs
+    float *XA = nullptr, *X1 = nullptr, *X2 = nullptr, *XY = nullptr, *xf = nullptr;
     float* xp[T2_MAX_PRENET_LAYERS] = {nullptr, nullptr, nullptr, nullptr};
-    int h_att_sz = 0, h1_sz = 0, h2_sz = 0;
+    int XA_sz = 0, X1_sz = 0, X2_sz = 0;         // floats per slot
+    int KBe = 0, KBa = 0, KBd = 0;
     int* ctl = nullptr;
     // output staging (graph-stable addresses)
     float *o_mel = nullptr, *o_stop = nullptr, *o_hist = nullptr, *i_targets = nullptr;
@@ -359,7 +361,7 @@ extern "C" int t2_model_finalize(t2_model* m) {
     m->memory_layer.k = 1; m->memory_layer.cin = E; m->memory_layer.cout = U;
     T2_TRY(upload(m, &m->memory_layer.w, w->data));
     T2_TRY(get_w(m, "attention/query_layer/kernel", &w, {A, U}));
-    T2_TRY(pack_skinny(m, &m->query, w->data.data(), U, {{0, A}}, 0, U, nullptr));
+    T2_TRY(upload(m, &m->wq, w->data));
     T2_TRY(get_w(m, "attention/location_features_convolution/kernel", &w, {K, 1, F}));
     T2_TRY(upload(m, &m->conv_w, w->data));
     T2_TRY(get_w(m, "attention/location_features_convolution/bias", &w, {F}));
@@ -415,7 +417,10 @@ extern "C" int t2_model_finalize(t2_model* m) {
     T2_TRY(upload(m, &m->post_proj.w, w->data));
     T2_TRY(upload(m, &m->post_proj.shift, b->data));
     HIP_TRY(hipHostMalloc((void**)&m->h_ctl, 8 * sizeof(int), hipHostMallocDefault));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_kernel),
+    if (d.attention_filters > 64 || U > 256) return fail(T2_EINVAL, "attention_filters <= 64 and attention_dim <= 256 supported");
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_kernel<32, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_kernel<64, 4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     m->hw.clear();
     m->finalized = true;
@@ -584,16 +589,17 @@ static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, con
         for (int dir = 0; dir < 2; ++dir) {
             c.w[dir] = m->enc_lstm[dir].w;
             c.bias[dir] = m->enc_lstm[dir].bias;
-            c.seg[dir][0] = SegDesc{xf + (size_t)dir * T * per_step_c, KPc / 16, 0, (int)per_step_c, 0};
-            c.seg[dir][1] = SegDesc{hst + (size_t)dir * 2 * hsz, KPh / 16, hsz, 0, 0};
+            c.seg[dir][0] = FragBuf{xf + (size_t)dir * T * per_step_c, (int)per_step_c, T, 0, 0};
+            c.seg[dir][1] = FragBuf{hst + (size_t)dir * 2 * hsz, hsz, 2, 0, 0};
             e.c[dir] = cst + (size_t)dir * MB * 16 * He;
-            e.hstate[dir] = hst + (size_t)dir * 2 * hsz;
-            e.hraw[dir] = nullptr;
+            e.hprev[dir] = FragBuf{hst + (size_t)dir * 2 * hsz, hsz, 2, 0, 0};
+            e.hstate[dir] = FragBuf{hst + (size_t)dir * 2 * hsz, hsz, 2, 1, 0};
+            e.hraw[dir] = FragBuf{nullptr, 0, 1, 0, 0};
             e.plain_off[dir] = dir * He;
             e.reverse[dir] = dir;
         }
-        c.nseg = 2; c.kbtot = m->enc_lstm[0].kbtot; c.ctl = ctl; c.step_off = s; c.B = B;
-        e.H = He; e.Hld = He; e.hstate_pp_stride = hsz; e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+        c.kb0 = KPc / 16; c.kbtot = m->enc_lstm[0].kbtot; c.ctl = ctl; c.step_off = s; c.B = B;
+        e.H = He; e.Hld = He; e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         e.lens = d_lens; e.plain_out = memory_out; e.plain_bs = T * E; e.plain_ts = E;
         launch_lstm<true>(MB, dim3(m->enc_lstm[0].n_wg, 2), st, c, e);
     }
@@ -670,14 +676,16 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     s->lens = (int*)((char*)s->fixed + o_lens);
     // zeroable part
     off = 0;
-    s->h_att_sz = R * pad16(A); s->h1_sz = R * pad16(D); s->h2_sz = R * pad16(D);
+    s->KBe = pad16(E) / 16; s->KBa = pad16(A) / 16; s->KBd = pad16(D) / 16;
+    const int blk = MB * 256;                      // floats per k-block
+    s->XA_sz = (s->KBe + s->KBa) * blk; s->X1_sz = (s->KBa + s->KBe + s->KBd) * blk; s->X2_sz = 2 * s->KBd * blk;
     const size_t o_ctl = carve(8 * 4);
     const size_t o_as = carve((size_t)B * T * 4), o_al = carve((size_t)B * T * 4);
-    const size_t o_cf = carve((size_t)R * pad16(E) * 4), o_cp = carve((size_t)B * E * 4), o_q = carve((size_t)R * U * 4);
+    const size_t o_cp = carve((size_t)B * E * 4), o_q = carve((size_t)m->att_lstm.n_wg * R * U * 4);
     const size_t o_ca = carve((size_t)R * A * 4), o_c1 = carve((size_t)R * D * 4), o_c2 = carve((size_t)R * D * 4);
-    const size_t o_ha = carve(2 * (size_t)s->h_att_sz * 4), o_h1 = carve(2 * (size_t)s->h1_sz * 4), o_h2 = carve(2 * (size_t)s->h2_sz * 4);
-    const size_t o_har = carve((size_t)s->h_att_sz * 4), o_y1 = carve((size_t)s->h1_sz * 4), o_y2 = carve((size_t)s->h2_sz * 4);
-    const size_t o_xin = carve((size_t)R * pad16(M * nf) * 4);
+    const size_t o_XA = carve(2 * (size_t)s->XA_sz * 4), o_X1 = carve(2 * (size_t)s->X1_sz * 4), o_X2 = carve(2 * (size_t)s->X2_sz * 4);
+    const size_t o_XY = carve((size_t)s->KBd * blk * 4);
+    const size_t o_xf = carve((size_t)R * pad16(M * nf) * 4);
     size_t o_xp[T2_MAX_PRENET_LAYERS];
     for (int i = 0; i < d.num_prenet_layers; ++i) o_xp[i] = carve((size_t)R * pad16(d.prenet_units[i]) * 4);
     s->slab_bytes = off;
@@ -686,11 +694,10 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     char* p = (char*)s->slab;
     s->ctl = (int*)(p + o_ctl);
     s->att_state = (float*)(p + o_as); s->alignments = (float*)(p + o_al);
-    s->ctx_frag = (float*)(p + o_cf); s->ctx_plain = (float*)(p + o_cp); s->q = (float*)(p + o_q);
+    s->ctx_plain = (float*)(p + o_cp); s->qpart = (float*)(p + o_q);
     s->c_att = (float*)(p + o_ca); s->c1 = (float*)(p + o_c1); s->c2 = (float*)(p + o_c2);
-    s->h_att = (float*)(p + o_ha); s->h1 = (float*)(p + o_h1); s->h2 = (float*)(p + o_h2);
-    s->h_att_raw = (float*)(p + o_har); s->y1_raw = (float*)(p + o_y1); s->y2_raw = (float*)(p + o_y2);
-    s->xin = (float*)(p + o_xin);
+    s->XA = (float*)(p + o_XA); s->X1 = (float*)(p + o_X1); s->X2 = (float*)(p + o_X2); s->XY = (float*)(p + o_XY);
+    s->xf = (float*)(p + o_xf);
     for (int i = 0; i < d.num_prenet_layers; ++i) s->xp[i] = (float*)(p + o_xp[i]);
     // output staging
     off = 0;
@@ -707,9 +714,7 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
 }
 
 static size_t attn_lds_bytes(const t2_dims& d, int T) {
-    const int F = d.attention_filters, U = d.attention_dim, K = d.attention_kernel;
-    size_t n = ((T + K + 3) & ~3) + ((T * F + 3) & ~3) + ((F * U + 3) & ~3) + ((T + 3) & ~3) + 32;
-    return n * 4;
+    return (size_t)attn_lds_floats(T, d.attention_dim, d.attention_filters, d.attention_kernel) * 4;
 }
 
 // attention mechanism constructor side effects + zero state
@@ -792,8 +797,8 @@ extern "C" int t2_state_get(t2_state* s, const char* name, float* out) {
         HIP_TRY(hipMemcpy2DAsync(out, cols * 4, src, ld_src * 4, cols * 4, rows, hipMemcpyDeviceToDevice, st));
         return T2_OK;
     };
-    auto copy_frag = [&](const float* src, int K) -> int {
-        hipLaunchKernelGGL(frag_to_plain_kernel, dim3(ceil_div(B * K, 256)), dim3(256), 0, st, src, out, B, K, s->MB);
+    auto copy_frag = [&](const float* src, int K, int koff) -> int {
+        hipLaunchKernelGGL(frag_to_plain_kernel, dim3(ceil_div(B * K, 256)), dim3(256), 0, st, src, out, B, K, s->MB, koff);
         HIP_TRY(hipGetLastError());
         return T2_OK;
     };
@@ -801,9 +806,9 @@ extern "C" int t2_state_get(t2_state* s, const char* name, float* out) {
     if (!strcmp(name, "attention_c")) return copy_plain(s->c_att, B, d.attention_lstm_units, d.attention_lstm_units);
     if (!strcmp(name, "lstm1_c")) return copy_plain(s->c1, B, d.decoder_lstm_units, d.decoder_lstm_units);
     if (!strcmp(name, "lstm2_c")) return copy_plain(s->c2, B, d.decoder_lstm_units, d.decoder_lstm_units);
-    if (!strcmp(name, "attention_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->h_att + (size_t)par * s->h_att_sz, d.attention_lstm_units); }
-    if (!strcmp(name, "lstm1_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->h1 + (size_t)par * s->h1_sz, d.decoder_lstm_units); }
-    if (!strcmp(name, "lstm2_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->h2 + (size_t)par * s->h2_sz, d.decoder_lstm_units); }
+    if (!strcmp(name, "attention_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->XA + (size_t)par * s->XA_sz, d.attention_lstm_units, s->KBe * 16); }
+    if (!strcmp(name, "lstm1_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->X1 + (size_t)par * s->X1_sz, d.decoder_lstm_units, (s->KBa + s->KBe) * 16); }
+    if (!strcmp(name, "lstm2_h")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->X2 + (size_t)par * s->X2_sz, d.decoder_lstm_units, s->KBd * 16); }
     if (!strcmp(name, "attention")) return copy_plain(s->ctx_plain, B, d.enc_units, d.enc_units);
     if (!strcmp(name, "alignments")) return copy_plain(s->alignments, B, T, T);
     if (!strcmp(name, "attention_state")) return copy_plain(s->att_state, B, T, T);
@@ -834,84 +839,88 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     auto core = [&](const Packed& p) {
         SkinnyCore c{};
         c.w[0] = c.w[1] = p.w; c.bias[0] = c.bias[1] = p.bias;
-        c.nseg = p.nseg; c.kbtot = p.kbtot; c.ctl = s->ctl; c.step_off = step_off; c.B = B;
+        c.kb0 = 0; c.kbtot = p.kbtot; c.ctl = s->ctl; c.step_off = step_off; c.B = B;
         return c;
     };
-    auto seg = [&](const float* base, int kb, int pp) { return SegDesc{base, kb, pp, 0, 0}; };
+    auto single = [&](float* base, int koff) { return FragBuf{base, 0, 1, 0, koff}; };
+    auto pp = [&](float* base, int sz, int dt, int koff) { return FragBuf{base, sz, 2, dt, koff}; };
+    const FragBuf none{nullptr, 0, 1, 0, 0};
+    const int KBe = s->KBe, KBa = s->KBa;
+    const int np = d.num_prenet_layers;
     // 1. decoder input frames (helpers.py:86 / :182 / go frame :187-188)
     if (io.feed_mode == 0 || io.feed_mode == 2) {
         FeedArgs f{};
-        f.src = io.feed_src; f.row_stride = io.feed_row_stride; f.t_stride = io.feed_t_stride; f.dst = s->xin;
+        f.src = io.feed_src; f.row_stride = io.feed_row_stride; f.t_stride = io.feed_t_stride; f.dst = single(s->xf, 0);
         f.B = B; f.K = M * nf; f.MB = MB; f.go_zero = io.feed_mode == 0; f.ctl = s->ctl; f.step_off = step_off;
         hipLaunchKernelGGL(feed_frames_kernel, dim3(ceil_div(MB * 16 * pad16(M * nf), 256)), dim3(256), 0, st, f);
     }
     // 2. prenets (rnn_wrappers.py:51-53)
-    const float* x = s->xin;
-    for (int i = 0; i < d.num_prenet_layers; ++i) {
+    for (int i = 0; i < np; ++i) {
         SkinnyCore c = core(m->prenet[i]);
-        c.seg[0][0] = seg(x, m->prenet[i].seg_kb[0], 0);
+        c.seg[0][1] = single(i == 0 ? s->xf : s->xp[i - 1], 0);
         DenseEpi e{};
-        e.N = d.prenet_units[i]; e.relu = 1; e.out_frag = s->xp[i]; e.frag_col0 = 0; e.stop_col = -1;
+        e.N = d.prenet_units[i]; e.relu = 1; e.out_frag = single(s->xp[i], 0); e.frag_col0 = 0; e.stop_col = -1;
         launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e);
-        x = s->xp[i];
     }
-    // 3. attention LSTM on concat(prenet out, previous context)  (AttentionWrapper, App. A6)
+    // 3. attention LSTM on concat(prenet out, previous context)  (AttentionWrapper, App. A6) + this step's
+    //    partial query products (tacotron_v2.py:122)
     {
         SkinnyCore c = core(m->att_lstm);
-        c.seg[0][0] = seg(x, m->att_lstm.seg_kb[0], 0);
-        c.seg[0][1] = seg(s->ctx_frag, m->att_lstm.seg_kb[1], 0);
-        c.seg[0][2] = seg(s->h_att, m->att_lstm.seg_kb[2], s->h_att_sz);
+        c.kb0 = m->att_lstm.seg_kb[0];
+        c.seg[0][0] = single(s->xp[np - 1], 0);
+        c.seg[0][1] = pp(s->XA, s->XA_sz, 0, 0);
         LstmEpi e{};
-        e.H = A; e.c[0] = s->c_att; e.Hld = A; e.hstate[0] = s->h_att; e.hstate_pp_stride = s->h_att_sz; e.hraw[0] = s->h_att_raw;
+        e.H = A; e.c[0] = s->c_att; e.Hld = A;
+        e.hprev[0] = pp(s->XA, s->XA_sz, 0, KBe * 16); e.hstate[0] = pp(s->XA, s->XA_sz, 1, KBe * 16);
+        e.hraw[0] = pp(s->X1, s->X1_sz, 0, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+        e.wq = m->wq; e.qpart = s->qpart; e.U = U;
         timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->att_lstm.n_wg, 1), st, c, e);
     }
-    // 4. processed query (tacotron_v2.py:122)
-    {
-        SkinnyCore c = core(m->query);
-        c.seg[0][0] = seg(s->h_att_raw, m->query.seg_kb[0], 0);
-        DenseEpi e{};
-        e.N = U; e.out_plain = s->q; e.plain_ld = U; e.plain_t_stride = 0; e.plain_ncol = U; e.stop_col = -1;
-        launch_dense(MB, dim3(m->query.n_wg), st, c, e);
-    }
-    // 5. location-sensitive attention + context
+    // 4./5. location-sensitive attention + context
     {
         AttnArgs a{};
         a.keys = s->keys; a.values = s->values; a.lens = s->lens; a.att_state = s->att_state; a.alignments = s->alignments;
-        a.history = io.hist; a.q = s->q; a.ctx_frag = s->ctx_frag; a.ctx_plain = s->ctx_plain;
+        a.history = io.hist; a.qpart = s->qpart; a.nparts = m->att_lstm.n_wg;
+        a.ctx_dst[0] = pp(s->XA, s->XA_sz, 1, 0); a.ctx_dst[1] = pp(s->X1, s->X1_sz, 0, KBa * 16); a.ctx_plain = s->ctx_plain;
         a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
         a.B = B; a.T = s->T; a.U = U; a.E = E; a.F = d.attention_filters; a.K = d.attention_kernel; a.MB = MB;
         a.cumulative = d.cumulative_weights; a.ctl = s->ctl; a.step_off = step_off;
-        hipLaunchKernelGGL(attention_step_kernel, dim3(B), dim3(T2_ATTN_THREADS), attn_lds_bytes(d, s->T), st, a);
+        const size_t lds = attn_lds_bytes(d, s->T);
+        if (d.attention_filters <= 32 && U <= 128)
+            hipLaunchKernelGGL((attention_step_kernel<32, 2>), dim3(B), dim3(T2_ATTN_THREADS), lds, st, a);
+        else
+            hipLaunchKernelGGL((attention_step_kernel<64, 4>), dim3(B), dim3(T2_ATTN_THREADS), lds, st, a);
     }
     // 6./7. decoder LSTMs on concat(attention cell output, new context)  (rnn_wrappers.py:76-78, tacotron_v2.py:155-161)
     {
         SkinnyCore c = core(m->lstm1);
-        c.seg[0][0] = seg(s->h_att_raw, m->lstm1.seg_kb[0], 0);
-        c.seg[0][1] = seg(s->ctx_frag, m->lstm1.seg_kb[1], 0);
-        c.seg[0][2] = seg(s->h1, m->lstm1.seg_kb[2], s->h1_sz);
+        c.seg[0][1] = pp(s->X1, s->X1_sz, 0, 0);
         LstmEpi e{};
-        e.H = D; e.c[0] = s->c1; e.Hld = D; e.hstate[0] = s->h1; e.hstate_pp_stride = s->h1_sz; e.hraw[0] = s->y1_raw;
+        e.H = D; e.c[0] = s->c1; e.Hld = D;
+        e.hprev[0] = pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16); e.hstate[0] = pp(s->X1, s->X1_sz, 1, (KBa + KBe) * 16);
+        e.hraw[0] = pp(s->X2, s->X2_sz, 0, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->lstm1.n_wg, 1), st, c, e);
     }
     {
         SkinnyCore c = core(m->lstm2);
-        c.seg[0][0] = seg(s->y1_raw, m->lstm2.seg_kb[0], 0);
-        c.seg[0][1] = seg(s->h2, m->lstm2.seg_kb[1], s->h2_sz);
+        c.seg[0][1] = pp(s->X2, s->X2_sz, 0, 0);
         LstmEpi e{};
-        e.H = D; e.c[0] = s->c2; e.Hld = D; e.hstate[0] = s->h2; e.hstate_pp_stride = s->h2_sz; e.hraw[0] = s->y2_raw;
+        e.H = D; e.c[0] = s->c2; e.Hld = D;
+        e.hprev[0] = pp(s->X2, s->X2_sz, 0, s->KBd * 16); e.hstate[0] = pp(s->X2, s->X2_sz, 1, s->KBd * 16);
+        e.hraw[0] = single(s->XY, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->lstm2.n_wg, 1), st, c, e);
     }
     // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
     {
         SkinnyCore c = core(m->proj);
-        c.seg[0][0] = seg(s->y2_raw, m->proj.seg_kb[0], 0);
+        c.seg[0][1] = single(s->XY, 0);
         DenseEpi e{};
         e.N = M * r + 1; e.relu = 0;
         e.out_plain = io.mel; e.plain_ld = io.mel_ld; e.plain_t_stride = io.mel_t_stride; e.plain_ncol = M * r;
-        e.out_frag = io.feed_mode == 1 ? s->xin : nullptr; e.frag_col0 = M * (r - nf);
+        e.out_frag = io.feed_mode == 1 ? single(s->xf, 0) : none; e.frag_col0 = M * (r - nf);
         e.stop_col = M * r; e.out_stop = io.stop; e.stop_ld = io.stop_ld; e.stop_t_mul = io.stop_t_mul; e.ctl_w = s->ctl;
         launch_dense(MB, dim3(m->proj.n_wg), st, c, e);
     }
