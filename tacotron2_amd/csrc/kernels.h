@@ -5,7 +5,7 @@
 //  * "frag16": activation matrix X[rows, K] stored in the operand order of
 //    v_mfma_f32_16x16x4_f32 so that one wave-instruction loads one contiguous 1 KiB piece:
 //        float index = (((kb*MB + rb)*4 + kg)*16 + rr)*4 + j,   k = kb*16 + kg*4 + j,  row = rb*16 + rr
-//    (MB = row blocks of 16 batch rows; K padded to a multiple of 16; pad rows / pad k are zero).
+//    (MB = row blocks of 16 batch rows; every K segment padded to a multiple of 64; pad rows / pad k are zero).
 //    Lane l = kg*16 + rr reads the float4 at ((kb*MB + rb)*64 + l)*4.
 //  * packed weights for the skinny (batch <= 64) GEMMs: per workgroup g a contiguous slab
 //        [kb][lane = kg*16 + c][j]  = W[k = kb*16 + kg*4 + j][col(g, c)]
@@ -17,9 +17,19 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define T2_SKINNY_THREADS 512
+#ifndef T2_SKINNY_WAVES
 #define T2_SKINNY_WAVES 8
+#endif
+#define T2_SKINNY_THREADS (64 * T2_SKINNY_WAVES)
 #define T2_MAX_SEG 3
+#ifndef T2_W_NT
+#define T2_W_NT 0   // plain loads measured faster than nontemporal ones here (tools/lstm_bench.hip)
+#endif
+#if T2_W_NT
+#define T2_WLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define T2_WLOAD(p) (*(p))
+#endif
 
 // ctl block (device ints): [0] base step, [1] nsteps_final (0 = not finished), [2] max steps,
 // [3] min_iters, [4] stop rule enabled
@@ -119,13 +129,29 @@ struct KGroup {
 };
 
 template <int MB, int G>
-__device__ __forceinline__ void kg_load(KGroup<MB, G>& g, const f32x4* __restrict__ wp, const f32x4* __restrict__ ap, int kb, int kba) {
+__device__ __forceinline__ void kg_load_w(KGroup<MB, G>& g, const f32x4* __restrict__ wp, int kb) {
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        g.b[u] = __builtin_nontemporal_load(wp + (size_t)(kb + u) * 64);
-#pragma unroll
-        for (int rb = 0; rb < MB; ++rb) g.a[u][rb] = ap[(size_t)((kba + u) * MB + rb) * 64];
+#ifdef T2_ABL_NOW   // ablation builds (tools/lstm_bench.hip) only
+        g.b[u] = f32x4{0.01f, 0.02f, 0.03f, 0.04f};
+#else
+        g.b[u] = T2_WLOAD(wp + (size_t)(kb + u) * 64);
+#endif
     }
+}
+
+template <int MB, int G>
+__device__ __forceinline__ void kg_load_a(KGroup<MB, G>& g, const f32x4* __restrict__ ap, int kba) {
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) {
+#ifdef T2_ABL_NOA
+            g.a[u][rb] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+#else
+            g.a[u][rb] = ap[(size_t)((kba + u) * MB + rb) * 64];
+#endif
+        }
 }
 
 template <int MB, int G>
@@ -135,58 +161,107 @@ __device__ __forceinline__ void kg_mma(const KGroup<MB, G>& g, f32x4 (&acc)[MB])
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int rb = 0; rb < MB; ++rb)
+            for (int rb = 0; rb < MB; ++rb) {
+#if defined(T2_ABL_NOMMA)
+                asm volatile("" ::"v"(g.a[u][rb][j]), "v"(g.b[u][j]));
+#elif defined(T2_ABL_DECOUPLE)   // MFMAs on constants, loads kept alive: do loads and MFMAs overlap at all?
+                asm volatile("" ::"v"(g.a[u][rb][j]), "v"(g.b[u][j]));
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(0.5f + j, 0.25f + u, acc[rb], 0, 0, 0);
+#else
                 acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.a[u][rb][j], g.b[u][j], acc[rb], 0, 0, 0);
+#endif
+            }
 }
 
-// k-blocks [lo, hi) of the weight slab; the A operand block index is (kb - ka_off)
-template <int MB, int G>
-__device__ __forceinline__ void skinny_range(const f32x4* __restrict__ wp, const f32x4* __restrict__ ap, int lo, int hi,
-                                             int ka_off, f32x4 (&acc)[MB]) {
-    const int n = hi - lo;
-    if (n <= 0) return;
-    const int nfull = n / G;
-    if (nfull > 0) {
-        KGroup<MB, G> g0, g1;
-        kg_load<MB, G>(g0, wp, ap, lo, lo - ka_off);
-        int g = 0;
-        for (; g + 2 <= nfull; g += 2) {
-            const int k1 = lo + (g + 1) * G;
-            kg_load<MB, G>(g1, wp, ap, k1, k1 - ka_off);
-            kg_mma<MB, G>(g0, acc);
-            // unconditional (clamped) prefetch keeps the wait counts static: the last one re-reads a group
-            const int k2 = lo + min(g + 2, nfull - 1) * G;
-            kg_load<MB, G>(g0, wp, ap, k2, k2 - ka_off);
-            kg_mma<MB, G>(g1, acc);
+// The wave's share of the K range is [lo, hi) in groups of G k-blocks (kb0 and kbtot are multiples of G:
+// the host pads every K segment to 64).  A ring of NBUF register buffers keeps NBUF groups of loads in
+// flight under the MFMAs.  The first weight loads are issued before the step index is known (they do
+// not depend on it); the walk through the range starts at a workgroup-dependent rotation so that the
+// 256 workgroups do not all request the same activation lines from L2 at the same moment.
+// Returns the step index, or -1 when this launch must do nothing (uniform over the workgroup).
+// NPW > 0: every wave owns exactly NPW or NPW + 1 groups (host-checked); the walk over them is then
+// fully unrolled straight-line code, so the compiler emits exact counted s_waitcnt vmcnt(N) and a wave
+// only ever waits for its OLDEST group in flight.  (With a runtime trip count hipcc drains vmcnt(0) at
+// the loop header and the loads stop overlapping the MFMAs: measured 22.8 vs ~13 us.)
+template <int NBUF, int N, class Buf, class Mma, class LoadW, class LoadA, class GIdx>
+__device__ __forceinline__ void ring_static(Buf (&buf)[NBUF], Mma&& mma, LoadW&& load_w, LoadA&& load_a, GIdx&& gidx) {
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i) load_a(buf[i], gidx(i < N ? i : N - 1));
+#pragma unroll
+    for (int g = 0; g < N; ++g) {
+        mma(buf[g % NBUF]);
+        if (g + NBUF < N) {
+            const int gi = gidx(g + NBUF);
+            load_w(buf[g % NBUF], gi);
+            load_a(buf[g % NBUF], gi);
         }
-        if (g < nfull) kg_mma<MB, G>(g0, acc);
-    }
-    for (int kb = lo + nfull * G; kb < hi; ++kb) {
-        KGroup<MB, 1> g;
-        kg_load<MB, 1>(g, wp, ap, kb, kb - ka_off);
-        kg_mma<MB, 1>(g, acc);
     }
 }
 
-template <int MB>
-__device__ __forceinline__ void skinny_core(const SkinnyCore& a, int dir, int t, f32x4 (&acc)[MB]) {
-    constexpr int G = (MB >= 4) ? 2 : 4;
+#ifndef T2_G4
+#define T2_G4 2      // k-blocks per group at MB = 4
+#endif
+#ifndef T2_NBUF
+#define T2_NBUF 3    // groups in flight per wave (3 measured best: tools/lstm_bench.hip)
+#endif
+template <int MB, int NPW>
+__device__ __forceinline__ int skinny_core(const SkinnyCore& a, int dir, f32x4 (&acc)[MB]) {
+    constexpr int G = (MB >= 4) ? T2_G4 : 4;
+    constexpr int NBUF = T2_NBUF;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int base = a.kbtot / T2_SKINNY_WAVES, rem = a.kbtot % T2_SKINNY_WAVES;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ng = a.kbtot / G, ng0 = a.kb0 / G;
+    const int base = ng / T2_SKINNY_WAVES, rem = ng % T2_SKINNY_WAVES;
     const int lo = wave * base + min(wave, rem);
-    const int hi = lo + base + (wave < rem ? 1 : 0);
+    const int n = base + (wave < rem ? 1 : 0);
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.w[dir]) + (size_t)blockIdx.x * a.kbtot * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (lo < a.kb0) {
-        const f32x4* ap = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][0], t)) + (size_t)(a.seg[dir][0].koff >> 4) * MB * 64 + lane;
-        skinny_range<MB, G>(wp, ap, lo, min(hi, a.kb0), 0, acc);
+    const int rot = n > 0 ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)n) : 0;
+    auto gidx = [&](int i) { const int j = i + rot; return lo + (j >= n ? j - n : j); };
+    auto load_w = [&](KGroup<MB, G>& b, int g) { kg_load_w<MB, G>(b, wp, g * G); };
+    KGroup<MB, G> buf[NBUF];
+    if (n > 0) {
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i) load_w(buf[i], gidx(min(i, n - 1)));
     }
-    if (hi > a.kb0) {
-        const f32x4* ap = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][1], t)) + (size_t)(a.seg[dir][1].koff >> 4) * MB * 64 + lane;
-        skinny_range<MB, G>(wp, ap, max(lo, a.kb0), hi, a.kb0, acc);
+    const int t = step_index(a.ctl, a.step_off);
+    if (t < 0) return -1;
+    if (n > 0) {
+        const f32x4* ap0 = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][0], t)) + (size_t)(a.seg[dir][0].koff >> 4) * MB * 64 + lane;
+        const f32x4* ap1 = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][1], t)) + (size_t)(a.seg[dir][1].koff >> 4) * MB * 64 + lane;
+        auto load_a = [&](KGroup<MB, G>& b, int g) {
+            const f32x4* ap = g < ng0 ? ap0 + (size_t)g * G * MB * 64 : ap1 + (size_t)(g - ng0) * G * MB * 64;
+            kg_load_a<MB, G>(b, ap, 0);
+        };
+        bool done = false;
+        if constexpr (NPW > 0) {
+            if (base == NPW) {      // checked on the device too: a wrong NPW must never walk out of the slab
+                auto mma = [&](const KGroup<MB, G>& b) { kg_mma<MB, G>(b, acc); };
+                if (n == NPW) ring_static<NBUF, NPW>(buf, mma, load_w, load_a, gidx);
+                else ring_static<NBUF, NPW + 1>(buf, mma, load_w, load_a, gidx);
+                done = true;
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int i = 0; i < NBUF; ++i) load_a(buf[i], gidx(min(i, n - 1)));
+            for (int g = 0; g < n; g += NBUF) {
+#pragma unroll
+                for (int i = 0; i < NBUF; ++i) {
+                    if (g + i < n) {
+                        kg_mma<MB, G>(buf[i], acc);
+                        if (g + i + NBUF < n) {
+                            const int gi = gidx(g + i + NBUF);
+                            load_w(buf[i], gi);
+                            load_a(buf[i], gi);
+                        }
+                    }
+                }
+            }
+        }
     }
+    return t;
 }
 
 // sum of the 8 waves' partial tiles for element (row, col c) of the workgroup's [MB*16 x 16] tile.
@@ -207,15 +282,14 @@ __device__ __forceinline__ float red_sum(const f32x4* red, int row, int c) {
 // zoneout blend of ZoneoutLSTMCell (reference tacotron/modules.py:261-283) and, for the attention
 // LSTM, this workgroup's share of the attention query projection (tacotron_v2.py:122).
 // ------------------------------------------------------------------------------------------------
-template <int MB, bool ENC>   // ENC: encoder BiLSTM instance (own name in profiles; same code)
+template <int MB, bool ENC, int NPW = 0>   // ENC: encoder BiLSTM instance (own name in profiles; same code)
 __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore a, LstmEpi e) {
-    const int t = step_index(a.ctl, a.step_off);
-    if (t < 0) return;
     const int dir = blockIdx.y;
     __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
     __shared__ float s_h[MB * 16 * 4];
     f32x4 acc[MB];
-    skinny_core<MB>(a, dir, t, acc);
+    const int t = skinny_core<MB, NPW>(a, dir, acc);
+    if (t < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
@@ -272,18 +346,193 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K LSTM step for batches > 16 rows.  With 4 units (16 columns) per workgroup every CU has to
+// pull the whole activation matrix through its L1 (B*K*4 bytes, ~0.65 MB at B=64), which, not the
+// MFMA pipe, bounds the kernel.  Here a workgroup owns 8 units (two 16-column tiles) and HALF of K:
+// activation bytes per CU halve, the weight bytes stay.  The two K-halves of a tile are combined
+// inside the launch: both workgroups store their partial gate pre-activations write-through
+// (sc1), draw a ticket with a returning agent-scope atomic, and the workgroup whose ticket is last
+// reads the other half with sc1 loads and runs the LSTM epilogue (cdna guide, "in-launch split-K
+// reduction", sc1 form; every store and every load of the handed-off bytes is an agent-scope
+// relaxed atomic access = global_store/load ... sc1).  The sum is always half0 + half1, so the
+// result does not depend on which workgroup arrives last.
+// ------------------------------------------------------------------------------------------------
+template <int MB, int G>
+struct KGroup2 {
+    f32x4 b0[G], b1[G];
+    f32x4 a[G][MB];
+};
+
+template <int MB, int NPW = 0>
+__global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_splitk_kernel(SkinnyCore a, LstmEpi e, int n_wg4,
+                                                                              unsigned* tickets, unsigned long long* slabs) {
+    constexpr int G = 2, NBUF = 3;
+    const int tile = blockIdx.x >> 1, half = blockIdx.x & 1;
+    __shared__ f32x4 red[T2_SKINNY_WAVES * 2 * MB * 64];
+    __shared__ float s_h[MB * 16 * 8];
+    __shared__ unsigned s_ticket;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ng = a.kbtot / G, ng0 = a.kb0 / G;
+    const int h_lo = half == 0 ? 0 : (ng + 1) / 2, h_n = half == 0 ? (ng + 1) / 2 : ng / 2;
+    const int base = h_n / T2_SKINNY_WAVES, rem = h_n % T2_SKINNY_WAVES;
+    const int lo = h_lo + wave * base + min(wave, rem);
+    const int n = base + (wave < rem ? 1 : 0);
+    const int t0i = 2 * tile, t1i = min(2 * tile + 1, n_wg4 - 1);
+    const f32x4* __restrict__ wp0 = reinterpret_cast<const f32x4*>(a.w[0]) + (size_t)t0i * a.kbtot * 64 + lane;
+    const f32x4* __restrict__ wp1 = reinterpret_cast<const f32x4*>(a.w[0]) + (size_t)t1i * a.kbtot * 64 + lane;
+    f32x4 acc0[MB], acc1[MB];
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) { acc0[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int rot = n > 0 ? (int)((tile * 5u) % (unsigned)n) : 0;
+    auto gidx = [&](int i) { const int j = i + rot; return lo + (j >= n ? j - n : j); };
+    KGroup2<MB, G> buf[NBUF];
+    auto load_w = [&](KGroup2<MB, G>& b, int g) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            b.b0[u] = T2_WLOAD(wp0 + (size_t)(g * G + u) * 64);
+            b.b1[u] = T2_WLOAD(wp1 + (size_t)(g * G + u) * 64);
+        }
+    };
+    if (n > 0) {
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i) load_w(buf[i], gidx(min(i, n - 1)));
+    }
+    const int t = step_index(a.ctl, a.step_off);
+    if (t < 0) return;
+    if (n > 0) {
+        const f32x4* ap0 = reinterpret_cast<const f32x4*>(frag_slot(a.seg[0][0], t)) + (size_t)(a.seg[0][0].koff >> 4) * MB * 64 + lane;
+        const f32x4* ap1 = reinterpret_cast<const f32x4*>(frag_slot(a.seg[0][1], t)) + (size_t)(a.seg[0][1].koff >> 4) * MB * 64 + lane;
+        auto load_a = [&](KGroup2<MB, G>& b, int g) {
+            const f32x4* ap = g < ng0 ? ap0 + (size_t)g * G * MB * 64 : ap1 + (size_t)(g - ng0) * G * MB * 64;
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) b.a[u][rb] = ap[(size_t)(u * MB + rb) * 64];
+        };
+        auto mma = [&](const KGroup2<MB, G>& b) {
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < MB; ++rb) {
+                        acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.a[u][rb][j], b.b0[u][j], acc0[rb], 0, 0, 0);
+                        acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.a[u][rb][j], b.b1[u][j], acc1[rb], 0, 0, 0);
+                    }
+        };
+        bool done = false;
+        if constexpr (NPW > 0) {
+            if (base == NPW) {
+                if (n == NPW) ring_static<NBUF, NPW>(buf, mma, load_w, load_a, gidx);
+                else ring_static<NBUF, NPW + 1>(buf, mma, load_w, load_a, gidx);
+                done = true;
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int i = 0; i < NBUF; ++i) load_a(buf[i], gidx(min(i, n - 1)));
+            for (int g = 0; g < n; g += NBUF) {
+#pragma unroll
+                for (int i = 0; i < NBUF; ++i) {
+                    if (g + i < n) {
+                        mma(buf[i]);
+                        if (g + i + NBUF < n) {
+                            const int gi = gidx(g + i + NBUF);
+                            load_w(buf[i], gi);
+                            load_a(buf[i], gi);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) {
+        red[((wave * 2 + 0) * MB + rb) * 64 + lane] = acc0[rb];
+        red[((wave * 2 + 1) * MB + rb) * 64 + lane] = acc1[rb];
+    }
+    __syncthreads();
+    // this half's partial pre-activations: thread -> (row, unit-in-tile), 4 gates
+    const int idx = threadIdx.x;
+    const bool owner = idx < MB * 16 * 8;
+    const int row = idx >> 3, u8 = idx & 7, ct = u8 >> 2, uu = u8 & 3;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+        const int rb = row >> 4, rr = row & 15, reg = rr & 3;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            const int src_lane = (rr >> 2) * 16 + gate * 4 + uu;
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < T2_SKINNY_WAVES; ++w) sacc += red[((w * 2 + ct) * MB + rb) * 64 + src_lane][reg];
+            z[gate] = sacc;
+        }
+    }
+    unsigned long long* my = slabs + ((size_t)(tile * 2 + half) * T2_SKINNY_THREADS + idx) * 2;
+    unsigned long long* other = slabs + ((size_t)(tile * 2 + (half ^ 1)) * T2_SKINNY_THREADS + idx) * 2;
+    if (owner) {
+        __hip_atomic_store(my, ((unsigned long long)__float_as_uint(z[1]) << 32) | __float_as_uint(z[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my + 1, ((unsigned long long)__float_as_uint(z[3]) << 32) | __float_as_uint(z[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket == 0u) return;                             // the other half finishes this tile
+    if (threadIdx.x == 0) __hip_atomic_store(tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    float hn = 0.f;
+    if (owner) {
+        const unsigned long long o0 = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long o1 = __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float oz[4] = {__uint_as_float((unsigned)o0), __uint_as_float((unsigned)(o0 >> 32)),
+                             __uint_as_float((unsigned)o1), __uint_as_float((unsigned)(o1 >> 32))};
+        float zt[4];
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) zt[gate] = half == 0 ? z[gate] + oz[gate] : oz[gate] + z[gate];   // always half0 + half1
+        const int wg4 = 2 * tile + ct;
+        const int unit = wg4 * 4 + uu;
+        if (row < a.B && unit < e.H) {
+            const float* bias = a.bias[0] + (size_t)wg4 * 16;
+            const float zi = zt[0] + bias[0 * 4 + uu], zj = zt[1] + bias[1 * 4 + uu];
+            const float zf = zt[2] + bias[2 * 4 + uu], zo = zt[3] + bias[3 * 4 + uu];
+            float* cptr = e.c[0] + (size_t)row * e.Hld + unit;
+            const float cp = *cptr;
+            const float hp = frag_slot(e.hprev[0], t)[frag_idx(row, e.hprev[0].koff + unit, MB)];
+            const float cn = sigmoidf_(zf + e.fb) * cp + sigmoidf_(zi) * tanhf(zj);
+            hn = sigmoidf_(zo) * tanhf(cn);
+            *cptr = (1.0f - e.zc) * cn + e.zc * cp;
+            frag_slot(e.hstate[0], t)[frag_idx(row, e.hstate[0].koff + unit, MB)] = (1.0f - e.zh) * hn + e.zh * hp;
+            if (e.hraw[0].base != nullptr) frag_slot(e.hraw[0], t)[frag_idx(row, e.hraw[0].koff + unit, MB)] = hn;
+        }
+        s_h[idx] = hn;
+    }
+    if (e.wq == nullptr) return;
+    __syncthreads();
+    const int U = e.U;
+    const float* wq = e.wq + (size_t)tile * 8 * U;
+    const int nvalid = min(8, e.H - tile * 8);
+    float* qp = e.qpart + (size_t)tile * MB * 16 * U;
+    for (int i = threadIdx.x; i < MB * 16 * U; i += T2_SKINNY_THREADS) {
+        const int r2 = i / U, u = i - r2 * U;
+        float sq = 0.f;
+        for (int k = 0; k < nvalid; ++k) sq = fmaf(s_h[r2 * 8 + k], wq[k * U + u], sq);
+        qp[i] = sq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense step: y = act(x . W + b) for 16 columns per workgroup.  Used for the PreNet layers
 // (modules.py:88-91) and the mel / stop projections (rnn_wrappers.py:105-109) together with the
 // stop rule of StopTokenBasedInferenceHelper (helpers.py:90-94) evaluated on the device.
 // ------------------------------------------------------------------------------------------------
 template <int MB>
 __global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCore a, DenseEpi e) {
-    const int t = step_index(a.ctl, a.step_off);
-    if (t < 0) return;
     __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
     __shared__ int s_notstop;
     f32x4 acc[MB];
-    skinny_core<MB>(a, 0, t, acc);
+    const int t = skinny_core<MB, 0>(a, 0, acc);
+    if (t < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
@@ -351,11 +600,28 @@ struct AttnArgs {
 
 __host__ __device__ inline int attn_lds_floats(int T, int U, int F, int K) {
     const int FP = (F + 3) & ~3, KP = (K + 3) & ~3;
-    return ((T + KP + 16 + 3) & ~3) + KP * FP + ((T + 8) * FP) + ((T + 3) & ~3) + 2 * ((U + 3) & ~3) * 4 + 64;
+    return ((T + KP + 16 + 3) & ~3) + KP * FP + ((T + 8) * FP) + ((T + 3) & ~3) + 2 * ((U + 3) & ~3) * 4 + 64 + 2048;
 }
+
+// tanh via v_exp_f32 / v_rcp_f32: abs error < 1e-6 (the energies feed a softmax; tolerance budget 1e-3)
+__device__ __forceinline__ float fast_tanhf(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
+
+// The kernel is a chain of short phases on ONE workgroup per batch row, so its time is mostly load
+// latency.  Every global load that does not depend on this step's LDS work (query partials, keys,
+// location-layer columns, and later the values) is issued as early as possible and consumed late.
+#ifdef T2_ATTN_STAMPS   // diagnostic builds (tools/attn_bench.hip) only
+__device__ unsigned long long* g_attn_stamps;
+#define T2_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_attn_stamps[i] = clock64(); } while (0)
+#else
+#define T2_STAMP(i) do { } while (0)
+#endif
 
 template <int FMAX, int UPL>
 __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArgs a) {
+    T2_STAMP(0);
     const int t_step = step_index(a.ctl, a.step_off);
     if (t_step < 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -368,13 +634,46 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
     float* s_cw = s_prev + ((T + KP + 16 + 3) & ~3);    // [KP][FP] conv kernel, zero padded
     float* s_f = s_cw + KP * FP;                        // [T + 8][FP]
     float* s_e = s_f + (T + 8) * FP;                    // [T]
-    float* s_q = s_e + ((T + 3) & ~3);                  // [4][UP] partial sums, then [0][:] = q + b_a
+    float* s_q = s_e + ((T + 3) & ~3);                  // [4][UP] partial sums, then [4*UP ..] = q + b_a
     float* s_red = s_q + 8 * UP;                        // [64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* s_ctx = s_red + 64;                          // [<= 2048] context partials
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = T2_ATTN_THREADS / 64;
     const int len = a.lens[b];
     float* state = a.att_state + (size_t)b * T;
-    // ---- phase 0 ----
+
+    // ---- early loads ----
+    constexpr int QN = 64;                               // query partials per thread held in registers
+    const int QG = min(4, T2_ATTN_THREADS / U);
+    const bool q_active = tid < QG * U;
+    const int qg = tid / U, qu = tid - qg * U;
+    const float* qp = a.qpart + (size_t)b * U + (q_active ? qu : 0);
+    const size_t pstride = (size_t)a.MB * 16 * U;
+    float qv[QN];
+#pragma unroll
+    for (int i = 0; i < QN; ++i) qv[i] = qp[(size_t)min(qg + i * QG, a.nparts - 1) * pstride];
+    const float* keys = a.keys + (size_t)b * T * U;
+    float kvA[8][UPL], kvB[8][UPL];
+    auto load_keys = [&](float (&kv)[8][UPL], int tb) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int tt = min(tb + r * NW, T - 1);
+#pragma unroll
+            for (int i = 0; i < UPL; ++i) kv[r][i] = keys[(size_t)tt * U + min(lane + 64 * i, U - 1)];
+        }
+    };
+    load_keys(kvA, wave);
+    load_keys(kvB, wave + 8 * NW);
+    float wl[FMAX][UPL];                                 // location-layer columns of this lane's units
+    float va[UPL], kq[UPL];
+#pragma unroll
+    for (int i = 0; i < UPL; ++i) {
+        const int u = lane + 64 * i;
+        va[i] = (u < U) ? a.v_a[u] : 0.f;                // va == 0 masks lanes with u >= U
+#pragma unroll
+        for (int c = 0; c < FMAX; ++c) wl[c][i] = (c < F && u < U) ? a.wloc[c * U + u] : 0.f;
+    }
     for (int i = tid; i < T + KP + 16; i += T2_ATTN_THREADS) {
         const int p = i - pad_l;
         s_prev[i] = (p >= 0 && p < T) ? state[p] : 0.f;
@@ -383,41 +682,9 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         const int j = i / FP, c = i - j * FP;
         s_cw[i] = (j < K && c < F) ? a.conv_w[j * F + c] : 0.f;
     }
-    {   // processed query: sum over the attention-LSTM workgroups' partial products
-        const int QG = min(4, T2_ATTN_THREADS / U);
-        if (tid < QG * U) {
-            const int g = tid / U, u = tid - g * U;
-            const float* qp = a.qpart + (size_t)b * U + u;
-            const size_t pstride = (size_t)a.MB * 16 * U;
-            float s0 = 0.f, s1 = 0.f;
-            int p = g;
-            for (; p + QG < a.nparts; p += 2 * QG) {
-                s0 += qp[(size_t)p * pstride];
-                s1 += qp[(size_t)(p + QG) * pstride];
-            }
-            if (p < a.nparts) s0 += qp[(size_t)p * pstride];
-            s_q[g * UP + u] = s0 + s1;
-        }
-    }
-    // location-layer columns of this lane's attention units, in registers
-    float wl[FMAX][UPL];
-    float va[UPL], kq[UPL];
-#pragma unroll
-    for (int i = 0; i < UPL; ++i) {
-        const int u = lane + 64 * i;
-        va[i] = (u < U) ? a.v_a[u] : 0.f;
-#pragma unroll
-        for (int c = 0; c < FMAX; ++c) wl[c][i] = (c < F && u < U) ? a.wloc[c * U + u] : 0.f;
-    }
+    T2_STAMP(1);
     __syncthreads();
-    {
-        const int QG = min(4, T2_ATTN_THREADS / U);
-        if (tid < U) {
-            float s = a.b_a[tid];
-            for (int g = 0; g < QG; ++g) s += s_q[g * UP + tid];
-            s_q[4 * UP + tid] = s;          // q[u] + b_a[u]
-        }
-    }
+    T2_STAMP(2);
     // ---- phase 1: location features f[t][c] = sum_j w[j][c] * prev[t + j - pad_l] + b[c]   (:128-130)
     {
         const int nblk = (T + 7) >> 3;
@@ -451,41 +718,79 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
             for (int i = 0; i < 8; ++i) s_f[(t0 + i) * FP + c] = accv[i] + bc;
         }
     }
-    __syncthreads();
-    // ---- phase 2: energies   (:131-133, :66-78)
+    T2_STAMP(3);
+    // processed query (tacotron_v2.py:122): sum over the attention-LSTM workgroups' partial products
     {
-        const float* keys = a.keys + (size_t)b * T * U;
+        float s0 = 0.f;
 #pragma unroll
-        for (int i = 0; i < UPL; ++i) { const int u = lane + 64 * i; kq[i] = (u < U) ? s_q[4 * UP + u] : 0.f; }
-        for (int tt = wave; tt < T; tt += NW) {
-            float pf[UPL];
-            float kv[UPL];
-#pragma unroll
-            for (int i = 0; i < UPL; ++i) {
-                const int u = lane + 64 * i;
-                pf[i] = 0.f;
-                kv[i] = (u < U) ? keys[(size_t)tt * U + u] : 0.f;
-            }
-            const float* ft = s_f + tt * FP;
-#pragma unroll
-            for (int c4 = 0; c4 < FMAX; c4 += 4) {
-                if (c4 < FP) {
-                    const f32x4 fv = *reinterpret_cast<const f32x4*>(ft + c4);
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                        for (int i = 0; i < UPL; ++i) pf[i] = fmaf(fv[cc], wl[c4 + cc][i], pf[i]);
-                }
-            }
-            float part = 0.f;
-#pragma unroll
-            for (int i = 0; i < UPL; ++i) part += va[i] * tanhf(kv[i] + kq[i] + pf[i]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if (lane == 0) s_e[tt] = part;
-        }
+        for (int i = 0; i < QN; ++i) s0 += (qg + i * QG < a.nparts) ? qv[i] : 0.f;
+        for (int p = qg + QN * QG; p < a.nparts; p += QG) s0 += qp[(size_t)p * pstride];   // only if nparts > 256
+        if (q_active) s_q[qg * UP + qu] = s0;
     }
     __syncthreads();
+    if (tid < U) {
+        float s = a.b_a[tid];
+        for (int g = 0; g < QG; ++g) s += s_q[g * UP + tid];
+        s_q[4 * UP + tid] = s;          // q[u] + b_a[u]
+    }
+    __syncthreads();
+    T2_STAMP(4);
+    // ---- phase 2: energies   (:131-133, :66-78); one wave per position, lanes over attention units
+    {
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) { const int u = lane + 64 * i; kq[i] = (u < U) ? s_q[4 * UP + u] : 0.f; }
+        auto energies = [&](const float (&kv)[8][UPL], int tb) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int tt = tb + r * NW;
+                if (tt < T) {
+                    float pf[UPL];
+#pragma unroll
+                    for (int i = 0; i < UPL; ++i) pf[i] = 0.f;
+                    const float* ft = s_f + tt * FP;
+#pragma unroll
+                    for (int c4 = 0; c4 < FMAX; c4 += 4) {
+                        if (c4 < FP) {
+                            const f32x4 fv = *reinterpret_cast<const f32x4*>(ft + c4);
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                                for (int i = 0; i < UPL; ++i) pf[i] = fmaf(fv[cc], wl[c4 + cc][i], pf[i]);
+                        }
+                    }
+                    float part = 0.f;
+#pragma unroll
+                    for (int i = 0; i < UPL; ++i) part += va[i] * fast_tanhf(kv[r][i] + kq[i] + pf[i]);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                    if (lane == 0) s_e[tt] = part;
+                }
+            }
+        };
+        energies(kvA, wave);
+        energies(kvB, wave + 8 * NW);
+        for (int tb = wave + 16 * NW; tb < T; tb += 8 * NW) {      // only if T > 128
+            load_keys(kvA, tb);
+            energies(kvA, tb);
+        }
+    }
+    T2_STAMP(5);
+    // ---- values for the context: issued before the softmax, consumed after it
+    const float* vals = a.values + (size_t)b * T * E;
+    const int EC = E >> 2;
+    const bool vec_ctx = (E & 3) == 0 && EC <= T2_ATTN_THREADS;
+    constexpr int VN = 32;
+    const int NG = vec_ctx ? T2_ATTN_THREADS / EC : 1;
+    const int vg = vec_ctx ? tid / EC : 0, vcq = vec_ctx ? tid - vg * EC : 0;
+    const bool v_active = vec_ctx && vg < NG;
+    f32x4 vv[VN];
+    if (v_active) {
+        const f32x4* vp = reinterpret_cast<const f32x4*>(vals) + vcq;
+#pragma unroll
+        for (int r = 0; r < VN; ++r) vv[r] = vp[(size_t)min(vg + r * NG, len - 1) * EC];
+    }
+    __syncthreads();
+    T2_STAMP(6);
     // ---- phase 3: masked softmax over positions < len (score mask value -inf -> probability exactly 0)
     float m = -INFINITY;
     for (int i = tid; i < len; i += T2_ATTN_THREADS) m = fmaxf(m, s_e[i]);
@@ -517,25 +822,47 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         state[i] = a.cumulative ? (p + s_prev[i + pad_l]) : p;      // :137-140
     }
     __syncthreads();
+    T2_STAMP(7);
     // ---- phase 4: context = alignments . values   (AttentionWrapper._compute_attention)
-    const float* vals = a.values + (size_t)b * T * E;
     float* d0 = a.ctx_dst[0].base ? frag_slot(a.ctx_dst[0], t_step) : nullptr;
     float* d1 = a.ctx_dst[1].base ? frag_slot(a.ctx_dst[1], t_step) : nullptr;
-    for (int c = tid; c < E; c += T2_ATTN_THREADS) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int i = 0;
-        for (; i + 3 < len; i += 4) {
-            s0 = fmaf(s_e[i], vals[(size_t)i * E + c], s0);
-            s1 = fmaf(s_e[i + 1], vals[(size_t)(i + 1) * E + c], s1);
-            s2 = fmaf(s_e[i + 2], vals[(size_t)(i + 2) * E + c], s2);
-            s3 = fmaf(s_e[i + 3], vals[(size_t)(i + 3) * E + c], s3);
+    auto emit = [&](int c, float v) {
+        if (d0) d0[frag_idx(b, a.ctx_dst[0].koff + c, a.MB)] = v;
+        if (d1) d1[frag_idx(b, a.ctx_dst[1].koff + c, a.MB)] = v;
+        if (a.ctx_plain) a.ctx_plain[(size_t)b * E + c] = v;
+    };
+    if (vec_ctx) {
+        if (v_active) {
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < VN; ++r) {
+                const int i = vg + r * NG;
+                const float p = (i < len) ? s_e[i] : 0.f;
+                acc4 += p * vv[r];
+            }
+            const f32x4* vp = reinterpret_cast<const f32x4*>(vals) + vcq;
+            for (int i = vg + VN * NG; i < len; i += NG) acc4 += s_e[i] * vp[(size_t)i * EC];    // only if len > VN*NG
+            *reinterpret_cast<f32x4*>(s_ctx + (size_t)vg * E + 4 * vcq) = acc4;
         }
-        for (; i < len; ++i) s0 = fmaf(s_e[i], vals[(size_t)i * E + c], s0);
-        const float s = (s0 + s1) + (s2 + s3);
-        if (d0) d0[frag_idx(b, a.ctx_dst[0].koff + c, a.MB)] = s;
-        if (d1) d1[frag_idx(b, a.ctx_dst[1].koff + c, a.MB)] = s;
-        if (a.ctx_plain) a.ctx_plain[(size_t)b * E + c] = s;
+        __syncthreads();
+        for (int c = tid; c < E; c += T2_ATTN_THREADS) {
+            float s = 0.f;
+            for (int gg = 0; gg < NG; ++gg) s += s_ctx[gg * E + c];
+            emit(c, s);
+        }
+    } else {
+        for (int c = tid; c < E; c += T2_ATTN_THREADS) {
+            float s0 = 0.f, s1 = 0.f;
+            int i = 0;
+            for (; i + 1 < len; i += 2) {
+                s0 = fmaf(s_e[i], vals[(size_t)i * E + c], s0);
+                s1 = fmaf(s_e[i + 1], vals[(size_t)(i + 1) * E + c], s1);
+            }
+            if (i < len) s0 = fmaf(s_e[i], vals[(size_t)i * E + c], s0);
+            emit(c, s0 + s1);
+        }
     }
+    T2_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -600,8 +927,7 @@ __global__ void mask_memory_kernel(const float* __restrict__ mem, const int* __r
 // conv stack output [B][T][C] -> per-step frag16 inputs of the BiLSTM:
 // dst[dir][s] (frag16 [C]) = x[b][s] (fw) or x[b][len_b-1-s] (bw, tf.reverse_sequence), 0 beyond len.
 __global__ void seq_to_frag_kernel(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ dst,
-                                   int B, int T, int C, int MB) {
-    const int KP = (C + 15) & ~15;
+                                   int B, int T, int C, int MB, int KP) {
     const long long per_step = (long long)MB * 16 * KP;
     const long long n = 2LL * T * per_step;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {

@@ -97,6 +97,7 @@ struct t2_model {
     int* h_ctl = nullptr;               // pinned host mirror of a ctl block
     int opt_graph = 1;                  // use hipGraph chunks for decode loops
     int opt_chunk = 16;                 // steps per graph
+    int opt_splitk = 0;                 // batches > 16 rows: split-K LSTM step with in-launch reduction
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
 };
 
@@ -119,6 +120,9 @@ struct t2_state {
     float* xp[T2_MAX_PRENET_LAYERS] = {nullptr, nullptr, nullptr, nullptr};
     int XA_sz = 0, X1_sz = 0, X2_sz = 0;         // floats per slot
     int KBe = 0, KBa = 0, KBd = 0;
+    unsigned* tickets = nullptr;                 // split-K arrival counters, 3 layers x tiles (zeroed with the slab)
+    unsigned long long* sk_slabs = nullptr;      // split-K partial slabs [tiles][2][512][2]
+    int sk_tiles = 0;
     int* ctl = nullptr;
     // output staging (graph-stable addresses)
     float *o_mel = nullptr, *o_stop = nullptr, *o_hist = nullptr, *i_targets = nullptr;
@@ -127,6 +131,15 @@ struct t2_state {
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     int gchunk[2] = {0, 0};
 };
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+static inline void launch_lstm_splitk(int MB, int n_wg4, hipStream_t st, const SkinnyCore& c, const LstmEpi& e, unsigned* tickets,
+                                      unsigned long long* slabs) {
+    const dim3 grid(2 * ceil_div(n_wg4, 2));
+    if (MB == 2) hipLaunchKernelGGL((lstm_step_splitk_kernel<2>), grid, dim3(T2_SKINNY_THREADS), 0, st, c, e, n_wg4, tickets, slabs);
+    else hipLaunchKernelGGL((lstm_step_splitk_kernel<4>), grid, dim3(T2_SKINNY_THREADS), 0, st, c, e, n_wg4, tickets, slabs);
+}
 
 // optional HIP-event timing of the decoder LSTM launches (eager mode only; bench.py's roofline leg)
 struct LstmTimer {
@@ -139,8 +152,9 @@ static LstmTimer g_timer;
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-static inline int pad16(int k) { return (k + 15) & ~15; }
+// every K segment of a skinny operand is padded to 64 (4 k-blocks of 16) so that the kernels' groups of
+// 2 or 4 k-blocks never straddle a segment
+static inline int pad16(int k) { return (k + 63) & ~63; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static int dev_alloc(t2_model* m, void** p, size_t bytes) {
@@ -327,6 +341,10 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     if (!m || !name) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "graph")) m->opt_graph = value;
     else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
+    else if (!strcmp(name, "splitk")) {
+        m->opt_splitk = value;
+        for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+    }
     else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
     else return fail(T2_EINVAL, "unknown option %s", name);
     return T2_OK;
@@ -475,24 +493,47 @@ static int check_batch(int B, int T) {
 
 static inline int mb_for(int B) { const int mb = ceil_div(B, 16); return mb == 3 ? 4 : mb; }
 
+// NPW (groups per wave, fully unrolled ring) instantiations; anything else runs the runtime loop.
+template <int MB, bool ENC>
+static inline void launch_lstm_mb(dim3 grid, hipStream_t st, const SkinnyCore& c, const LstmEpi& e) {
+    constexpr int G = (MB >= 4) ? T2_G4 : 4;
+    const int base = (c.kbtot / G) / T2_SKINNY_WAVES;
+    const dim3 blk(T2_SKINNY_THREADS);
+    if (ENC) { hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 0>), grid, blk, 0, st, c, e); return; }
+    switch (base) {
+        case 3: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 3>), grid, blk, 0, st, c, e); break;
+        case 4: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 4>), grid, blk, 0, st, c, e); break;
+        case 5: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 5>), grid, blk, 0, st, c, e); break;
+        case 7: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 7>), grid, blk, 0, st, c, e); break;
+        case 8: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 8>), grid, blk, 0, st, c, e); break;
+        case 10: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 10>), grid, blk, 0, st, c, e); break;
+        default: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 0>), grid, blk, 0, st, c, e); break;
+    }
+}
 template <bool ENC>
 static inline void launch_lstm(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const LstmEpi& e) {
-    if (MB == 1) hipLaunchKernelGGL((lstm_step_kernel<1, ENC>), grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
-    else if (MB == 2) hipLaunchKernelGGL((lstm_step_kernel<2, ENC>), grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
-    else hipLaunchKernelGGL((lstm_step_kernel<4, ENC>), grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+    if (MB == 1) launch_lstm_mb<1, ENC>(grid, st, c, e);
+    else if (MB == 2) launch_lstm_mb<2, ENC>(grid, st, c, e);
+    else launch_lstm_mb<4, ENC>(grid, st, c, e);
 }
 
-static void timed_lstm(bool timing, int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const LstmEpi& e) {
+static void timed_lstm(bool timing, int MB, int n_wg4, hipStream_t st, const SkinnyCore& c, const LstmEpi& e, unsigned* tickets,
+                       unsigned long long* slabs) {
+    const bool splitk = tickets != nullptr && MB >= 2;
+    auto go = [&]() {
+        if (splitk) launch_lstm_splitk(MB, n_wg4, st, c, e, tickets, slabs);
+        else launch_lstm<false>(MB, dim3(n_wg4, 1), st, c, e);
+    };
     if (timing) {
         if (g_timer.used + 2 > g_timer.ev.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return; g_timer.ev.push_back(ev); }
         }
         (void)hipEventRecord(g_timer.ev[g_timer.used], st);
-        launch_lstm<false>(MB, grid, st, c, e);
+        go();
         (void)hipEventRecord(g_timer.ev[g_timer.used + 1], st);
         g_timer.used += 2;
     } else {
-        launch_lstm<false>(MB, grid, st, c, e);
+        go();
     }
 }
 static inline void launch_dense(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const DenseEpi& e) {
@@ -577,7 +618,7 @@ static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, con
     {
         const long long n = 2LL * T * per_step_c;
         hipLaunchKernelGGL(seq_to_frag_kernel, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, st,
-                           cur, d_lens, xf, B, T, Cx, MB);
+                           cur, d_lens, xf, B, T, Cx, MB, KPc);
     }
     HIP_TRY(hipMemsetAsync(memory_out, 0, (size_t)Mtot * E * 4, st));
     const int h_ctl[8] = {0, 0, T, 0, 0, 0, 0, 0};
@@ -685,6 +726,9 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     const size_t o_ca = carve((size_t)R * A * 4), o_c1 = carve((size_t)R * D * 4), o_c2 = carve((size_t)R * D * 4);
     const size_t o_XA = carve(2 * (size_t)s->XA_sz * 4), o_X1 = carve(2 * (size_t)s->X1_sz * 4), o_X2 = carve(2 * (size_t)s->X2_sz * 4);
     const size_t o_XY = carve((size_t)s->KBd * blk * 4);
+    s->sk_tiles = std::max(ceil_div(m->att_lstm.n_wg, 2), ceil_div(m->lstm1.n_wg, 2));
+    const size_t o_tk = carve((size_t)3 * s->sk_tiles * 4);
+    const size_t o_sk = carve((size_t)s->sk_tiles * 2 * T2_SKINNY_THREADS * 2 * 8);
     const size_t o_xf = carve((size_t)R * pad16(M * nf) * 4);
     size_t o_xp[T2_MAX_PRENET_LAYERS];
     for (int i = 0; i < d.num_prenet_layers; ++i) o_xp[i] = carve((size_t)R * pad16(d.prenet_units[i]) * 4);
@@ -698,6 +742,7 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     s->c_att = (float*)(p + o_ca); s->c1 = (float*)(p + o_c1); s->c2 = (float*)(p + o_c2);
     s->XA = (float*)(p + o_XA); s->X1 = (float*)(p + o_X1); s->X2 = (float*)(p + o_X2); s->XY = (float*)(p + o_XY);
     s->xf = (float*)(p + o_xf);
+    s->tickets = (unsigned*)(p + o_tk); s->sk_slabs = (unsigned long long*)(p + o_sk);
     for (int i = 0; i < d.num_prenet_layers; ++i) s->xp[i] = (float*)(p + o_xp[i]);
     // output staging
     off = 0;
@@ -875,13 +920,13 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.hraw[0] = pp(s->X1, s->X1_sz, 0, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         e.wq = m->wq; e.qpart = s->qpart; e.U = U;
-        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->att_lstm.n_wg, 1), st, c, e);
+        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, m->att_lstm.n_wg, st, c, e, m->opt_splitk ? s->tickets : nullptr, s->sk_slabs);
     }
     // 4./5. location-sensitive attention + context
     {
         AttnArgs a{};
         a.keys = s->keys; a.values = s->values; a.lens = s->lens; a.att_state = s->att_state; a.alignments = s->alignments;
-        a.history = io.hist; a.qpart = s->qpart; a.nparts = m->att_lstm.n_wg;
+        a.history = io.hist; a.qpart = s->qpart; a.nparts = (m->opt_splitk && MB >= 2) ? ceil_div(m->att_lstm.n_wg, 2) : m->att_lstm.n_wg;
         a.ctx_dst[0] = pp(s->XA, s->XA_sz, 1, 0); a.ctx_dst[1] = pp(s->X1, s->X1_sz, 0, KBa * 16); a.ctx_plain = s->ctx_plain;
         a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
         a.B = B; a.T = s->T; a.U = U; a.E = E; a.F = d.attention_filters; a.K = d.attention_kernel; a.MB = MB;
@@ -901,7 +946,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.hprev[0] = pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16); e.hstate[0] = pp(s->X1, s->X1_sz, 1, (KBa + KBe) * 16);
         e.hraw[0] = pp(s->X2, s->X2_sz, 0, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
-        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->lstm1.n_wg, 1), st, c, e);
+        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, m->lstm1.n_wg, st, c, e, m->opt_splitk ? s->tickets + s->sk_tiles : nullptr, s->sk_slabs);
     }
     {
         SkinnyCore c = core(m->lstm2);
@@ -911,7 +956,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.hprev[0] = pp(s->X2, s->X2_sz, 0, s->KBd * 16); e.hstate[0] = pp(s->X2, s->X2_sz, 1, s->KBd * 16);
         e.hraw[0] = single(s->XY, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
-        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, dim3(m->lstm2.n_wg, 1), st, c, e);
+        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, m->lstm2.n_wg, st, c, e, m->opt_splitk ? s->tickets + 2 * s->sk_tiles : nullptr, s->sk_slabs);
     }
     // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
     {

@@ -1,0 +1,207 @@
+"""Mirror of the reference's tacotron/rnn_wrappers.py: the RNNCell decorators that compose one
+decoder step (prenet -> attention-wrapped RNN -> concat context -> mel / stop projections).
+
+Every class keeps the reference's protocol (``state_size``, ``output_size``, ``zero_state``,
+``compute_output_shape``, ``call`` / ``__call__``).  The composition is a *description*: the
+outermost ``OutputAndStopTokenWrapper`` binds the whole stack to the HIP library and one
+``call(inputs, state)`` is one ``t2_decode_step`` (include/t2mi.h).
+"""
+from __future__ import annotations
+
+from math import gcd
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .hparams import T2Dims
+from .modules import PreNet, ZoneoutLSTMCell
+from .weights import init_weights
+
+
+class _Delegating:
+    """state_size / output_size / zero_state delegation shared by the wrappers."""
+
+    @property
+    def state_size(self):
+        return self._cell.state_size
+
+    @property
+    def output_size(self):
+        return self._cell.output_size
+
+    def zero_state(self, batch_size, dtype=None):
+        return self._cell.zero_state(batch_size, dtype)
+
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0], input_shape[1], self.output_size)
+
+    def __call__(self, inputs, state):
+        return self.call(inputs, state)
+
+
+class AttentionWrapperStateSize:
+    """The fields of tf.contrib.seq2seq.AttentionWrapperState that the reference reads
+    (rnn_wrappers.py:68 uses ``state_size.attention``)."""
+
+    def __init__(self, cell_state, attention, alignments):
+        self.cell_state, self.attention, self.time = cell_state, attention, ()
+        self.alignments, self.alignment_history, self.attention_state = alignments, (), alignments
+
+
+class _AttentionWrapperSpec(_Delegating):
+    """Stands for tf.contrib.seq2seq.AttentionWrapper(cell, mechanism, alignment_history=True,
+    output_attention=False) as built at rnn_wrappers.py:118-122."""
+
+    def __init__(self, cell, attention_mechanism):
+        self._cell_spec = cell
+        self.mechanism = attention_mechanism
+
+    @property
+    def state_size(self):
+        m = self.mechanism
+        return AttentionWrapperStateSize(self._cell_spec.state_size, m.values_depth, m.alignments_size)
+
+    @property
+    def output_size(self):
+        return self._cell_spec.output_size      # output_attention=False
+
+    def zero_state(self, batch_size, dtype=None):
+        raise RuntimeError("zero_state is provided by the bound OutputAndStopTokenWrapper")
+
+    def call(self, inputs, state):
+        raise RuntimeError("the attention wrapper runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+
+
+class DecoderPreNetWrapper(_Delegating):
+    """rnn_wrappers.py:30-53."""
+
+    def __init__(self, cell, prenets: Tuple[PreNet, ...]):
+        self._cell = cell
+        self.prenets = tuple(prenets)
+
+    def call(self, inputs, state):
+        raise RuntimeError("runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+
+
+class ConcatOutputAndAttentionWrapper(_Delegating):
+    """rnn_wrappers.py:56-78: output_size = cell output + state_size.attention (:66-68)."""
+
+    def __init__(self, cell):
+        self._cell = cell
+
+    @property
+    def output_size(self):
+        return self._cell.output_size + self._cell.state_size.attention
+
+    def call(self, inputs, state):
+        raise RuntimeError("runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+
+
+class AttentionRNN(_Delegating):
+    """rnn_wrappers.py:112-144: ``cell`` is any LSTM cell description (ZoneoutLSTMCell here),
+    ``prenets`` a tuple of PreNet, ``attention_mechanism`` a LocationSensitiveAttention."""
+
+    def __init__(self, cell: ZoneoutLSTMCell, prenets: Tuple[PreNet, ...], attention_mechanism, name=None, dtype=None):
+        attention_cell = _AttentionWrapperSpec(cell, attention_mechanism)
+        prenet_cell = DecoderPreNetWrapper(attention_cell, prenets)     # prenet -> attention
+        concat_cell = ConcatOutputAndAttentionWrapper(prenet_cell)      # prenet -> attention -> concat
+        self._cell = concat_cell
+        self.lstm, self.prenets, self.mechanism = cell, tuple(prenets), attention_mechanism
+
+    def call(self, inputs, state):
+        raise RuntimeError("runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+
+
+class OutputProjectionWrapper(_Delegating):
+    """rnn_wrappers.py:147-186 (Tacotron-1 only).  The constructor check is kept; the projection
+    itself belongs to the V1 path, which is not built yet."""
+
+    def __init__(self, cell, output_size, activation=None, use_bias=True, name=None, dtype=None):
+        if output_size < 1:
+            raise ValueError("Parameter output_size must be > 0: %d." % output_size)
+        self._cell = cell
+        self._output_size = output_size
+        self._activation = activation
+        self._use_bias = use_bias
+
+    @property
+    def output_size(self):
+        return self._output_size
+
+    def call(self, inputs, state):
+        raise NotImplementedError("OutputProjectionWrapper belongs to the Tacotron v1 path (not built yet)")
+
+
+class OutputAndStopTokenWrapper(_Delegating):
+    """rnn_wrappers.py:81-109.  ``cell`` is a DecoderRNNV2.  Binding (first ``zero_state``) creates the
+    HIP model for the whole cell stack; ``call`` is one t2_decode_step and advances ``state`` in place.
+
+    ``weights``: optional dict with the decoder / attention variables under the names of
+    tacotron2_amd.weights.weight_shapes; missing variables are initialised as TF would
+    (Glorot-uniform kernels, zero biases).  ``n_feed_units`` = num_mels * n_feed_frame, the width of
+    the decoder input (defaults to ``out_units``, i.e. n_feed_frame == outputs_per_step)."""
+
+    def __init__(self, cell, out_units, weights: Optional[Dict[str, np.ndarray]] = None, n_feed_units=None, engine=None,
+                 seed=1234, num_mels=None, name=None, dtype=None):
+        self._out_units = out_units
+        self._cell = cell
+        self._weights = weights
+        self._n_feed_units = n_feed_units or out_units
+        self._engine = engine
+        self._seed = seed
+        self._num_mels = num_mels
+
+    @property
+    def output_size(self):
+        return (self._out_units, 1)
+
+    # -- binding to the HIP library ---------------------------------------------------------
+    def decoder_dims(self) -> T2Dims:
+        att = self._cell.attention_cell
+        mech = att.mechanism
+        g = self._num_mels or gcd(self._out_units, self._n_feed_units)
+        lstms = self._cell.lstms
+        if lstms[0].num_units != lstms[1].num_units:
+            raise ValueError("DecoderRNNV2 uses one out_units for both LSTM layers")
+        zc = {att.lstm._zoneout_cell, lstms[0]._zoneout_cell, lstms[1]._zoneout_cell}
+        zh = {att.lstm._zoneout_outputs, lstms[0]._zoneout_outputs, lstms[1]._zoneout_outputs}
+        if len(zc) != 1 or len(zh) != 1:
+            raise NotImplementedError("one pair of zoneout factors per decoder is supported")
+        for c in (att.lstm, lstms[0], lstms[1]):
+            if c.is_training and (c._zoneout_cell > 0 or c._zoneout_outputs > 0):
+                raise NotImplementedError("training-mode zoneout sampling is not built (inference arithmetic only)")
+        for p in att.prenets:
+            if p.dropout_enabled and p.drop_rate > 0:
+                raise NotImplementedError("active PreNet dropout is not built (inference arithmetic only)")
+        return T2Dims(num_symbols=2, embedding_dim=mech.values_depth, enc_conv_layers=0, enc_units=mech.values_depth,
+                      prenet_units=tuple(p.out_units for p in att.prenets), attention_lstm_units=att.lstm.num_units,
+                      decoder_lstm_units=lstms[0].num_units, attention_dim=mech.num_units,
+                      attention_filters=mech.attention_filters, attention_kernel=mech.attention_kernel,
+                      cumulative_weights=mech.cumulative_weights, num_mels=g, outputs_per_step=self._out_units // g,
+                      n_feed_frame=self._n_feed_units // g, postnet_layers=1, postnet_kernel=1, postnet_channels=1,
+                      zoneout_cell=zc.pop(), zoneout_output=zh.pop())
+
+    def engine(self):
+        if self._engine is None:
+            from .engine import Engine
+            dims = self.decoder_dims()
+            w = init_weights(dims, self._seed)
+            if self._weights:
+                for k, v in self._weights.items():
+                    if k in w and k.split('/')[0] in ('decoder', 'attention'):
+                        w[k] = np.asarray(v, dtype=np.float32)
+            self._engine = Engine(dims, w)
+        return self._engine
+
+    def zero_state(self, batch_size, dtype=None):
+        mech = self._cell.attention_cell.mechanism
+        if batch_size != mech.batch_size:
+            raise ValueError("batch_size does not match the attention memory")
+        return self.engine().new_state(mech.memory, mech.memory_sequence_length)
+
+    def call(self, inputs, state):
+        if inputs.shape[-1] != self._n_feed_units:
+            raise ValueError(f"decoder input width {inputs.shape[-1]} != n_feed_units {self._n_feed_units}")
+        mel_output, stop_token = self.engine().decode_step(state, inputs)
+        return (mel_output, stop_token), state

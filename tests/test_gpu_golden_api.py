@@ -1,0 +1,143 @@
+"""HIP path against the committed golden fixtures (tests/golden/*.npz, made by the CPU oracle) and
+through the reference-shaped Python API (tacotron_v2.py / rnn_wrappers.py / helpers.py mirrors)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import t2_oracle as O
+from tacotron2_amd.hparams import PROFILE_TINY
+from tacotron2_amd.weights import init_weights
+from tests.golden import make_golden as G
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ATOL = 2e-4          # north_star bound is 1e-3 abs
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["tiny_r1_nf1", "tiny_r2_nf1", "tiny_r2_nf2", "mid_teacher", "mid_free", "paper_b1_teacher"])
+def test_hip_matches_golden(name):
+    from tacotron2_amd.tacotron_v2 import TacotronV2Model, ModeKeys
+    d, w, inp = G.materialize(name, G.cases()[name])
+    gold = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    assert abs(G.weights_checksum(w) - float(gold["weights_checksum"])) < 1e-3 * float(gold["weights_checksum"])
+    model = TacotronV2Model(d, w)
+    feats = {"id": None, "text": None, "source": inp["ids"], "source_length": inp["lens"]}
+    if inp["mode"] == "teacher":
+        B, T = inp["targets"].shape[:2]
+        S = T // d.outputs_per_step
+        labels = {"mel": inp["targets"], "done": np.zeros((B, S), np.float32),
+                  "spec_loss_mask": np.ones((B, T), np.float32), "binary_loss_mask": np.ones((B, S), np.float32)}
+        memory = model.engine.encode(inp["ids"], inp["lens"])
+        mel, stop, st = model.decoder(memory, is_training=False, is_validation=True, teacher_forcing=True,
+                                      memory_sequence_length=inp["lens"], target=inp["targets"])
+        align = st[0].alignment_history.stack().permute(1, 2, 0)
+        post = model.postnet(mel)
+        ev = model.model_fn(feats, labels, ModeKeys.EVAL)
+        ref_loss = O.spec_loss(gold["mel"], inp["targets"], labels["spec_loss_mask"])
+        assert abs(float(ev["eval_metric_ops"]["mel_loss_with_teacher"]) - float(ref_loss)) < 1e-4
+    else:
+        pred = model.predict(feats)
+        memory = model.engine.encode(inp["ids"], inp["lens"])
+        mel, stop, align, post = pred["mel"], pred["stop_token"], pred["alignment"], pred["mel_postnet"]
+        assert stop.shape[1] == int(gold["steps"])          # identical stop-step index
+    for k, got in (("memory", memory), ("mel", mel), ("stop", stop), ("alignment", align), ("mel_postnet", post)):
+        np.testing.assert_allclose(_np(got), gold[k], atol=ATOL, err_msg=f"{name}:{k}")
+    model.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_reference_property_free_run_equals_teacher_forced(seed):
+    """The reference's own test (tests/decoder_test.py:42-67) on the HIP decoder, V2 cells:
+    free-running output fed back as teacher-forcing target reproduces alignments, mel and stop."""
+    from tacotron2_amd.tacotron_v2 import DecoderV2
+    rng = np.random.default_rng(seed)
+    bs, num_mels, r = int(rng.integers(1, 4)), int(rng.integers(2, 21)), int(rng.integers(1, 5))
+    t_in, depth = int(rng.integers(5, 21)), int(rng.integers(2, 11)) * 2
+    memory = rng.uniform(-1, 1, (bs, t_in, depth)).astype(np.float32)
+    lens = np.repeat(t_in, bs)
+    dec = DecoderV2(prenet_out_units=(16, 8), drop_rate=0.0, attention_out_units=12, decoder_out_units=20, num_mels=num_mels,
+                    outputs_per_step=r, max_iters=10, n_feed_frame=1, attention_dim=8, attention_kernel=5, attention_filters=4,
+                    seed=seed)
+    out_i, stop_i, st_i = dec(torch.from_numpy(memory).cuda(), is_training=False, memory_sequence_length=lens)
+    assert stop_i.shape[1] == 10
+    out_t, stop_t, st_t = dec(torch.from_numpy(memory).cuda(), is_training=True, memory_sequence_length=lens, target=out_i)
+    al_i = st_i[0].alignment_history.stack().permute(1, 2, 0)
+    al_t = st_t[0].alignment_history.stack().permute(1, 2, 0)
+    np.testing.assert_allclose(_np(al_i), _np(al_t), atol=1e-6)
+    np.testing.assert_allclose(_np(out_i), _np(out_t), atol=1e-6)
+    np.testing.assert_allclose(_np(stop_i), _np(stop_t), atol=1e-6)
+
+
+def test_generic_helper_loop_equals_fused_loops_and_oracle():
+    """RNNCell / Helper protocol path (one t2_decode_step per iteration, helpers.py rules on the
+    host) against the fused device loops and the oracle."""
+    from tacotron2_amd.tacotron_v2 import DecoderV2
+    d = G.MID
+    w = init_weights(d, 9, perturb=True)
+    rng = np.random.default_rng(5)
+    B, T = 3, 14
+    memory = rng.uniform(-1, 1, (B, T, d.enc_units)).astype(np.float32)
+    lens = np.array([14, 9, 12])
+    w, steps = G.tune_stop(d, w, memory, lens, 15, 36)
+    dec = DecoderV2(prenet_out_units=d.prenet_units, drop_rate=0.0, attention_out_units=d.attention_lstm_units,
+                    decoder_out_units=d.decoder_lstm_units, num_mels=d.num_mels, outputs_per_step=d.outputs_per_step,
+                    max_iters=d.max_iters, n_feed_frame=d.n_feed_frame, attention_dim=d.attention_dim,
+                    attention_kernel=d.attention_kernel, attention_filters=d.attention_filters,
+                    zoneout_factor_cell=d.zoneout_cell, zoneout_factor_output=d.zoneout_output, weights=w)
+    mem_t = torch.from_numpy(memory).cuda()
+    mel_o, stop_o, st_o = O.decoder_v2(d, w, memory, memory_sequence_length=lens)
+    assert stop_o.shape[1] == steps
+    for generic in (False, True):
+        mel, stop, st = dec(mem_t, is_training=False, memory_sequence_length=lens, generic_loop=generic)
+        assert stop.shape[1] == steps
+        np.testing.assert_allclose(_np(mel), mel_o, atol=5 * ATOL)
+        np.testing.assert_allclose(_np(stop), stop_o, atol=5 * ATOL)
+        np.testing.assert_allclose(_np(st[0].alignment_history.stack()), np.stack(st_o[0].alignment_history), atol=5 * ATOL)
+    tgt = rng.uniform(0, 1, (B, 12, d.num_mels)).astype(np.float32)
+    mel_o, stop_o, _ = O.decoder_v2(d, w, memory, is_training=True, memory_sequence_length=lens, target=tgt)
+    for generic in (False, True):
+        mel, stop, _ = dec(mem_t, is_training=False, is_validation=True, teacher_forcing=True, memory_sequence_length=lens,
+                           target=tgt, generic_loop=generic)
+        np.testing.assert_allclose(_np(mel), mel_o, atol=ATOL)
+        np.testing.assert_allclose(_np(stop), stop_o, atol=ATOL)
+
+
+def test_api_rejections():
+    from tacotron2_amd.tacotron_v2 import LocationSensitiveAttention, DecoderV2, EncoderV2
+    mem = torch.zeros(1, 4, 6)
+    with pytest.raises(TypeError):
+        LocationSensitiveAttention(8, mem, None, 5, 3, smoothing=True)
+    with pytest.raises(AssertionError):
+        EncoderV2(1, 3, 7, 0.0, 0.0, 0.0, False)
+    dec = DecoderV2(prenet_out_units=(8,), drop_rate=0.5, attention_out_units=8, decoder_out_units=8, num_mels=4,
+                    outputs_per_step=2, attention_dim=4, attention_kernel=3, attention_filters=2)
+    with pytest.raises(NotImplementedError):            # active dropout in training mode is not built
+        dec(mem.cuda(), is_training=True, target=torch.zeros(1, 4, 4))
+    with pytest.raises(AssertionError):
+        DecoderV2(num_mels=4, outputs_per_step=1, n_feed_frame=2)(mem.cuda(), is_training=False)
+
+
+def test_synthesize_driver_and_splitk_option():
+    from tacotron2_amd.synthesize import synthesize
+    from tacotron2_amd.tacotron_v2 import TacotronV2Model
+    d = G.MID.replace(num_symbols=128, max_iters=14)
+    w = init_weights(d, 3, perturb=True)
+    model = TacotronV2Model(d, w)
+    texts = ["HELLO WORLD", "A", "MI355X SPEAKS"] * 7            # 21 rows -> MB = 2
+    res = synthesize(model, texts)
+    assert len(res) == 21 and res[0]["mel"].shape[1] == d.num_mels and res[1]["alignment"].shape[0] == 2
+    model.engine.set_option("splitk", 1)                         # split-K LSTM step must give the same frames
+    res2 = synthesize(model, texts)
+    for a, b in zip(res, res2):
+        np.testing.assert_allclose(a["mel"], b["mel"], atol=1e-5)
+    ids, lens = np.array([[72, 73, 1]]), np.array([3])
+    ref = O.tacotron2_forward(d, w, ids, lens, mode="predict")
+    got = synthesize(model, ["HI"])[0]
+    np.testing.assert_allclose(got["mel"], ref["mel_postnet"][0], atol=5 * ATOL)
+    model.close()
