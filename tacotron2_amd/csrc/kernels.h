@@ -598,20 +598,20 @@ struct AttnArgs {
 
 #define T2_ATTN_THREADS 512
 
+__host__ __device__ inline int attn_upl(int U, int F) { return (F <= 32 && U <= 128) ? 2 : 4; }
+
 __host__ __device__ inline int attn_lds_floats(int T, int U, int F, int K) {
-    const int FP = (F + 3) & ~3, KP = (K + 3) & ~3;
-    return ((T + KP + 16 + 3) & ~3) + KP * FP + ((T + 8) * FP) + ((T + 3) & ~3) + 2 * ((U + 3) & ~3) * 4 + 64 + 2048;
+    const int FP = (F + 3) & ~3, KP = (K + 3) & ~3, UP = (U + 3) & ~3;
+    const int FMAX = attn_upl(U, F) == 2 ? 32 : 64;
+    return ((T + KP + 16 + 3) & ~3) + KP * FP + ((T + 8) * FMAX) + ((T + 3) & ~3) + 17 * UP + 64 + 2048 + FMAX * 64 * attn_upl(U, F);
 }
 
 // tanh via v_exp_f32 / v_rcp_f32: abs error < 1e-6 (the energies feed a softmax; tolerance budget 1e-3)
 __device__ __forceinline__ float fast_tanhf(float x) {
     const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-// The kernel is a chain of short phases on ONE workgroup per batch row, so its time is mostly load
-// latency.  Every global load that does not depend on this step's LDS work (query partials, keys,
-// location-layer columns, and later the values) is issued as early as possible and consumed late.
 #ifdef T2_ATTN_STAMPS   // diagnostic builds (tools/attn_bench.hip) only
 __device__ unsigned long long* g_attn_stamps;
 #define T2_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_attn_stamps[i] = clock64(); } while (0)
@@ -619,8 +619,19 @@ __device__ unsigned long long* g_attn_stamps;
 #define T2_STAMP(i) do { } while (0)
 #endif
 
+template <int N> struct VecOf;
+template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// The kernel is a chain of short phases on ONE workgroup per batch row, so its time is load latency
+// and instruction issue on one CU.  Every global load that does not depend on this step's LDS work
+// (query partials, keys, later the values) is issued early, in the order it is needed, with wide
+// loads; the location-layer matrix goes through LDS once instead of once per wave; the per-position
+// sums over attention units are reduced eight positions at a time (transposed butterfly).
+// Lane l owns attention units UPL*l .. UPL*l + UPL-1.
 template <int FMAX, int UPL>
 __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArgs a) {
+    typedef typename VecOf<UPL>::type vecu;
     T2_STAMP(0);
     const int t_step = step_index(a.ctl, a.step_off);
     if (t_step < 0) return;
@@ -630,50 +641,22 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
     const int FP = (F + 3) & ~3, KP = (K + 3) & ~3;
     const int pad_l = (K - 1) / 2;
     const int UP = (U + 3) & ~3;
+    constexpr int UW = 64 * UPL;                        // padded unit count of the register layout
     float* s_prev = smem;                               // [T + KP + 16]: index i <-> position i - pad_l
     float* s_cw = s_prev + ((T + KP + 16 + 3) & ~3);    // [KP][FP] conv kernel, zero padded
-    float* s_f = s_cw + KP * FP;                        // [T + 8][FP]
-    float* s_e = s_f + (T + 8) * FP;                    // [T]
-    float* s_q = s_e + ((T + 3) & ~3);                  // [4][UP] partial sums, then [4*UP ..] = q + b_a
-    float* s_red = s_q + 8 * UP;                        // [64]
+    float* s_f = s_cw + KP * FP;                        // [T + 8][FMAX], columns >= F are zero
+    float* s_e = s_f + (T + 8) * FMAX;                  // [T]
+    float* s_q = s_e + ((T + 3) & ~3);                  // [16][UP] partial sums, then [16*UP ..] = q + b_a
+    float* s_red = s_q + 17 * UP;                       // [64]
     float* s_ctx = s_red + 64;                          // [<= 2048] context partials
+    float* s_wl = s_ctx + 2048;                         // [FMAX][UW] location layer, zero padded
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = T2_ATTN_THREADS / 64;
     const int len = a.lens[b];
     float* state = a.att_state + (size_t)b * T;
 
-    // ---- early loads ----
-    constexpr int QN = 64;                               // query partials per thread held in registers
-    const int QG = min(4, T2_ATTN_THREADS / U);
-    const bool q_active = tid < QG * U;
-    const int qg = tid / U, qu = tid - qg * U;
-    const float* qp = a.qpart + (size_t)b * U + (q_active ? qu : 0);
-    const size_t pstride = (size_t)a.MB * 16 * U;
-    float qv[QN];
-#pragma unroll
-    for (int i = 0; i < QN; ++i) qv[i] = qp[(size_t)min(qg + i * QG, a.nparts - 1) * pstride];
-    const float* keys = a.keys + (size_t)b * T * U;
-    float kvA[8][UPL], kvB[8][UPL];
-    auto load_keys = [&](float (&kv)[8][UPL], int tb) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int tt = min(tb + r * NW, T - 1);
-#pragma unroll
-            for (int i = 0; i < UPL; ++i) kv[r][i] = keys[(size_t)tt * U + min(lane + 64 * i, U - 1)];
-        }
-    };
-    load_keys(kvA, wave);
-    load_keys(kvB, wave + 8 * NW);
-    float wl[FMAX][UPL];                                 // location-layer columns of this lane's units
-    float va[UPL], kq[UPL];
-#pragma unroll
-    for (int i = 0; i < UPL; ++i) {
-        const int u = lane + 64 * i;
-        va[i] = (u < U) ? a.v_a[u] : 0.f;                // va == 0 masks lanes with u >= U
-#pragma unroll
-        for (int c = 0; c < FMAX; ++c) wl[c][i] = (c < F && u < U) ? a.wloc[c * U + u] : 0.f;
-    }
+    // ---- early loads, in the order they are consumed ----
     for (int i = tid; i < T + KP + 16; i += T2_ATTN_THREADS) {
         const int p = i - pad_l;
         s_prev[i] = (p >= 0 && p < T) ? state[p] : 0.f;
@@ -682,14 +665,82 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         const int j = i / FP, c = i - j * FP;
         s_cw[i] = (j < K && c < F) ? a.conv_w[j * F + c] : 0.f;
     }
+    // location layer [F][U]: loaded to registers now (small, issued before the big loads), staged to LDS
+    // [FMAX][UW] (zero padded) after the conv phase, once per workgroup instead of once per wave
+    constexpr int WLN = FMAX * UW / 4 / T2_ATTN_THREADS;
+    f32x4 wlreg[WLN];
+    {
+        const bool w_vec = (U & 3) == 0;
+#pragma unroll
+        for (int k = 0; k < WLN; ++k) {
+            const int i4 = tid + k * T2_ATTN_THREADS;
+            const int c = i4 / (UW / 4), u4 = (i4 - c * (UW / 4)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < F) {
+                if (w_vec && u4 + 3 < U) v = *reinterpret_cast<const f32x4*>(a.wloc + (size_t)c * U + u4);
+                else {
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) if (u4 + e4 < U) v[e4] = a.wloc[(size_t)c * U + u4 + e4];
+                }
+            }
+            wlreg[k] = v;
+        }
+    }
+    // query partials: thread -> (unit quad, part group), float4 loads, up to 16 in flight per thread
+    constexpr int QN = 16;
+    const bool q_vec = (U & 3) == 0;
+    const int QV = q_vec ? (U >> 2) : U;                // columns of the partial matrix in load units
+    const int PG = min(16, T2_ATTN_THREADS / QV);       // part groups
+    const bool q_active = tid < PG * QV;
+    const int qg = q_active ? tid / QV : 0, qc = q_active ? tid - qg * QV : 0;
+    const size_t pstride = (size_t)a.MB * 16 * U;
+    const float* qbase = a.qpart + (size_t)b * U;
+    f32x4 qv[QN];
+    if (q_vec) {
+#pragma unroll
+        for (int i = 0; i < QN; ++i)
+            qv[i] = *reinterpret_cast<const f32x4*>(qbase + (size_t)min(qg + i * PG, a.nparts - 1) * pstride + 4 * qc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < QN; ++i) {
+            const float v = qbase[(size_t)min(qg + i * PG, a.nparts - 1) * pstride + qc];
+            qv[i] = f32x4{v, 0.f, 0.f, 0.f};
+        }
+    }
+    // keys of this wave's positions tb, tb + NW, ... (8 per batch)
+    const float* keys = a.keys + (size_t)b * T * U;
+    const bool k_vec = (U % UPL) == 0;
+    vecu kvA[8], kvB[8];
+    auto load_keys = [&](vecu (&kv)[8], int tb) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int tt = min(tb + r * NW, T - 1);
+            if (k_vec) {
+                kv[r] = *reinterpret_cast<const vecu*>(keys + (size_t)tt * U + min(UPL * lane, U - UPL));
+            } else {
+#pragma unroll
+                for (int i = 0; i < UPL; ++i) kv[r][i] = keys[(size_t)tt * U + min(UPL * lane + i, U - 1)];
+            }
+        }
+    };
+    load_keys(kvA, wave);
+    load_keys(kvB, wave + 8 * NW);
+    float va[UPL], kq[UPL];
+#pragma unroll
+    for (int i = 0; i < UPL; ++i) { const int u = UPL * lane + i; va[i] = (u < U) ? a.v_a[u] : 0.f; }   // 0 masks u >= U
     T2_STAMP(1);
     __syncthreads();
     T2_STAMP(2);
     // ---- phase 1: location features f[t][c] = sum_j w[j][c] * prev[t + j - pad_l] + b[c]   (:128-130)
     {
         const int nblk = (T + 7) >> 3;
-        for (int item = tid; item < nblk * F; item += T2_ATTN_THREADS) {
-            const int c = item % F, t0 = (item / F) << 3;
+        for (int item = tid; item < nblk * FMAX; item += T2_ATTN_THREADS) {
+            const int c = item % FMAX, t0 = (item / FMAX) << 3;
+            if (c >= F) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s_f[(t0 + i) * FMAX + c] = 0.f;
+                continue;
+            }
             float accv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) accv[i] = 0.f;
@@ -715,60 +766,100 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
             }
             const float bc = a.conv_b[c];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s_f[(t0 + i) * FP + c] = accv[i] + bc;
+            for (int i = 0; i < 8; ++i) s_f[(t0 + i) * FMAX + c] = accv[i] + bc;
         }
     }
+#pragma unroll
+    for (int k = 0; k < WLN; ++k) *reinterpret_cast<f32x4*>(s_wl + 4 * (tid + k * T2_ATTN_THREADS)) = wlreg[k];
     T2_STAMP(3);
     // processed query (tacotron_v2.py:122): sum over the attention-LSTM workgroups' partial products
     {
-        float s0 = 0.f;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < QN; ++i) s0 += (qg + i * QG < a.nparts) ? qv[i] : 0.f;
-        for (int p = qg + QN * QG; p < a.nparts; p += QG) s0 += qp[(size_t)p * pstride];   // only if nparts > 256
-        if (q_active) s_q[qg * UP + qu] = s0;
+        for (int i = 0; i < QN; ++i) s0 += (qg + i * PG < a.nparts) ? qv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = qg + QN * PG; p < a.nparts; p += PG) {          // only if nparts > 16 * PG
+            if (q_vec) s0 += *reinterpret_cast<const f32x4*>(qbase + (size_t)p * pstride + 4 * qc);
+            else s0[0] += qbase[(size_t)p * pstride + qc];
+        }
+        if (q_active) {
+            if (q_vec) *reinterpret_cast<f32x4*>(s_q + qg * UP + 4 * qc) = s0;
+            else s_q[qg * UP + qc] = s0[0];
+        }
     }
     __syncthreads();
     if (tid < U) {
-        float s = a.b_a[tid];
-        for (int g = 0; g < QG; ++g) s += s_q[g * UP + tid];
-        s_q[4 * UP + tid] = s;          // q[u] + b_a[u]
+        float sq = a.b_a[tid];
+        for (int g = 0; g < PG; ++g) sq += s_q[g * UP + tid];
+        s_q[16 * UP + tid] = sq;          // q[u] + b_a[u]
     }
     __syncthreads();
+    // location-layer columns of this lane's units: LDS -> registers
+    float wl[FMAX][UPL];
+#pragma unroll
+    for (int c = 0; c < FMAX; ++c) {
+        const vecu w = *reinterpret_cast<const vecu*>(s_wl + c * UW + UPL * lane);
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) wl[c][i] = w[i];
+    }
     T2_STAMP(4);
-    // ---- phase 2: energies   (:131-133, :66-78); one wave per position, lanes over attention units
+    // ---- phase 2: energies   (:131-133, :66-78); one wave per position, 8 positions per batch
     {
 #pragma unroll
-        for (int i = 0; i < UPL; ++i) { const int u = lane + 64 * i; kq[i] = (u < U) ? s_q[4 * UP + u] : 0.f; }
-        auto energies = [&](const float (&kv)[8][UPL], int tb) {
+        for (int i = 0; i < UPL; ++i) { const int u = UPL * lane + i; kq[i] = (u < U) ? s_q[16 * UP + u] : 0.f; }
+        auto energies = [&](const vecu (&kv)[8], int tb) {
+            float part[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int tt = tb + r * NW;
-                if (tt < T) {
-                    float pf[UPL];
+                const int tt = min(tb + r * NW, T - 1);           // clamped: branch-free, invalid ones are not stored
+                float pf[UPL];
 #pragma unroll
-                    for (int i = 0; i < UPL; ++i) pf[i] = 0.f;
-                    const float* ft = s_f + tt * FP;
+                for (int i = 0; i < UPL; ++i) pf[i] = 0.f;
+                const float* ft = s_f + tt * FMAX;
 #pragma unroll
-                    for (int c4 = 0; c4 < FMAX; c4 += 4) {
-                        if (c4 < FP) {
-                            const f32x4 fv = *reinterpret_cast<const f32x4*>(ft + c4);
+                for (int c4 = 0; c4 < FMAX; c4 += 4) {
+                    const f32x4 fv = *reinterpret_cast<const f32x4*>(ft + c4);
 #pragma unroll
-                            for (int cc = 0; cc < 4; ++cc)
+                    for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-                                for (int i = 0; i < UPL; ++i) pf[i] = fmaf(fv[cc], wl[c4 + cc][i], pf[i]);
-                        }
-                    }
-                    float part = 0.f;
-#pragma unroll
-                    for (int i = 0; i < UPL; ++i) part += va[i] * fast_tanhf(kv[r][i] + kq[i] + pf[i]);
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-                    if (lane == 0) s_e[tt] = part;
+                        for (int i = 0; i < UPL; ++i) pf[i] = fmaf(fv[cc], wl[c4 + cc][i], pf[i]);
                 }
+                float p = 0.f;
+#pragma unroll
+                for (int i = 0; i < UPL; ++i) p += va[i] * fast_tanhf(kv[r][i] + kq[i] + pf[i]);
+                part[r] = p;
+            }
+            // transposed butterfly: 8 sums over 64 lanes with 10 shuffles; position r ends on lanes with
+            // (lane>>5, (lane>>4)&1, (lane>>3)&1) = bits of r, lane & 7 == 0
+            float p4[4], p2[2], p1;
+            const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float send = h5 ? part[k] : part[k + 4];
+                const float keep = h5 ? part[k + 4] : part[k];
+                p4[k] = keep + __shfl_xor(send, 32);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float send = h4 ? p4[k] : p4[k + 2];
+                const float keep = h4 ? p4[k + 2] : p4[k];
+                p2[k] = keep + __shfl_xor(send, 16);
+            }
+            {
+                const float send = h3 ? p2[0] : p2[1];
+                const float keep = h3 ? p2[1] : p2[0];
+                p1 = keep + __shfl_xor(send, 8);
+            }
+            p1 += __shfl_xor(p1, 4);
+            p1 += __shfl_xor(p1, 2);
+            p1 += __shfl_xor(p1, 1);
+            if ((lane & 7) == 0) {
+                const int r = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
+                const int tt = tb + r * NW;
+                if (tt < T) s_e[tt] = p1;
             }
         };
         energies(kvA, wave);
-        energies(kvB, wave + 8 * NW);
+        if (wave + 8 * NW < T) energies(kvB, wave + 8 * NW);
         for (int tb = wave + 16 * NW; tb < T; tb += 8 * NW) {      // only if T > 128
             load_keys(kvA, tb);
             energies(kvA, tb);
@@ -846,9 +937,9 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         }
         __syncthreads();
         for (int c = tid; c < E; c += T2_ATTN_THREADS) {
-            float s = 0.f;
-            for (int gg = 0; gg < NG; ++gg) s += s_ctx[gg * E + c];
-            emit(c, s);
+            float sc = 0.f;
+            for (int gg = 0; gg < NG; ++gg) sc += s_ctx[gg * E + c];
+            emit(c, sc);
         }
     } else {
         for (int c = tid; c < E; c += T2_ATTN_THREADS) {
