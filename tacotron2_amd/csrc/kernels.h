@@ -332,15 +332,24 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
     if (!ENC) {
         if (e.wq == nullptr) return;
         __syncthreads();
+        // thread -> (row group, unit u): the 4 query-layer rows of this workgroup's hidden units stay in
+        // registers; only the valid batch rows are produced (the attention kernel reads rows < B)
         const int U = e.U;
-        const float* wq = e.wq + (size_t)blockIdx.x * 4 * U;
-        const int nvalid = min(4, e.H - (int)blockIdx.x * 4);
-        float* qp = e.qpart + (size_t)blockIdx.x * MB * 16 * U;
-        for (int i = threadIdx.x; i < MB * 16 * U; i += T2_SKINNY_THREADS) {
-            const int row = i / U, u = i - row * U;
-            float s = 0.f;
-            for (int uu = 0; uu < nvalid; ++uu) s = fmaf(s_h[row * 4 + uu], wq[uu * U + u], s);
-            qp[i] = s;
+        const int RG = max(1, T2_SKINNY_THREADS / U);
+        if ((int)threadIdx.x < RG * U) {
+            const int rg = threadIdx.x / U, u = threadIdx.x - rg * U;
+            const float* wq = e.wq + (size_t)blockIdx.x * 4 * U + u;
+            const int nvalid = min(4, e.H - (int)blockIdx.x * 4);
+            float wv[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) wv[uu] = uu < nvalid ? wq[uu * U] : 0.f;
+            float* qp = e.qpart + (size_t)blockIdx.x * MB * 16 * U + u;
+            for (int row = rg; row < a.B; row += RG) {
+                float sq = 0.f;
+#pragma unroll
+                for (int uu = 0; uu < 4; ++uu) sq = fmaf(s_h[row * 4 + uu], wv[uu], sq);
+                qp[(size_t)row * U] = sq;
+            }
         }
     }
 }
