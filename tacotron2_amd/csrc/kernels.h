@@ -72,10 +72,14 @@ struct SkinnyCore {
     const float* w[2];        // packed weights per direction (blockIdx.y)
     const float* bias[2];     // LSTM: packed [n_wg][16]; dense: [N] (may be null)
     FragBuf seg[2][2];        // per direction: k-blocks [0,kb0) from seg[.][0], [kb0,kbtot) from seg[.][1]
-    int kb0;
-    int kbtot;
+    int kb0;                  // k-blocks (of this launch) served by seg[.][0]
+    int kbtot;                // k-blocks of this launch
+    int kb_w0;                // first k-block of the weight slab used by this launch
+    int kb_full;              // k-blocks per workgroup slab (slab stride)
     const int* ctl;
     int step_off;
+    int t_hint;               // >= 0: step index known to select the same operand slots as the real one (lets the
+                              // activation loads start before ctl arrives); -1: wait for ctl
     int B;                    // valid rows
 };
 
@@ -92,6 +96,7 @@ struct LstmEpi {
     int plain_bs, plain_ts;   // batch / time strides (floats)
     int plain_off[2];         // column offset per direction
     int reverse[2];           // direction writes to position len-1-t
+    const float* zpart;       // optional partial pre-activations of the recurrent K range (partial_step_kernel), D-fragment layout
     // fused partial query (attention LSTM only): qpart[wg][row][u] = sum_uu h[row][4wg+uu] * wq[4wg+uu][u]
     const float* wq;          // [A][U] or null
     float* qpart;             // [n_wg][MB*16][U]
@@ -186,8 +191,6 @@ __device__ __forceinline__ void kg_mma(const KGroup<MB, G>& g, f32x4 (&acc)[MB])
 template <int NBUF, int N, class Buf, class Mma, class LoadW, class LoadA, class GIdx>
 __device__ __forceinline__ void ring_static(Buf (&buf)[NBUF], Mma&& mma, LoadW&& load_w, LoadA&& load_a, GIdx&& gidx) {
 #pragma unroll
-    for (int i = 0; i < NBUF; ++i) load_a(buf[i], gidx(i < N ? i : N - 1));
-#pragma unroll
     for (int g = 0; g < N; ++g) {
         mma(buf[g % NBUF]);
         if (g + NBUF < N) {
@@ -204,8 +207,8 @@ __device__ __forceinline__ void ring_static(Buf (&buf)[NBUF], Mma&& mma, LoadW&&
 #ifndef T2_NBUF
 #define T2_NBUF 3    // groups in flight per wave (3 measured best: tools/lstm_bench.hip)
 #endif
-template <int MB, int NPW>
-__device__ __forceinline__ int skinny_core(const SkinnyCore& a, int dir, f32x4 (&acc)[MB]) {
+template <int MB, int NPW, class Pre>
+__device__ __forceinline__ int skinny_core(const SkinnyCore& a, int dir, int wg, f32x4 (&acc)[MB], Pre&& pre) {
     constexpr int G = (MB >= 4) ? T2_G4 : 4;
     constexpr int NBUF = T2_NBUF;
     const int lane = threadIdx.x & 63;
@@ -214,10 +217,10 @@ __device__ __forceinline__ int skinny_core(const SkinnyCore& a, int dir, f32x4 (
     const int base = ng / T2_SKINNY_WAVES, rem = ng % T2_SKINNY_WAVES;
     const int lo = wave * base + min(wave, rem);
     const int n = base + (wave < rem ? 1 : 0);
-    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.w[dir]) + (size_t)blockIdx.x * a.kbtot * 64 + lane;
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.w[dir]) + ((size_t)wg * a.kb_full + a.kb_w0) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int rot = n > 0 ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)n) : 0;
+    const int rot = n > 0 ? (int)(((unsigned)wg * 7u + (unsigned)dir * 3u) % (unsigned)n) : 0;
     auto gidx = [&](int i) { const int j = i + rot; return lo + (j >= n ? j - n : j); };
     auto load_w = [&](KGroup<MB, G>& b, int g) { kg_load_w<MB, G>(b, wp, g * G); };
     KGroup<MB, G> buf[NBUF];
@@ -225,15 +228,30 @@ __device__ __forceinline__ int skinny_core(const SkinnyCore& a, int dir, f32x4 (
 #pragma unroll
         for (int i = 0; i < NBUF; ++i) load_w(buf[i], gidx(min(i, n - 1)));
     }
+    // activation prologue: with a slot hint it is issued before ctl is back
+    const f32x4* ap0 = nullptr;
+    const f32x4* ap1 = nullptr;
+    auto set_ap = [&](int ts) {
+        ap0 = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][0], ts)) + (size_t)(a.seg[dir][0].koff >> 4) * MB * 64 + lane;
+        ap1 = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][1], ts)) + (size_t)(a.seg[dir][1].koff >> 4) * MB * 64 + lane;
+    };
+    auto load_a = [&](KGroup<MB, G>& b, int g) {
+        const f32x4* ap = g < ng0 ? ap0 + (size_t)g * G * MB * 64 : ap1 + (size_t)(g - ng0) * G * MB * 64;
+        kg_load_a<MB, G>(b, ap, 0);
+    };
+    auto prologue_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i) load_a(buf[i], gidx(min(i, n - 1)));
+    };
+    const bool hinted = a.t_hint >= 0;
+    if (hinted && n > 0) { set_ap(a.t_hint); prologue_a(); }
     const int t = step_index(a.ctl, a.step_off);
     if (t < 0) return -1;
+    pre(t);                      // the caller's epilogue-operand prefetch
     if (n > 0) {
-        const f32x4* ap0 = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][0], t)) + (size_t)(a.seg[dir][0].koff >> 4) * MB * 64 + lane;
-        const f32x4* ap1 = reinterpret_cast<const f32x4*>(frag_slot(a.seg[dir][1], t)) + (size_t)(a.seg[dir][1].koff >> 4) * MB * 64 + lane;
-        auto load_a = [&](KGroup<MB, G>& b, int g) {
-            const f32x4* ap = g < ng0 ? ap0 + (size_t)g * G * MB * 64 : ap1 + (size_t)(g - ng0) * G * MB * 64;
-            kg_load_a<MB, G>(b, ap, 0);
-        };
+        const bool same = hinted && frag_slot(a.seg[dir][0], t) == frag_slot(a.seg[dir][0], a.t_hint) &&
+                          frag_slot(a.seg[dir][1], t) == frag_slot(a.seg[dir][1], a.t_hint);
+        if (!same) { set_ap(t); prologue_a(); }     // no hint, or (host bug) a hint that selects other slots
         bool done = false;
         if constexpr (NPW > 0) {
             if (base == NPW) {      // checked on the device too: a wrong NPW must never walk out of the slab
@@ -244,8 +262,6 @@ __device__ __forceinline__ int skinny_core(const SkinnyCore& a, int dir, f32x4 (
             }
         }
         if (!done) {
-#pragma unroll
-            for (int i = 0; i < NBUF; ++i) load_a(buf[i], gidx(min(i, n - 1)));
             for (int g = 0; g < n; g += NBUF) {
 #pragma unroll
                 for (int i = 0; i < NBUF; ++i) {
@@ -288,38 +304,50 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
     __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
     __shared__ float s_h[MB * 16 * 4];
     f32x4 acc[MB];
-    const int t = skinny_core<MB, NPW>(a, dir, acc);
+    // epilogue operands of thread (row, unit): requested as soon as the step index is known, used after the GEMM
+    const int idx = threadIdx.x;
+    const int row = idx >> 2, uu = idx & 3;
+    const int unit = blockIdx.x * 4 + uu;
+    const bool owner = idx < MB * 16 * 4 && row < a.B && unit < e.H;
+    float cp = 0.f, hp = 0.f, zp4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+    int len = 0;
+    const int t = skinny_core<MB, NPW>(a, dir, blockIdx.x, acc, [&](int tt) {
+        if (owner) {
+            cp = e.c[dir][(size_t)row * e.Hld + unit];
+            hp = frag_slot(e.hprev[dir], tt)[frag_idx(row, e.hprev[dir].koff + unit, MB)];
+            const float* bias = a.bias[dir] + (size_t)blockIdx.x * 16;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) b4[g4] = bias[g4 * 4 + uu];
+            if (e.zpart != nullptr) {
+                const float* zp = e.zpart + ((size_t)(blockIdx.x * MB + (row >> 4)) * 64 + ((row & 15) >> 2) * 16) * 4 + (row & 3);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) zp4[g4] = zp[(g4 * 4 + uu) * 4];
+            }
+            if (e.lens != nullptr) len = e.lens[row];
+        }
+    });
     if (t < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
     __syncthreads();
-    const int idx = threadIdx.x;
     if (idx < MB * 16 * 4) {
-        const int row = idx >> 2, uu = idx & 3;
-        const int unit = blockIdx.x * 4 + uu;
         float hn = 0.f;
-        if (row < a.B && unit < e.H) {
-            const float* bias = a.bias[dir] + (size_t)blockIdx.x * 16;
-            const float zi = red_sum<MB>(red, row, 0 * 4 + uu) + bias[0 * 4 + uu];
-            const float zj = red_sum<MB>(red, row, 1 * 4 + uu) + bias[1 * 4 + uu];
-            const float zf = red_sum<MB>(red, row, 2 * 4 + uu) + bias[2 * 4 + uu];
-            const float zo = red_sum<MB>(red, row, 3 * 4 + uu) + bias[3 * 4 + uu];
-            float* cptr = e.c[dir] + (size_t)row * e.Hld + unit;
-            const float cp = *cptr;
-            const float hp = frag_slot(e.hprev[dir], t)[frag_idx(row, e.hprev[dir].koff + unit, MB)];
+        if (owner) {
+            const float zi = red_sum<MB>(red, row, 0 * 4 + uu) + b4[0] + zp4[0];
+            const float zj = red_sum<MB>(red, row, 1 * 4 + uu) + b4[1] + zp4[1];
+            const float zf = red_sum<MB>(red, row, 2 * 4 + uu) + b4[2] + zp4[2];
+            const float zo = red_sum<MB>(red, row, 3 * 4 + uu) + b4[3] + zp4[3];
             const float cn = sigmoidf_(zf + e.fb) * cp + sigmoidf_(zi) * tanhf(zj);
             hn = sigmoidf_(zo) * tanhf(cn);
             float cs = (1.0f - e.zc) * cn + e.zc * cp;
             float hs = (1.0f - e.zh) * hn + e.zh * hp;
             bool live = true;
-            int len = 0;
             if (e.lens != nullptr) {
-                len = e.lens[row];
                 live = t < len;
                 if (!live) { cs = cp; hs = hp; hn = 0.f; }   // dynamic_rnn: zero output, state copied through
             }
-            *cptr = cs;
+            e.c[dir][(size_t)row * e.Hld + unit] = cs;
             frag_slot(e.hstate[dir], t)[frag_idx(row, e.hstate[dir].koff + unit, MB)] = hs;
             if (e.hraw[dir].base != nullptr) frag_slot(e.hraw[dir], t)[frag_idx(row, e.hraw[dir].koff + unit, MB)] = hn;
             if (e.plain_out != nullptr && live) {
@@ -355,6 +383,47 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
 }
 
 // ------------------------------------------------------------------------------------------------
+// Recurrent-half pre-activations: z_part = [state operands of step t] . kernel[their K range].  These
+// operands are known as soon as the previous step's producer has run, so this launch sits on a side
+// branch of the step graph and overlaps the attention / prenet / projection chain; the LSTM step then
+// only multiplies the operands produced in its own step and adds z_part (LstmEpi::zpart).
+// Output: the summed 16x16 tiles in D-fragment layout, [wg][rb][lane] float4.
+// ------------------------------------------------------------------------------------------------
+template <int MB, int NPW>
+__device__ __forceinline__ void partial_body(const SkinnyCore& a, float* __restrict__ zout, int wg, f32x4* red) {
+    f32x4 acc[MB];
+    const int t = skinny_core<MB, NPW>(a, 0, wg, acc, [](int) {});
+    if (t < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
+    __syncthreads();
+    for (int i = threadIdx.x; i < MB * 64; i += T2_SKINNY_THREADS) {
+        f32x4 sacc = red[i];
+#pragma unroll
+        for (int w = 1; w < T2_SKINNY_WAVES; ++w) sacc += red[w * MB * 64 + i];
+        reinterpret_cast<f32x4*>(zout)[(size_t)wg * MB * 64 + i] = sacc;
+    }
+}
+
+template <int MB, int NPW = 0>
+__global__ __launch_bounds__(T2_SKINNY_THREADS) void partial_step_kernel(SkinnyCore a, float* __restrict__ zout) {
+    __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
+    partial_body<MB, NPW>(a, zout, blockIdx.x, red);
+}
+
+// Up to two recurrent-half jobs that ride in front of a small kernel's grid (horizontal fusion): the
+// attention step (one CU per batch row) and the projection step (a dozen workgroups) leave most of the
+// chip idle, and kernels of different streams / graph branches were measured not to overlap on this
+// stack, so the independent GEMM work is put into the SAME launch: the host kernel's own workgroups
+// come first (they are the critical path), then n0 workgroups of job 0 and n1 of job 1.
+struct PartialJobs {
+    SkinnyCore core[2];
+    float* z[2];
+    int n[2];
+};
+
+// ------------------------------------------------------------------------------------------------
 // Split-K LSTM step for batches > 16 rows.  With 4 units (16 columns) per workgroup every CU has to
 // pull the whole activation matrix through its L1 (B*K*4 bytes, ~0.65 MB at B=64), which, not the
 // MFMA pipe, bounds the kernel.  Here a workgroup owns 8 units (two 16-column tiles) and HALF of K:
@@ -388,8 +457,8 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_splitk_kernel(Ski
     const int lo = h_lo + wave * base + min(wave, rem);
     const int n = base + (wave < rem ? 1 : 0);
     const int t0i = 2 * tile, t1i = min(2 * tile + 1, n_wg4 - 1);
-    const f32x4* __restrict__ wp0 = reinterpret_cast<const f32x4*>(a.w[0]) + (size_t)t0i * a.kbtot * 64 + lane;
-    const f32x4* __restrict__ wp1 = reinterpret_cast<const f32x4*>(a.w[0]) + (size_t)t1i * a.kbtot * 64 + lane;
+    const f32x4* __restrict__ wp0 = reinterpret_cast<const f32x4*>(a.w[0]) + ((size_t)t0i * a.kb_full + a.kb_w0) * 64 + lane;
+    const f32x4* __restrict__ wp1 = reinterpret_cast<const f32x4*>(a.w[0]) + ((size_t)t1i * a.kb_full + a.kb_w0) * 64 + lane;
     f32x4 acc0[MB], acc1[MB];
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) { acc0[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -430,6 +499,8 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_splitk_kernel(Ski
                         acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.a[u][rb][j], b.b1[u][j], acc1[rb], 0, 0, 0);
                     }
         };
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i) load_a(buf[i], gidx(min(i, n - 1)));
         bool done = false;
         if constexpr (NPW > 0) {
             if (base == NPW) {
@@ -439,8 +510,6 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_splitk_kernel(Ski
             }
         }
         if (!done) {
-#pragma unroll
-            for (int i = 0; i < NBUF; ++i) load_a(buf[i], gidx(min(i, n - 1)));
             for (int g = 0; g < n; g += NBUF) {
 #pragma unroll
                 for (int i = 0; i < NBUF; ++i) {
@@ -535,23 +604,26 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_splitk_kernel(Ski
 // (modules.py:88-91) and the mel / stop projections (rnn_wrappers.py:105-109) together with the
 // stop rule of StopTokenBasedInferenceHelper (helpers.py:90-94) evaluated on the device.
 // ------------------------------------------------------------------------------------------------
-template <int MB>
-__global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCore a, DenseEpi e) {
+template <int MB, int NPW>      // NPW: static ring of the riding partial job (0: runtime loop)
+__global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCore a, DenseEpi e, PartialJobs pj) {
     __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
     __shared__ int s_notstop;
+    const int n_own = (int)gridDim.x - pj.n[0];      // the kernel's own workgroups come first: they are the critical path
+    if ((int)blockIdx.x >= n_own) { partial_body<MB, NPW>(pj.core[0], pj.z[0], blockIdx.x - n_own, red); return; }
+    const int wg = blockIdx.x;
     f32x4 acc[MB];
-    const int t = skinny_core<MB, 0>(a, 0, acc);
+    const int t = skinny_core<MB, 0>(a, 0, wg, acc, [](int) {});
     if (t < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
     if (threadIdx.x == 0) s_notstop = 0;
     __syncthreads();
-    const bool has_stop = e.stop_col >= 0 && (e.stop_col >> 4) == (int)blockIdx.x;
+    const bool has_stop = e.stop_col >= 0 && (e.stop_col >> 4) == wg;
     float* ofrag = e.out_frag.base ? frag_slot(e.out_frag, t) : nullptr;
     for (int idx = threadIdx.x; idx < MB * 16 * 16; idx += T2_SKINNY_THREADS) {
         const int row = idx >> 4, c = idx & 15;
-        const int col = blockIdx.x * 16 + c;
+        const int col = wg * 16 + c;
         if (row >= a.B || col >= e.N) continue;
         float v = red_sum<MB>(red, row, c);
         if (a.bias[0] != nullptr) v += a.bias[0][col];
@@ -638,9 +710,16 @@ template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(
 // loads; the location-layer matrix goes through LDS once instead of once per wave; the per-position
 // sums over attention units are reduced eight positions at a time (transposed butterfly).
 // Lane l owns attention units UPL*l .. UPL*l + UPL-1.
-template <int FMAX, int UPL>
-__global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArgs a) {
+template <int FMAX, int UPL, int MB, int NPW>     // MB / NPW: geometry of the riding partial jobs
+__global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArgs a, PartialJobs pj) {
     typedef typename VecOf<UPL>::type vecu;
+    static_assert(T2_ATTN_THREADS == T2_SKINNY_THREADS, "the riding jobs use the skinny GEMM geometry");
+    {
+        __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
+        const int j = (int)blockIdx.x - a.B;           // the attention rows come first: they are the critical path
+        if (j >= pj.n[0]) { partial_body<MB, NPW>(pj.core[1], pj.z[1], j - pj.n[0], red); return; }
+        if (j >= 0) { partial_body<MB, NPW>(pj.core[0], pj.z[0], j, red); return; }
+    }
     T2_STAMP(0);
     const int t_step = step_index(a.ctl, a.step_off);
     if (t_step < 0) return;

@@ -98,6 +98,8 @@ struct t2_model {
     int opt_graph = 1;                  // use hipGraph chunks for decode loops
     int opt_chunk = 16;                 // steps per graph
     int opt_splitk = 0;                 // batches > 16 rows: split-K LSTM step with in-launch reduction
+    int opt_hoist = 0;                  // recurrent halves of the LSTM GEMMs ride in the attention / projection launches
+    int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
 };
 
@@ -120,6 +122,7 @@ struct t2_state {
     float* xp[T2_MAX_PRENET_LAYERS] = {nullptr, nullptr, nullptr, nullptr};
     int XA_sz = 0, X1_sz = 0, X2_sz = 0;         // floats per slot
     int KBe = 0, KBa = 0, KBd = 0;
+    float *ZA = nullptr, *Z1 = nullptr, *Z2 = nullptr;   // recurrent-half pre-activations (partial_step_kernel)
     unsigned* tickets = nullptr;                 // split-K arrival counters, 3 layers x tiles (zeroed with the slab)
     unsigned long long* sk_slabs = nullptr;      // split-K partial slabs [tiles][2][512][2]
     int sk_tiles = 0;
@@ -345,6 +348,14 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
         m->opt_splitk = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
+    else if (!strcmp(name, "hoist")) {
+        m->opt_hoist = value;
+        for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+    }
+    else if (!strcmp(name, "lstm_only")) {
+        m->opt_lstm_only = value;
+        for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+    }
     else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
     else return fail(T2_EINVAL, "unknown option %s", name);
     return T2_OK;
@@ -436,10 +447,14 @@ extern "C" int t2_model_finalize(t2_model* m) {
     T2_TRY(upload(m, &m->post_proj.shift, b->data));
     HIP_TRY(hipHostMalloc((void**)&m->h_ctl, 8 * sizeof(int), hipHostMallocDefault));
     if (d.attention_filters > 64 || U > 256) return fail(T2_EINVAL, "attention_filters <= 64 and attention_dim <= 256 supported");
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_kernel<32, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_kernel<64, 4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    {
+        const void* fns[] = {
+            (const void*)attention_step_kernel<32, 2, 1, 0>, (const void*)attention_step_kernel<32, 2, 1, 2>, (const void*)attention_step_kernel<32, 2, 1, 4>,
+            (const void*)attention_step_kernel<32, 2, 2, 0>, (const void*)attention_step_kernel<32, 2, 2, 2>, (const void*)attention_step_kernel<32, 2, 2, 4>,
+            (const void*)attention_step_kernel<32, 2, 4, 0>, (const void*)attention_step_kernel<32, 2, 4, 2>, (const void*)attention_step_kernel<32, 2, 4, 4>,
+            (const void*)attention_step_kernel<64, 4, 1, 0>, (const void*)attention_step_kernel<64, 4, 2, 0>, (const void*)attention_step_kernel<64, 4, 4, 0>};
+        for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    }
     m->hw.clear();
     m->finalized = true;
     return T2_OK;
@@ -501,9 +516,11 @@ static inline void launch_lstm_mb(dim3 grid, hipStream_t st, const SkinnyCore& c
     const dim3 blk(T2_SKINNY_THREADS);
     if (ENC) { hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 0>), grid, blk, 0, st, c, e); return; }
     switch (base) {
+        case 2: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 2>), grid, blk, 0, st, c, e); break;
         case 3: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 3>), grid, blk, 0, st, c, e); break;
         case 4: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 4>), grid, blk, 0, st, c, e); break;
         case 5: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 5>), grid, blk, 0, st, c, e); break;
+        case 6: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 6>), grid, blk, 0, st, c, e); break;
         case 7: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 7>), grid, blk, 0, st, c, e); break;
         case 8: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 8>), grid, blk, 0, st, c, e); break;
         case 10: hipLaunchKernelGGL((lstm_step_kernel<MB, ENC, 10>), grid, blk, 0, st, c, e); break;
@@ -515,6 +532,25 @@ static inline void launch_lstm(int MB, dim3 grid, hipStream_t st, const SkinnyCo
     if (MB == 1) launch_lstm_mb<1, ENC>(grid, st, c, e);
     else if (MB == 2) launch_lstm_mb<2, ENC>(grid, st, c, e);
     else launch_lstm_mb<4, ENC>(grid, st, c, e);
+}
+
+template <int MB>
+static inline void launch_partial_mb(dim3 grid, hipStream_t st, const SkinnyCore& c, float* z) {
+    constexpr int G = (MB >= 4) ? T2_G4 : 4;
+    const int base = (c.kbtot / G) / T2_SKINNY_WAVES;
+    const dim3 blk(T2_SKINNY_THREADS);
+    switch (base) {
+        case 2: hipLaunchKernelGGL((partial_step_kernel<MB, 2>), grid, blk, 0, st, c, z); break;
+        case 3: hipLaunchKernelGGL((partial_step_kernel<MB, 3>), grid, blk, 0, st, c, z); break;
+        case 4: hipLaunchKernelGGL((partial_step_kernel<MB, 4>), grid, blk, 0, st, c, z); break;
+        case 6: hipLaunchKernelGGL((partial_step_kernel<MB, 6>), grid, blk, 0, st, c, z); break;
+        default: hipLaunchKernelGGL((partial_step_kernel<MB, 0>), grid, blk, 0, st, c, z); break;
+    }
+}
+static inline void launch_partial(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, float* z) {
+    if (MB == 1) launch_partial_mb<1>(grid, st, c, z);
+    else if (MB == 2) launch_partial_mb<2>(grid, st, c, z);
+    else launch_partial_mb<4>(grid, st, c, z);
 }
 
 static void timed_lstm(bool timing, int MB, int n_wg4, hipStream_t st, const SkinnyCore& c, const LstmEpi& e, unsigned* tickets,
@@ -536,10 +572,47 @@ static void timed_lstm(bool timing, int MB, int n_wg4, hipStream_t st, const Ski
         go();
     }
 }
-static inline void launch_dense(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const DenseEpi& e) {
-    if (MB == 1) hipLaunchKernelGGL(dense_step_kernel<1>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
-    else if (MB == 2) hipLaunchKernelGGL(dense_step_kernel<2>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
-    else hipLaunchKernelGGL(dense_step_kernel<4>, grid, dim3(T2_SKINNY_THREADS), 0, st, c, e);
+template <int MB>
+static inline void launch_dense_mb(dim3 grid, hipStream_t st, const SkinnyCore& c, const DenseEpi& e, const PartialJobs& pj) {
+    constexpr int G = (MB >= 4) ? T2_G4 : 4;
+    const int base = pj.n[0] > 0 ? (pj.core[0].kbtot / G) / T2_SKINNY_WAVES : 0;
+    const dim3 blk(T2_SKINNY_THREADS);
+    switch (base) {
+        case 3: hipLaunchKernelGGL((dense_step_kernel<MB, 3>), grid, blk, 0, st, c, e, pj); break;
+        case 6: hipLaunchKernelGGL((dense_step_kernel<MB, 6>), grid, blk, 0, st, c, e, pj); break;
+        default: hipLaunchKernelGGL((dense_step_kernel<MB, 0>), grid, blk, 0, st, c, e, pj); break;
+    }
+}
+// grid.x = workgroups of the dense role; the riding job's workgroups are appended
+static inline void launch_dense(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const DenseEpi& e, const PartialJobs* jobs = nullptr) {
+    PartialJobs pj{};
+    if (jobs) pj = *jobs;
+    grid.x += pj.n[0];
+    if (MB == 1) launch_dense_mb<1>(grid, st, c, e, pj);
+    else if (MB == 2) launch_dense_mb<2>(grid, st, c, e, pj);
+    else launch_dense_mb<4>(grid, st, c, e, pj);
+}
+
+template <int MB>
+static inline void launch_attention_mb(int B, size_t lds, hipStream_t st, const AttnArgs& a, const PartialJobs& pj, bool small) {
+    constexpr int G = (MB >= 4) ? T2_G4 : 4;
+    const int base = pj.n[0] > 0 ? (pj.core[0].kbtot / G) / T2_SKINNY_WAVES : 0;
+    const int base1 = pj.n[1] > 0 ? (pj.core[1].kbtot / G) / T2_SKINNY_WAVES : base;
+    const dim3 grid(B + pj.n[0] + pj.n[1]), blk(T2_ATTN_THREADS);
+    if (!small) { hipLaunchKernelGGL((attention_step_kernel<64, 4, MB, 0>), grid, blk, lds, st, a, pj); return; }
+    const int npw = base == base1 ? base : 0;
+    switch (npw) {
+        case 2: hipLaunchKernelGGL((attention_step_kernel<32, 2, MB, 2>), grid, blk, lds, st, a, pj); break;
+        case 4: hipLaunchKernelGGL((attention_step_kernel<32, 2, MB, 4>), grid, blk, lds, st, a, pj); break;
+        default: hipLaunchKernelGGL((attention_step_kernel<32, 2, MB, 0>), grid, blk, lds, st, a, pj); break;
+    }
+}
+static inline void launch_attention(int MB, int B, size_t lds, hipStream_t st, const AttnArgs& a, const PartialJobs* jobs, bool small) {
+    PartialJobs pj{};
+    if (jobs) pj = *jobs;
+    if (MB == 1) launch_attention_mb<1>(B, lds, st, a, pj, small);
+    else if (MB == 2) launch_attention_mb<2>(B, lds, st, a, pj, small);
+    else launch_attention_mb<4>(B, lds, st, a, pj, small);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -639,7 +712,7 @@ static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, con
             e.plain_off[dir] = dir * He;
             e.reverse[dir] = dir;
         }
-        c.kb0 = KPc / 16; c.kbtot = m->enc_lstm[0].kbtot; c.ctl = ctl; c.step_off = s; c.B = B;
+        c.kb0 = KPc / 16; c.kbtot = m->enc_lstm[0].kbtot; c.kb_w0 = 0; c.kb_full = c.kbtot; c.ctl = ctl; c.step_off = s; c.t_hint = s; c.B = B;
         e.H = He; e.Hld = He; e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         e.lens = d_lens; e.plain_out = memory_out; e.plain_bs = T * E; e.plain_ts = E;
         launch_lstm<true>(MB, dim3(m->enc_lstm[0].n_wg, 2), st, c, e);
@@ -730,6 +803,8 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     const size_t o_tk = carve((size_t)3 * s->sk_tiles * 4);
     const size_t o_sk = carve((size_t)s->sk_tiles * 2 * T2_SKINNY_THREADS * 2 * 8);
     const size_t o_xf = carve((size_t)R * pad16(M * nf) * 4);
+    const size_t o_ZA = carve((size_t)m->att_lstm.n_wg * MB * 256 * 4), o_Z1 = carve((size_t)m->lstm1.n_wg * MB * 256 * 4),
+                 o_Z2 = carve((size_t)m->lstm2.n_wg * MB * 256 * 4);
     size_t o_xp[T2_MAX_PRENET_LAYERS];
     for (int i = 0; i < d.num_prenet_layers; ++i) o_xp[i] = carve((size_t)R * pad16(d.prenet_units[i]) * 4);
     s->slab_bytes = off;
@@ -742,6 +817,7 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     s->c_att = (float*)(p + o_ca); s->c1 = (float*)(p + o_c1); s->c2 = (float*)(p + o_c2);
     s->XA = (float*)(p + o_XA); s->X1 = (float*)(p + o_X1); s->X2 = (float*)(p + o_X2); s->XY = (float*)(p + o_XY);
     s->xf = (float*)(p + o_xf);
+    s->ZA = (float*)(p + o_ZA); s->Z1 = (float*)(p + o_Z1); s->Z2 = (float*)(p + o_Z2);
     s->tickets = (unsigned*)(p + o_tk); s->sk_slabs = (unsigned long long*)(p + o_sk);
     for (int i = 0; i < d.num_prenet_layers; ++i) s->xp[i] = (float*)(p + o_xp[i]);
     // output staging
@@ -872,6 +948,7 @@ struct StepIO {
     float* mel; int mel_ld; long long mel_t_stride;
     float* stop; int stop_ld; int stop_t_mul;
     float* hist;
+    int slot_hint;              // 1: ctl base is even (chunked loops with an even chunk), so t and step_off select the same slots
 };
 
 static int launch_step(t2_state* s, int step_off, const StepIO& io) {
@@ -884,7 +961,8 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     auto core = [&](const Packed& p) {
         SkinnyCore c{};
         c.w[0] = c.w[1] = p.w; c.bias[0] = c.bias[1] = p.bias;
-        c.kb0 = 0; c.kbtot = p.kbtot; c.ctl = s->ctl; c.step_off = step_off; c.B = B;
+        c.kb0 = 0; c.kbtot = p.kbtot; c.kb_w0 = 0; c.kb_full = p.kbtot; c.ctl = s->ctl; c.step_off = step_off; c.B = B;
+        c.t_hint = io.slot_hint ? step_off : -1;
         return c;
     };
     auto single = [&](float* base, int koff) { return FragBuf{base, 0, 1, 0, koff}; };
@@ -892,74 +970,100 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     const FragBuf none{nullptr, 0, 1, 0, 0};
     const int KBe = s->KBe, KBa = s->KBa;
     const int np = d.num_prenet_layers;
+    const bool all = !m->opt_lstm_only;
     // 1. decoder input frames (helpers.py:86 / :182 / go frame :187-188)
-    if (io.feed_mode == 0 || io.feed_mode == 2) {
+    if (all && (io.feed_mode == 0 || io.feed_mode == 2)) {
         FeedArgs f{};
         f.src = io.feed_src; f.row_stride = io.feed_row_stride; f.t_stride = io.feed_t_stride; f.dst = single(s->xf, 0);
         f.B = B; f.K = M * nf; f.MB = MB; f.go_zero = io.feed_mode == 0; f.ctl = s->ctl; f.step_off = step_off;
         hipLaunchKernelGGL(feed_frames_kernel, dim3(ceil_div(MB * 16 * pad16(M * nf), 256)), dim3(256), 0, st, f);
     }
     // 2. prenets (rnn_wrappers.py:51-53)
-    for (int i = 0; i < np; ++i) {
+    for (int i = 0; all && i < np; ++i) {
         SkinnyCore c = core(m->prenet[i]);
         c.seg[0][1] = single(i == 0 ? s->xf : s->xp[i - 1], 0);
         DenseEpi e{};
         e.N = d.prenet_units[i]; e.relu = 1; e.out_frag = single(s->xp[i], 0); e.frag_col0 = 0; e.stop_col = -1;
         launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e);
     }
+    const bool hoist = m->opt_hoist != 0;
+    const bool timing = m->opt_time_lstm && !m->opt_graph;
+    // recurrent half of an LSTM layer: [state operands] . kernel[their K range] -> z (partial_body)
+    auto job = [&](const Packed& p, int kb_w0, int kb_n, FragBuf src, int off) {
+        SkinnyCore c = core(p);
+        c.step_off = step_off + off;
+        c.t_hint = io.slot_hint ? step_off + off : -1;
+        c.kb_w0 = kb_w0; c.kbtot = kb_n; c.kb0 = 0; c.seg[0][1] = src;
+        return c;
+    };
     // 3. attention LSTM on concat(prenet out, previous context)  (AttentionWrapper, App. A6) + this step's
     //    partial query products (tacotron_v2.py:122)
     {
         SkinnyCore c = core(m->att_lstm);
-        c.kb0 = m->att_lstm.seg_kb[0];
-        c.seg[0][0] = single(s->xp[np - 1], 0);
-        c.seg[0][1] = pp(s->XA, s->XA_sz, 0, 0);
         LstmEpi e{};
+        if (hoist) {
+            c.kbtot = m->att_lstm.seg_kb[0];
+            c.seg[0][1] = single(s->xp[np - 1], 0);
+            e.zpart = s->ZA;
+        } else {
+            c.kb0 = m->att_lstm.seg_kb[0];
+            c.seg[0][0] = single(s->xp[np - 1], 0);
+            c.seg[0][1] = pp(s->XA, s->XA_sz, 0, 0);
+        }
         e.H = A; e.c[0] = s->c_att; e.Hld = A;
         e.hprev[0] = pp(s->XA, s->XA_sz, 0, KBe * 16); e.hstate[0] = pp(s->XA, s->XA_sz, 1, KBe * 16);
         e.hraw[0] = pp(s->X1, s->X1_sz, 0, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         e.wq = m->wq; e.qpart = s->qpart; e.U = U;
-        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, m->att_lstm.n_wg, st, c, e, m->opt_splitk ? s->tickets : nullptr, s->sk_slabs);
+        timed_lstm(timing, MB, m->att_lstm.n_wg, st, c, e, (m->opt_splitk && !hoist) ? s->tickets : nullptr, s->sk_slabs);
     }
     // 4./5. location-sensitive attention + context
-    {
+    if (all) {
         AttnArgs a{};
         a.keys = s->keys; a.values = s->values; a.lens = s->lens; a.att_state = s->att_state; a.alignments = s->alignments;
-        a.history = io.hist; a.qpart = s->qpart; a.nparts = (m->opt_splitk && MB >= 2) ? ceil_div(m->att_lstm.n_wg, 2) : m->att_lstm.n_wg;
+        a.history = io.hist; a.qpart = s->qpart;
+        a.nparts = (m->opt_splitk && !hoist && MB >= 2) ? ceil_div(m->att_lstm.n_wg, 2) : m->att_lstm.n_wg;
         a.ctx_dst[0] = pp(s->XA, s->XA_sz, 1, 0); a.ctx_dst[1] = pp(s->X1, s->X1_sz, 0, KBa * 16); a.ctx_plain = s->ctx_plain;
         a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
         a.B = B; a.T = s->T; a.U = U; a.E = E; a.F = d.attention_filters; a.K = d.attention_kernel; a.MB = MB;
         a.cumulative = d.cumulative_weights; a.ctl = s->ctl; a.step_off = step_off;
         const size_t lds = attn_lds_bytes(d, s->T);
-        if (d.attention_filters <= 32 && U <= 128)
-            hipLaunchKernelGGL((attention_step_kernel<32, 2>), dim3(B), dim3(T2_ATTN_THREADS), lds, st, a);
-        else
-            hipLaunchKernelGGL((attention_step_kernel<64, 4>), dim3(B), dim3(T2_ATTN_THREADS), lds, st, a);
+        // the recurrent halves of the two decoder LSTMs of THIS step ride behind the attention grid
+        PartialJobs pj{};
+        if (hoist) {
+            pj.core[0] = job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0); pj.z[0] = s->Z1; pj.n[0] = m->lstm1.n_wg;
+            pj.core[1] = job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0); pj.z[1] = s->Z2; pj.n[1] = m->lstm2.n_wg;
+        }
+        launch_attention(MB, B, lds, st, a, hoist ? &pj : nullptr, d.attention_filters <= 32 && U <= 128);
+    } else if (hoist) {      // lstm_only timing runs: the riding jobs as launches of their own
+        launch_partial(MB, dim3(m->lstm1.n_wg), st, job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0), s->Z1);
+        launch_partial(MB, dim3(m->lstm2.n_wg), st, job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0), s->Z2);
     }
     // 6./7. decoder LSTMs on concat(attention cell output, new context)  (rnn_wrappers.py:76-78, tacotron_v2.py:155-161)
     {
         SkinnyCore c = core(m->lstm1);
-        c.seg[0][1] = pp(s->X1, s->X1_sz, 0, 0);
         LstmEpi e{};
+        c.seg[0][1] = pp(s->X1, s->X1_sz, 0, 0);
+        if (hoist) { c.kbtot = KBa + KBe; e.zpart = s->Z1; }
         e.H = D; e.c[0] = s->c1; e.Hld = D;
         e.hprev[0] = pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16); e.hstate[0] = pp(s->X1, s->X1_sz, 1, (KBa + KBe) * 16);
         e.hraw[0] = pp(s->X2, s->X2_sz, 0, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
-        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, m->lstm1.n_wg, st, c, e, m->opt_splitk ? s->tickets + s->sk_tiles : nullptr, s->sk_slabs);
+        timed_lstm(timing, MB, m->lstm1.n_wg, st, c, e, (m->opt_splitk && !hoist) ? s->tickets + s->sk_tiles : nullptr, s->sk_slabs);
     }
     {
         SkinnyCore c = core(m->lstm2);
-        c.seg[0][1] = pp(s->X2, s->X2_sz, 0, 0);
         LstmEpi e{};
+        c.seg[0][1] = pp(s->X2, s->X2_sz, 0, 0);
+        if (hoist) { c.kbtot = s->KBd; e.zpart = s->Z2; }
         e.H = D; e.c[0] = s->c2; e.Hld = D;
         e.hprev[0] = pp(s->X2, s->X2_sz, 0, s->KBd * 16); e.hstate[0] = pp(s->X2, s->X2_sz, 1, s->KBd * 16);
         e.hraw[0] = single(s->XY, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
-        timed_lstm(m->opt_time_lstm && !m->opt_graph, MB, m->lstm2.n_wg, st, c, e, m->opt_splitk ? s->tickets + 2 * s->sk_tiles : nullptr, s->sk_slabs);
+        timed_lstm(timing, MB, m->lstm2.n_wg, st, c, e, (m->opt_splitk && !hoist) ? s->tickets + 2 * s->sk_tiles : nullptr, s->sk_slabs);
     }
     // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
-    {
+    if (all) {
         SkinnyCore c = core(m->proj);
         c.seg[0][1] = single(s->XY, 0);
         DenseEpi e{};
@@ -967,7 +1071,12 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.out_plain = io.mel; e.plain_ld = io.mel_ld; e.plain_t_stride = io.mel_t_stride; e.plain_ncol = M * r;
         e.out_frag = io.feed_mode == 1 ? single(s->xf, 0) : none; e.frag_col0 = M * (r - nf);
         e.stop_col = M * r; e.out_stop = io.stop; e.stop_ld = io.stop_ld; e.stop_t_mul = io.stop_t_mul; e.ctl_w = s->ctl;
-        launch_dense(MB, dim3(m->proj.n_wg), st, c, e);
+        // the recurrent half of the attention LSTM of the NEXT step rides behind the projection grid
+        PartialJobs pj{};
+        if (hoist) { pj.core[0] = job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1); pj.z[0] = s->ZA; pj.n[0] = m->att_lstm.n_wg; }
+        launch_dense(MB, dim3(m->proj.n_wg), st, c, e, hoist ? &pj : nullptr);
+    } else if (hoist) {
+        launch_partial(MB, dim3(m->att_lstm.n_wg), st, job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1), s->ZA);
     }
     HIP_TRY(hipGetLastError());
     return T2_OK;
@@ -1024,6 +1133,7 @@ static StepIO loop_io(t2_state* s, int mode) {
     io.mel = s->o_mel; io.mel_ld = s->cap * r * M; io.mel_t_stride = (long long)r * M;
     io.stop = s->o_stop; io.stop_ld = s->cap; io.stop_t_mul = 1;
     io.hist = s->o_hist;
+    io.slot_hint = (s->m->opt_chunk % 2 == 0) ? 1 : 0;
     return io;
 }
 

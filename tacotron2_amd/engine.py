@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import weakref
 from typing import Dict, Optional
 
@@ -105,6 +106,10 @@ class Engine:
             shape = (C.c_int64 * a.ndim)(*a.shape)
             _lib.check(self.lib.t2_model_set_weight(self._model, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
         _lib.check(self.lib.t2_model_finalize(self._model))
+        # tuning hook: T2MI_OPTIONS="name=value,name=value" applies library options to every engine
+        for kv in filter(None, os.environ.get("T2MI_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), int(v))
 
     # -- plumbing -------------------------------------------------------------------------
     def synchronize(self):
@@ -232,13 +237,19 @@ class Engine:
         n = steps.value
         return mel[:, :n * d.outputs_per_step], stop[:, :n].unsqueeze(-1), align[:n], n
 
-    def decode_free_launch(self, memory, lens, max_iters, min_iters, buffers):
+    def decode_free_launch(self, memory, lens, max_iters, min_iters, buffers, events=None):
+        """events: optional (start, end) torch.cuda.Event pair recorded on the library's stream around the call
+        (the state set-up before the first decoder step is inside the bracket)."""
         lens = _i64(lens)
         B, T_in, _ = memory.shape
         mel, stop, align = buffers
         with self._ordered():
+            if events is not None:
+                events[0].record(self.stream)
             _lib.check(self.lib.t2_decode_free_launch(self._model, memory.data_ptr(), _hp(lens), B, T_in, max_iters, min_iters,
                                                   mel.data_ptr(), stop.data_ptr(), align.data_ptr()))
+            if events is not None:
+                events[1].record(self.stream)
 
     def decode_free_finish(self) -> int:
         steps = C.c_int(0)

@@ -35,7 +35,7 @@ static void run(int B, int T, int iters) {
     float best = 1e9;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) { a.step_off = i; hipLaunchKernelGGL((attention_step_kernel<32, 2>), dim3(B), dim3(T2_ATTN_THREADS), lds, s, a); }
+        for (int i = 0; i < iters; ++i) { a.step_off = i; hipLaunchKernelGGL((attention_step_kernel<32, 2, 4, 0>), dim3(B), dim3(T2_ATTN_THREADS), lds, s, a, PartialJobs{}); }
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     }

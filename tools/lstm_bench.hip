@@ -32,7 +32,7 @@ static void run(int K, int H, int B, int iters, int rotate) {
         CK(hipEventRecord(e0, st));
         for (int i = 0; i < iters; ++i) {
             SkinnyCore a{}; LstmEpi e{};
-            a.w[0] = w + (size_t)(i % nrot) * wsz; a.bias[0] = bias; a.kb0 = 0; a.kbtot = kbtot; a.ctl = ctl; a.step_off = i; a.B = B;
+            a.w[0] = w + (size_t)(i % nrot) * wsz; a.bias[0] = bias; a.kb0 = 0; a.kbtot = kbtot; a.kb_w0 = 0; a.kb_full = kbtot; a.ctl = ctl; a.step_off = i; a.t_hint = i; a.B = B;
             a.seg[0][1] = FragBuf{X, (int)xsz, 2, 0, 0};
             e.H = H; e.c[0] = c; e.Hld = H;
             const int hoff = K - H;
@@ -77,7 +77,7 @@ static void run_splitk(int K, int H, int B, int iters) {
         CK(hipEventRecord(e0, st));
         for (int i = 0; i < iters; ++i) {
             SkinnyCore a{}; LstmEpi e{};
-            a.w[0] = w + (size_t)(i % 3) * wsz; a.bias[0] = bias; a.kb0 = 0; a.kbtot = kbtot; a.ctl = ctl; a.step_off = i; a.B = B;
+            a.w[0] = w + (size_t)(i % 3) * wsz; a.bias[0] = bias; a.kb0 = 0; a.kbtot = kbtot; a.kb_w0 = 0; a.kb_full = kbtot; a.ctl = ctl; a.step_off = i; a.t_hint = i; a.B = B;
             a.seg[0][1] = FragBuf{X, (int)xsz, 2, 0, 0};
             e.H = H; e.c[0] = c; e.Hld = H;
             const int hoff = K - H;
