@@ -150,6 +150,7 @@ def main():
         n_steps = 96
         lb = eng.decode_free_buffers(B, T_in, n_steps)
         eng.set_option("lstm_only", 1)
+        eng.set_option("hoist", 0)            # whole-K launches: one kernel = one LSTM layer's gate GEMM + cell
         eng.decode_free_launch(memory, lens, n_steps, d.min_iters, lb)       # warm-up + graph capture
         eng.decode_free_finish()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,7 +159,18 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         n_l = 3 * n_steps
+        # the production split of the same GEMMs (recurrent halves as jobs of their own)
+        eng.set_option("hoist", 1)
+        eng.decode_free_launch(memory, lens, n_steps, d.min_iters, lb)
+        eng.decode_free_finish()
+        eng.decode_free_launch(memory, lens, n_steps, d.min_iters, lb, events=(e0, e1))
+        eng.decode_free_finish()
+        torch.cuda.synchronize()
+        ms_split = e0.elapsed_time(e1)
         eng.set_option("lstm_only", 0)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            eng.set_option(k, int(v))
         flops, byts = lstm_algorithmic(d, B)
         avg_s = ms * 1e-3 / max(n_l, 1)
         achieved = flops / avg_s / 1e12
@@ -174,6 +186,8 @@ def main():
                            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                            "avg_launch_us": avg_s * 1e6, "launches_timed": int(n_l),
                            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
+                           "lstm_gemm_us_per_decoder_step": {"whole_k_3_launches": ms * 1e3 / n_steps,
+                                                             "split_6_launches_standalone": ms_split * 1e3 / n_steps},
                            "hbm_side": {"achieved_GBs": byts / avg_s / 1e9, "peak_GBs": HBM_PEAK_GBS,
                                         "frac": byts / avg_s / 1e9 / HBM_PEAK_GBS}}
 

@@ -113,6 +113,7 @@ struct DenseEpi {
     long long plain_t_stride;
     int plain_ncol;           // columns < plain_ncol go to out_plain
     // stop token handling (projection kernel): column stop_col holds the stop logit
+    int n_wg;               // workgroups (16-column tiles) of this dense layer
     int stop_col;             // -1: none
     float* out_stop;          // [row * stop_ld + t * stop_t_mul]
     int stop_ld;
@@ -188,15 +189,25 @@ __device__ __forceinline__ void kg_mma(const KGroup<MB, G>& g, f32x4 (&acc)[MB])
 // fully unrolled straight-line code, so the compiler emits exact counted s_waitcnt vmcnt(N) and a wave
 // only ever waits for its OLDEST group in flight.  (With a runtime trip count hipcc drains vmcnt(0) at
 // the loop header and the loads stop overlapping the MFMAs: measured 22.8 vs ~13 us.)
+#ifndef T2_FENCE
+#define T2_FENCE 0
+#endif
+#if T2_FENCE
+#define T2_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define T2_SCHED_FENCE() do { } while (0)
+#endif
 template <int NBUF, int N, class Buf, class Mma, class LoadW, class LoadA, class GIdx>
 __device__ __forceinline__ void ring_static(Buf (&buf)[NBUF], Mma&& mma, LoadW&& load_w, LoadA&& load_a, GIdx&& gidx) {
 #pragma unroll
     for (int g = 0; g < N; ++g) {
         mma(buf[g % NBUF]);
+        T2_SCHED_FENCE();
         if (g + NBUF < N) {
             const int gi = gidx(g + NBUF);
             load_w(buf[g % NBUF], gi);
             load_a(buf[g % NBUF], gi);
+            T2_SCHED_FENCE();
         }
     }
 }
@@ -604,20 +615,15 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_splitk_kernel(Ski
 // (modules.py:88-91) and the mel / stop projections (rnn_wrappers.py:105-109) together with the
 // stop rule of StopTokenBasedInferenceHelper (helpers.py:90-94) evaluated on the device.
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NPW>      // NPW: static ring of the riding partial job (0: runtime loop)
-__global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCore a, DenseEpi e, PartialJobs pj) {
-    __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
-    __shared__ int s_notstop;
-    const int n_own = (int)gridDim.x - pj.n[0];      // the kernel's own workgroups come first: they are the critical path
-    if ((int)blockIdx.x >= n_own) { partial_body<MB, NPW>(pj.core[0], pj.z[0], blockIdx.x - n_own, red); return; }
-    const int wg = blockIdx.x;
+template <int MB>
+__device__ __forceinline__ void dense_body(const SkinnyCore& a, const DenseEpi& e, int wg, f32x4* red, int* s_notstop) {
     f32x4 acc[MB];
     const int t = skinny_core<MB, 0>(a, 0, wg, acc, [](int) {});
     if (t < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
-    if (threadIdx.x == 0) s_notstop = 0;
+    if (threadIdx.x == 0) *s_notstop = 0;
     __syncthreads();
     const bool has_stop = e.stop_col >= 0 && (e.stop_col >> 4) == wg;
     float* ofrag = e.out_frag.base ? frag_slot(e.out_frag, t) : nullptr;
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCor
         if (e.relu) v = fmaxf(v, 0.f);
         if (col == e.stop_col) {
             e.out_stop[(size_t)row * e.stop_ld + (size_t)t * e.stop_t_mul] = v;
-            if (!(v > 0.f)) atomicOr(&s_notstop, 1);       // sigmoid(v) > 0.5  <=>  v > 0
+            if (!(v > 0.f)) atomicOr(s_notstop, 1);       // sigmoid(v) > 0.5  <=>  v > 0
             continue;
         }
         if (e.out_plain != nullptr && col < e.plain_ncol)
@@ -641,9 +647,23 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCor
         __syncthreads();
         // finished = reduce_all(stop & (time > min_iters)); outputs of the finishing step are kept,
         // so the decode emits t + 1 steps.  Readers at step t see 0 or t + 1: both let step t run.
-        if (threadIdx.x == 0 && e.ctl_w != nullptr && e.ctl_w[CTL_STOP_EN] != 0 && s_notstop == 0 &&
+        if (threadIdx.x == 0 && e.ctl_w != nullptr && e.ctl_w[CTL_STOP_EN] != 0 && *s_notstop == 0 &&
             t > e.ctl_w[CTL_MINIT] && e.ctl_w[CTL_FINAL] == 0)
             e.ctl_w[CTL_FINAL] = t + 1;
+    }
+}
+
+// Grid = max(e.n_wg, pj.n[0]).  Workgroup i first runs the kernel's own column tile i (the critical
+// path), then tile i of the riding job: the skinny kernels hold one workgroup per CU (register file), so
+// extra workgroups beyond 256 would run as a second round behind the job's.
+template <int MB, int NPW>      // NPW: static ring of the riding partial job (0: runtime loop)
+__global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCore a, DenseEpi e, PartialJobs pj) {
+    __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
+    __shared__ int s_notstop;
+    if ((int)blockIdx.x < e.n_wg) dense_body<MB>(a, e, blockIdx.x, red, &s_notstop);
+    if ((int)blockIdx.x < pj.n[0]) {
+        __syncthreads();
+        partial_body<MB, NPW>(pj.core[0], pj.z[0], blockIdx.x, red);
     }
 }
 

@@ -98,7 +98,7 @@ struct t2_model {
     int opt_graph = 1;                  // use hipGraph chunks for decode loops
     int opt_chunk = 16;                 // steps per graph
     int opt_splitk = 0;                 // batches > 16 rows: split-K LSTM step with in-launch reduction
-    int opt_hoist = 0;                  // recurrent halves of the LSTM GEMMs ride in the attention / projection launches
+    int opt_hoist = 1;                  // recurrent halves of the LSTM GEMMs ride in the attention / projection launches
     int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
 };
@@ -583,14 +583,16 @@ static inline void launch_dense_mb(dim3 grid, hipStream_t st, const SkinnyCore& 
         default: hipLaunchKernelGGL((dense_step_kernel<MB, 0>), grid, blk, 0, st, c, e, pj); break;
     }
 }
-// grid.x = workgroups of the dense role; the riding job's workgroups are appended
+// grid.x = workgroups of the dense role; the grid is widened to the riding job's workgroup count
 static inline void launch_dense(int MB, dim3 grid, hipStream_t st, const SkinnyCore& c, const DenseEpi& e, const PartialJobs* jobs = nullptr) {
     PartialJobs pj{};
     if (jobs) pj = *jobs;
-    grid.x += pj.n[0];
-    if (MB == 1) launch_dense_mb<1>(grid, st, c, e, pj);
-    else if (MB == 2) launch_dense_mb<2>(grid, st, c, e, pj);
-    else launch_dense_mb<4>(grid, st, c, e, pj);
+    DenseEpi e2 = e;
+    e2.n_wg = grid.x;
+    grid.x = std::max<unsigned>(grid.x, pj.n[0]);
+    if (MB == 1) launch_dense_mb<1>(grid, st, c, e2, pj);
+    else if (MB == 2) launch_dense_mb<2>(grid, st, c, e2, pj);
+    else launch_dense_mb<4>(grid, st, c, e2, pj);
 }
 
 template <int MB>

@@ -95,10 +95,16 @@ static void run_splitk(int K, int H, int B, int iters) {
 
 int main(int argc, char** argv) {
 #if T2_SKINNY_WAVES == 8
-    run_splitk<4, 0>(2560, 1024, 64, 200);
-    run_splitk<4, 5>(2560, 1024, 64, 200);
+    if (argc <= 1) run_splitk<4, 0>(2560, 1024, 64, 200);
+    if (argc <= 1) run_splitk<4, 5>(2560, 1024, 64, 200);
 #endif
-    if (argc > 1) { run<4>(2560, 1024, 64, 50, 1); return 0; }
+    if (argc > 1) {      // short list for A/B builds
+        run<4, 160 / T2_G4 / T2_SKINNY_WAVES>(2560, 1024, 64, 200, 1);
+        run<4, 96 / T2_G4 / T2_SKINNY_WAVES>(1536, 1024, 64, 200, 1);
+        run<4, 64 / T2_G4 / T2_SKINNY_WAVES>(1024, 1024, 64, 200, 1);
+        run<1, 40 / T2_SKINNY_WAVES>(2560, 1024, 1, 200, 1);
+        return 0;
+    }
     run<4>(2560, 1024, 64, 200, 1);
     run<4, 160 / T2_G4 / T2_SKINNY_WAVES>(2560, 1024, 64, 200, 1);
     run<4, 128 / T2_G4 / T2_SKINNY_WAVES>(2048, 1024, 64, 200, 1);

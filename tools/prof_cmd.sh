@@ -1,0 +1,8 @@
+#!/bin/bash
+# tools/prof_cmd.sh <name> <python script + args...>: rocprofv3 kernel stats of a python command
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/$name -o p -- python "$@" > $root/gpurun_out/$name.log 2>&1 || { tail -n 5 $root/gpurun_out/$name.log; exit 1; }
+grep "decode only" $root/gpurun_out/$name.log
+cd $root && python profiles/summarize.py gpurun_out/$name 2>&1 | head -n 14
