@@ -146,12 +146,41 @@ int t2_decode_free_launch(t2_model* m, const float* memory, const int64_t* lens,
 int t2_decode_free_finish(t2_model* m, int* steps_out);
 
 /* Tuning / measurement hooks (no reference counterpart).  Options: "graph" (1: decode loops replay
- * hipGraph chunks, 0: eager launches), "chunk" (decoder steps per graph, 1..64), "splitk" (1: split-K LSTM step for batches > 16), "lstm_only" (1: decode steps launch only the three
+ * hipGraph chunks, 0: eager launches), "chunk" (decoder steps per graph, 1..64), "splitk" (1: split-K LSTM step for batches > 16), "hoist" (1, default: the recurrent halves of the LSTM gate GEMMs ride as extra workgroups in the attention / projection launches; 0: whole-K LSTM launches), "lstm_only" (1: decode steps launch only the
  * LSTM kernels -- timing runs, outputs meaningless), "time_lstm" (1:
  * record HIP events around every decoder LSTM launch in eager mode; resets the counters).
  * Stats: "lstm_launches", "lstm_ms" (sum of event-timed launch durations, synchronises). */
 int t2_model_set_option(t2_model* m, const char* name, int value);
 int t2_model_get_stat(t2_model* m, const char* name, double* out);
+
+/* ---- training-step math (BASELINE.json configs[3]) ---------------------------
+ * All buffers are dev fp32.  out3 = {sum of weighted losses, number of non-zero broadcast weights,
+ * sum / count (0 when count == 0)}: tf.losses.compute_weighted_loss with its default
+ * SUM_BY_NONZERO_WEIGHTS reduction.  The first two let a data-parallel caller all-reduce numerator and
+ * count over ranks and divide afterwards, which reproduces the single-device value of the whole batch. */
+
+/* SingleSpeakerTacotronV1Model.spec_loss (tacotron/models.py:136-144): |y_hat - y| [B,T,M] weighted by
+ * mask [B,T] broadcast over M (priority-frequency blend unused: defaults None / 0). */
+int t2_spec_loss(t2_ctx* ctx, const float* y_hat, const float* y, const float* mask, int B, int T, int M, float* out3);
+
+/* binary_loss (tacotron/models.py:146-148): tf.losses.sigmoid_cross_entropy(done, logits, weights = mask),
+ * logits / done / mask [B,S]. */
+int t2_binary_loss(t2_ctx* ctx, const float* logits, const float* done, const float* mask, int B, int S, float* out3);
+
+/* The optimizer block of model_fn (tacotron/models.py:67-76) over ONE flat parameter / gradient buffer of
+ * n_params floats (16-byte aligned): tf.clip_by_global_norm(grads, clip_norm) followed by
+ * tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).apply_gradients -- TF arithmetic: epsilon outside the
+ * square root, bias correction folded into lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t).
+ * grad_scale multiplies the gradients first (1 / world_size after a sum all-reduce); clip_norm <= 0
+ * disables clipping.  The library owns m, v and the step count t. */
+typedef struct t2_optim t2_optim;
+int t2_optim_create(t2_ctx* ctx, int64_t n_params, float beta1, float beta2, float epsilon, t2_optim** out);
+int t2_optim_destroy(t2_optim* o);
+int t2_optim_global_norm(t2_optim* o, const float* grads, float grad_scale, float* norm_out /* dev [1] */);
+int t2_optim_step(t2_optim* o, float* params, const float* grads, float learning_rate, float clip_norm, float grad_scale);
+/* checkpoint / resume of the slots (NULL pointers are skipped) */
+int t2_optim_get_state(t2_optim* o, float* m_out, float* v_out, int64_t* step_out);
+int t2_optim_set_state(t2_optim* o, const float* m_in, const float* v_in, int64_t step);
 
 #ifdef __cplusplus
 }

@@ -474,3 +474,35 @@ def learning_rate_decay(init_rate, global_step):
     warmup_steps = 4000.0
     step = float(global_step + 1)
     return init_rate * warmup_steps ** 0.5 * min(step * warmup_steps ** -1.5, step ** -0.5)
+
+
+def loss_parts(l, wgt):
+    """(sum of weighted losses, number of non-zero broadcast weights): the two numbers a data-parallel
+    job all-reduces before dividing."""
+    wgt = np.broadcast_to(wgt.astype(F32), l.shape)
+    return float(np.sum(l.astype(F32) * wgt, dtype=np.float64)), int(np.count_nonzero(wgt))
+
+
+def global_norm(grads):
+    """tf.global_norm: sqrt(sum over all tensors of sum(g^2))."""
+    return float(np.sqrt(sum(float(np.sum(np.asarray(g, np.float64) ** 2)) for g in grads)))
+
+
+def clip_by_global_norm(grads, clip_norm):
+    """tf.clip_by_global_norm (models.py:71): g * clip_norm / max(global_norm, clip_norm)."""
+    norm = global_norm(grads)
+    scale = clip_norm / max(norm, clip_norm)
+    return [(np.asarray(g, F32) * F32(scale)).astype(F32) for g in grads], norm
+
+
+def adam_apply(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer._apply_dense at step t (1-based), fp32 slots (models.py:67-68,76; App. A of
+    SURVEY.md): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps) -- epsilon outside
+    the square root, unlike torch.optim.Adam."""
+    lr_t = F32(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+    b1, b2, e = F32(beta1), F32(beta2), F32(eps)
+    g = np.asarray(g, F32)
+    m = (b1 * m + (F32(1) - b1) * g).astype(F32)
+    v = (b2 * v + (F32(1) - b2) * g * g).astype(F32)
+    p = (p - lr_t * m / (np.sqrt(v) + e)).astype(F32)
+    return p, m, v

@@ -58,6 +58,14 @@ _SIGS = {
     "t2_decode_free": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]),
     "t2_decode_free_launch": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "t2_decode_free_finish": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "t2_spec_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
+    "t2_binary_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p]),
+    "t2_optim_create": (C.c_int, [_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.POINTER(_p)]),
+    "t2_optim_destroy": (C.c_int, [_p]),
+    "t2_optim_global_norm": (C.c_int, [_p, _p, C.c_float, _p]),
+    "t2_optim_step": (C.c_int, [_p, _p, _p, C.c_float, C.c_float, C.c_float]),
+    "t2_optim_get_state": (C.c_int, [_p, _p, _p, _i64p]),
+    "t2_optim_set_state": (C.c_int, [_p, _p, _p, C.c_int64]),
 }
 
 _lib = None

@@ -51,6 +51,7 @@ struct t2_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    float* red_ws = nullptr;   // partial sums of the loss reductions (train.h)
 };
 
 struct HostWeight {
@@ -293,6 +294,7 @@ extern "C" int t2_ctx_create(int device, void* hip_stream, t2_ctx** out) {
 
 extern "C" int t2_ctx_destroy(t2_ctx* c) {
     if (!c) return T2_OK;
+    if (c->red_ws) (void)hipFree(c->red_ws);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return T2_OK;
@@ -1297,3 +1299,8 @@ extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
     }
     return fail(T2_EINVAL, "unknown stat %s", name);
 }
+
+// ------------------------------------------------------------------------------------------------
+// losses and optimizer block
+// ------------------------------------------------------------------------------------------------
+#include "train.h"

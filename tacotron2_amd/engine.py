@@ -83,21 +83,67 @@ class DecoderState:
             pass
 
 
-class Engine:
-    def __init__(self, dims: T2Dims, weights: Dict[str, np.ndarray], device: int = 0):
+class Context:
+    """One t2_ctx: a GPU plus the stream the library enqueues on.  The library's stream is its own
+    (capturable) torch stream; every call orders it after torch's current stream on entry and torch's
+    current stream after it on exit (``ordered``)."""
+
+    def __init__(self, device: int = 0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("tacotron2_amd needs an MI355X (gfx950) GPU: there is no CPU path")
-        check_weights(dims, weights)
-        self.dims = dims
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        # The library enqueues on its own (capturable) stream; every call below orders that stream
-        # after torch's current stream on entry and torch's current stream after it on exit.
         self.stream = torch.cuda.Stream(self.device)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.t2_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(self.handle)))
+
+    def f32(self, x) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float32))
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    @contextlib.contextmanager
+    def ordered(self):
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        try:
+            yield
+        finally:
+            cur.wait_stream(self.stream)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.t2_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_shared: Dict[int, Context] = {}
+
+
+def shared_context(device: int = 0) -> Context:
+    """A process-wide Context per GPU for calls that are not tied to a model (losses, optimizer)."""
+    if device not in _shared:
+        _shared[device] = Context(device)
+    return _shared[device]
+
+
+class Engine:
+    def __init__(self, dims: T2Dims, weights: Dict[str, np.ndarray], device: int = 0):
+        check_weights(dims, weights)
+        self.context = Context(device)
+        self.lib = self.context.lib
+        self.dims = dims
+        self.device = self.context.device
+        self.stream = self.context.stream
         self._states = weakref.WeakSet()
-        self._ctx = C.c_void_p()
-        _lib.check(self.lib.t2_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(self._ctx)))
+        self._ctx = self.context.handle
         self._model = C.c_void_p()
         ds = _dims_struct(dims)
         _lib.check(self.lib.t2_model_create(self._ctx, C.byref(ds), C.byref(self._model)))
@@ -124,18 +170,10 @@ class Engine:
         return v.value
 
     def _f32(self, x) -> torch.Tensor:
-        if not isinstance(x, torch.Tensor):
-            x = torch.as_tensor(np.asarray(x, dtype=np.float32))
-        return x.to(device=self.device, dtype=torch.float32).contiguous()
+        return self.context.f32(x)
 
-    @contextlib.contextmanager
     def _ordered(self):
-        cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(cur)
-        try:
-            yield
-        finally:
-            cur.wait_stream(self.stream)
+        return self.context.ordered()
 
     def close(self):
         for st in list(getattr(self, "_states", [])):
@@ -144,7 +182,7 @@ class Engine:
             self.lib.t2_model_destroy(self._model)
             self._model = None
         if getattr(self, "_ctx", None):
-            self.lib.t2_ctx_destroy(self._ctx)
+            self.context.close()
             self._ctx = None
 
     def __del__(self):

@@ -14,7 +14,8 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from .engine import Engine
+from . import training
+from .engine import Engine, shared_context
 from .hparams import T2Dims
 from .helpers import StopTokenBasedInferenceHelper, TrainingHelper, ValidationHelper
 from .modules import Conv1d, PreNet, ZoneoutLSTMCell
@@ -252,27 +253,21 @@ class DecoderV2:
         return mel_output, stop, final_state
 
 
-def spec_loss(y_hat, y, mask):
-    """models.py:136-144 with compute_weighted_loss(SUM_BY_NONZERO_WEIGHTS)."""
-    l1 = torch.abs(y_hat - y)
-    w = mask.unsqueeze(2).to(l1.dtype).expand_as(l1)
-    nz = torch.count_nonzero(w)
-    return (l1 * w).sum() / nz.clamp(min=1)
+def spec_loss(y_hat, y, mask, n_priority_freq=None, priority_w=0, engine=None):
+    """SingleSpeakerTacotronV1Model.spec_loss (models.py:136-144) on the HIP library (t2_spec_loss)."""
+    return training.spec_loss(engine or shared_context(_device_index(y_hat)), y_hat, y, mask, n_priority_freq, priority_w)
 
 
-def binary_loss(done_hat, done, mask):
-    """models.py:146-148: sigmoid cross entropy weighted by mask, SUM_BY_NONZERO_WEIGHTS."""
-    x, z = done_hat.squeeze(-1), done.to(done_hat.dtype)
-    ce = torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x)))
-    nz = torch.count_nonzero(mask)
-    return (ce * mask.to(ce.dtype)).sum() / nz.clamp(min=1)
+def binary_loss(done_hat, done, mask, engine=None):
+    """binary_loss (models.py:146-148) on the HIP library (t2_binary_loss)."""
+    return training.binary_loss(engine or shared_context(_device_index(done_hat)), done_hat, done, mask)
 
 
-def learning_rate_decay(init_rate, global_step):
-    """models.py:150-154."""
-    warmup_steps = 4000.0
-    step = float(global_step + 1)
-    return init_rate * warmup_steps ** 0.5 * min(step * warmup_steps ** -1.5, step ** -0.5)
+def _device_index(x):
+    return x.device.index if isinstance(x, torch.Tensor) and x.is_cuda else torch.cuda.current_device()
+
+
+learning_rate_decay = training.learning_rate_decay      # models.py:150-154
 
 
 class TacotronV2Model:
@@ -318,12 +313,12 @@ class TacotronV2Model:
         if is_validation:
             eng = self.engine
             mel_t, done, m1, m2 = (eng._f32(lab[k]) for k in ("mel", "done", "spec_loss_mask", "binary_loss_mask"))
-            mel_loss = spec_loss(mel_output, mel_t, m1)
-            done_loss = binary_loss(stop_token, done, m2)
+            mel_loss = spec_loss(mel_output, mel_t, m1, engine=eng)
+            done_loss = binary_loss(stop_token, done, m2, engine=eng)
             mel_tf, stop_tf, _ = self.decoder(encoder_output, is_training=False, is_validation=True,
                                               memory_sequence_length=source_length, target=target, teacher_forcing=True)
-            mel_loss_tf = spec_loss(mel_tf, mel_t, m1)
-            done_loss_tf = binary_loss(stop_tf, done, m2)
+            mel_loss_tf = spec_loss(mel_tf, mel_t, m1, engine=eng)
+            done_loss_tf = binary_loss(stop_tf, done, m2, engine=eng)
             return {"loss": mel_loss + done_loss, "eval_metric_ops": {
                 "mel_loss": mel_loss, "done_loss": done_loss, "loss_with_teacher": mel_loss_tf + done_loss_tf,
                 "mel_loss_with_teacher": mel_loss_tf, "done_loss_with_teacher": done_loss_tf},

@@ -1,0 +1,192 @@
+"""Training-step math of the reference's model_fn (tacotron/models.py:57-76) on the HIP library:
+the two losses, the learning-rate schedule (T3) and the optimizer block
+(T4: tf.clip_by_global_norm + tf.train.AdamOptimizer) over one flat fp32 parameter buffer, plus the
+data-parallel gradient exchange of section 8e.  No arithmetic happens in Python or torch here:
+torch provides device memory and the RCCL all-reduce (``torch.distributed`` backend "nccl").
+
+The backward pass that produces the gradients is not built yet; ``AdamOptimizer.apply_gradients``
+takes the flat gradient buffer from its caller."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import Context
+
+
+def _ctx_of(obj) -> Context:
+    return obj if isinstance(obj, Context) else obj.context
+
+
+def _weighted(ctx: Context, fn, *tensors, dims) -> torch.Tensor:
+    out = torch.empty(3, dtype=torch.float32, device=ctx.device)
+    with ctx.ordered():
+        _lib.check(fn(ctx.handle, *[t.data_ptr() for t in tensors], *dims, out.data_ptr()))
+    return out
+
+
+def spec_loss_parts(ctx, y_hat, y, mask) -> torch.Tensor:
+    """[sum |y_hat - y| * mask, non-zero weight count, their ratio] as a dev tensor (models.py:136-144)."""
+    ctx = _ctx_of(ctx)
+    y_hat, y, mask = ctx.f32(y_hat), ctx.f32(y), ctx.f32(mask)
+    if y_hat.shape != y.shape or y_hat.dim() != 3 or tuple(mask.shape) != tuple(y.shape[:2]):
+        raise ValueError(f"spec_loss shapes: y_hat {tuple(y_hat.shape)}, y {tuple(y.shape)}, mask {tuple(mask.shape)}")
+    B, T, M = y.shape
+    return _weighted(ctx, ctx.lib.t2_spec_loss, y_hat, y, mask, dims=(B, T, M))
+
+
+def binary_loss_parts(ctx, done_hat, done, mask) -> torch.Tensor:
+    """Same triple for the stop-token loss (models.py:146-148); done_hat [B,S,1] or [B,S] logits."""
+    ctx = _ctx_of(ctx)
+    done_hat = ctx.f32(done_hat)
+    if done_hat.dim() == 3:
+        if done_hat.shape[-1] != 1:
+            raise ValueError("done_hat must be [B, S, 1]")      # tf.squeeze(axis=-1) fails the same way
+        done_hat = done_hat.squeeze(-1).contiguous()
+    done, mask = ctx.f32(done), ctx.f32(mask)
+    if done_hat.shape != done.shape or done.shape != mask.shape or done.dim() != 2:
+        raise ValueError(f"binary_loss shapes: {tuple(done_hat.shape)}, {tuple(done.shape)}, {tuple(mask.shape)}")
+    B, S = done.shape
+    return _weighted(ctx, ctx.lib.t2_binary_loss, done_hat, done, mask, dims=(B, S))
+
+
+def spec_loss(ctx, y_hat, y, mask, n_priority_freq=None, priority_w=0) -> torch.Tensor:
+    """SingleSpeakerTacotronV1Model.spec_loss (models.py:136-144).  The priority-frequency blend is
+    never enabled by the reference's hparams (None / 0) and is rejected here."""
+    if n_priority_freq is not None and priority_w > 0:
+        raise NotImplementedError("priority-frequency L1 blend (models.py:139-142) is unused by the reference's hparams")
+    return spec_loss_parts(ctx, y_hat, y, mask)[2]
+
+
+def binary_loss(ctx, done_hat, done, mask) -> torch.Tensor:
+    """binary_loss (models.py:146-148)."""
+    return binary_loss_parts(ctx, done_hat, done, mask)[2]
+
+
+def learning_rate_decay(init_rate, global_step):
+    """models.py:150-154 (Noam schedule with 4000 warm-up steps)."""
+    warmup_steps = 4000.0
+    step = float(global_step + 1)
+    return init_rate * warmup_steps ** 0.5 * min(step * warmup_steps ** -1.5, step ** -0.5)
+
+
+def allreduce_loss_parts(parts: torch.Tensor, group=None) -> torch.Tensor:
+    """Section 8e: SUM_BY_NONZERO_WEIGHTS is not a plain mean, so a data-parallel job sums numerator and
+    count over ranks and divides afterwards -- the value a single device would get on the whole batch."""
+    import torch.distributed as dist
+    nc = parts[:2].clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(nc, op=dist.ReduceOp.SUM, group=group)
+    return torch.where(nc[1] > 0, nc[0] / nc[1].clamp(min=1), torch.zeros_like(nc[0]))
+
+
+# ---- flat parameter buffer ---------------------------------------------------------------------
+def flatten_spec(weights: Dict[str, np.ndarray]) -> List[Tuple[str, Tuple[int, ...], int, int]]:
+    """(name, shape, offset, size) of every variable in the flat buffer: sorted by name (the order TF's
+    checkpoint and tf.trainable_variables-by-name listing use), each start padded to 4 floats so that
+    every variable is float4-aligned."""
+    spec, off = [], 0
+    for name in sorted(weights):
+        shape = tuple(int(x) for x in np.shape(weights[name]))
+        size = int(np.prod(shape)) if shape else 1
+        spec.append((name, shape, off, size))
+        off += (size + 3) & ~3
+    return spec
+
+
+def flat_size(spec) -> int:
+    name, shape, off, size = spec[-1]
+    return off + ((size + 3) & ~3)
+
+
+def flatten(weights: Dict[str, np.ndarray], spec=None) -> np.ndarray:
+    spec = spec or flatten_spec(weights)
+    flat = np.zeros(flat_size(spec), np.float32)
+    for name, shape, off, size in spec:
+        flat[off:off + size] = np.asarray(weights[name], np.float32).reshape(-1)
+    return flat
+
+
+def unflatten(flat, spec) -> Dict[str, np.ndarray]:
+    flat = flat.detach().cpu().numpy() if isinstance(flat, torch.Tensor) else np.asarray(flat)
+    return {name: flat[off:off + size].reshape(shape).copy() for name, shape, off, size in spec}
+
+
+def allreduce_gradients(flat_grads: torch.Tensor, group=None) -> float:
+    """One sum all-reduce of the whole flat gradient buffer (RCCL over xGMI when the backend is "nccl";
+    ~151 MB at profile P: a single large collective, section 8e).  Returns the factor 1 / world_size
+    the optimizer multiplies in (``grad_scale``), so the mean costs no extra pass over the buffer."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer as model_fn uses it (models.py:67-76), fused with tf.clip_by_global_norm,
+    over one flat parameter buffer.  ``learning_rate`` may be a float or a callable of global_step."""
+
+    def __init__(self, ctx, n_params: int, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.ctx = _ctx_of(ctx)
+        self.n = int(n_params)
+        self.learning_rate = learning_rate
+        self._h = C.c_void_p()
+        _lib.check(self.ctx.lib.t2_optim_create(self.ctx.handle, self.n, float(beta1), float(beta2), float(epsilon),
+                                                C.byref(self._h)))
+
+    def _check(self, t: torch.Tensor, what: str) -> torch.Tensor:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.n):
+            raise ValueError(f"{what} must be a contiguous fp32 device tensor of {self.n} elements")
+        return t
+
+    def global_norm(self, grads: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
+        """tf.global_norm of grad_scale * grads (dev scalar)."""
+        self._check(grads, "grads")
+        out = torch.empty(1, dtype=torch.float32, device=self.ctx.device)
+        with self.ctx.ordered():
+            _lib.check(self.ctx.lib.t2_optim_global_norm(self._h, grads.data_ptr(), float(grad_scale), out.data_ptr()))
+        return out[0]
+
+    def apply_gradients(self, grads: torch.Tensor, params: torch.Tensor, global_step: int = 0, clip_norm: float = 1.0,
+                        grad_scale: float = 1.0) -> int:
+        """clip_by_global_norm(grads, clip_norm) then Adam on ``params`` in place; returns global_step + 1
+        (apply_gradients increments the global step, models.py:76)."""
+        self._check(grads, "grads")
+        self._check(params, "params")
+        lr = self.learning_rate(global_step) if callable(self.learning_rate) else self.learning_rate
+        with self.ctx.ordered():
+            _lib.check(self.ctx.lib.t2_optim_step(self._h, params.data_ptr(), grads.data_ptr(), float(lr), float(clip_norm),
+                                                  float(grad_scale)))
+        return global_step + 1
+
+    def state(self):
+        m = torch.empty(self.n, dtype=torch.float32, device=self.ctx.device)
+        v = torch.empty_like(m)
+        step = C.c_int64(0)
+        with self.ctx.ordered():
+            _lib.check(self.ctx.lib.t2_optim_get_state(self._h, m.data_ptr(), v.data_ptr(), C.byref(step)))
+        return m, v, step.value
+
+    def load_state(self, m: torch.Tensor, v: torch.Tensor, step: int):
+        self._check(m, "m")
+        self._check(v, "v")
+        with self.ctx.ordered():
+            _lib.check(self.ctx.lib.t2_optim_set_state(self._h, m.data_ptr(), v.data_ptr(), int(step)))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.t2_optim_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -47,3 +47,47 @@ def test_two_rank_sharding_and_reduction():
         assert p.exitcode == 0
     assert res[0][1] == [0, 2] and res[1][1] == [1, 3]
     assert res[0][2] == res[1][2] == 1.5 and res[0][3] == res[1][3] == 256 * 800.0
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tacotron2_amd import training as TR
+    from oracle import t2_oracle as O
+    rng = np.random.default_rng(100 + rank)
+    g = torch.tensor(rng.standard_normal(1024).astype(np.float32))
+    scale = TR.allreduce_gradients(g)                       # in-place sum; mean factor handed to the optimizer
+    # per-rank loss parts -> the loss of the global batch (SUM_BY_NONZERO_WEIGHTS is not a mean of means)
+    B = 2 + rank
+    l = rng.uniform(0, 1, (B, 5, 3)).astype(np.float32)
+    mask = (np.arange(5)[None, :] < np.array([5, 2, 4, 1][:B])[:, None]).astype(np.float32)
+    num, cnt = O.loss_parts(l, mask[:, :, None])
+    loss = TR.allreduce_loss_parts(torch.tensor([num, cnt, 0.0], dtype=torch.float32))
+    q.put((rank, g.numpy(), scale, float(loss), l, mask))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_and_loss_exchange():
+    """The training-step exchange of SURVEY.md 8e on gloo: one sum all-reduce of the flat gradient buffer
+    (+ 1/world handed to the optimizer) and the (numerator, count) pairs of the losses."""
+    from oracle import t2_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0 = np.random.default_rng(100).standard_normal(1024).astype(np.float32)
+    g1 = np.random.default_rng(101).standard_normal(1024).astype(np.float32)
+    for r in res:
+        np.testing.assert_allclose(r[1], g0 + g1, rtol=1e-6)
+        assert r[2] == 0.5
+    l_all = np.concatenate([res[0][4], res[1][4]])
+    m_all = np.concatenate([res[0][5], res[1][5]])
+    num, cnt = O.loss_parts(l_all, m_all[:, :, None])
+    assert abs(res[0][3] - num / cnt) < 1e-6 and res[0][3] == res[1][3]

@@ -112,3 +112,19 @@ def test_sharding_covers_every_utterance_once():
     assert sorted(got) == list(range(8))
     # length-sorted batches have little padding
     assert all(lens[b].max() - lens[b].min() <= 15 for b in batches)
+
+
+def test_flat_parameter_buffer_roundtrip():
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.hparams import PROFILE_TINY
+    from tacotron2_amd.weights import init_weights
+    w = init_weights(PROFILE_TINY, seed=3)
+    spec = TR.flatten_spec(w)
+    flat = TR.flatten(w, spec)
+    assert flat.size == TR.flat_size(spec) and flat.size % 4 == 0
+    assert all(off % 4 == 0 for _, _, off, _ in spec)                 # every variable float4-aligned
+    assert [n for n, *_ in spec] == sorted(w)
+    back = TR.unflatten(flat, spec)
+    for k in w:
+        np.testing.assert_array_equal(back[k], np.asarray(w[k], np.float32))
+    assert abs(TR.learning_rate_decay(0.002, 3999) - 0.002) < 1e-9

@@ -2,6 +2,7 @@
 (SURVEY.md §8c fixture kind 1) and the TF-semantics quirks of SURVEY.md Appendix A/B."""
 import numpy as np
 import pytest
+import torch
 
 from oracle import t2_oracle as O
 from oracle import torch_check as TC
@@ -142,3 +143,27 @@ def test_dims_validation():
         T2Dims(enc_units=511)
     with pytest.raises(AssertionError):
         T2Dims(n_feed_frame=3, outputs_per_step=2)
+
+
+def test_optimizer_block_oracle_against_torch():
+    """clip_by_global_norm and TF-form Adam (epsilon outside the sqrt) against an independent torch
+    statement of the same formulas."""
+    rng = np.random.default_rng(3)
+    n = 257
+    p, g = rng.standard_normal(n).astype(np.float32), (rng.standard_normal(n) * 0.5).astype(np.float32)
+    (gc,), norm = O.clip_by_global_norm([g], 1.0)
+    tg = torch.tensor(g, dtype=torch.float64)
+    assert abs(norm - float(tg.norm())) < 1e-9
+    np.testing.assert_allclose(gc, (tg * (1.0 / max(float(tg.norm()), 1.0))).numpy(), rtol=1e-6)
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    tp, tm, tv = torch.tensor(p, dtype=torch.float64), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    for t in range(1, 4):
+        p, m, v = O.adam_apply(p, gc, m, v, t, 0.01)
+        tgc = torch.tensor(gc, dtype=torch.float64)
+        tm = 0.9 * tm + 0.1 * tgc
+        tv = 0.999 * tv + 0.001 * tgc * tgc
+        tp = tp - 0.01 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * tm / (tv.sqrt() + 1e-8)
+        np.testing.assert_allclose(p, tp.numpy(), atol=2e-6)
+    # a small gradient is left alone by the clipping
+    (gs,), _ = O.clip_by_global_norm([g * 1e-3], 1.0)
+    np.testing.assert_array_equal(gs, (g * 1e-3).astype(np.float32))
