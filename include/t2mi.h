@@ -182,6 +182,53 @@ int t2_optim_step(t2_optim* o, float* params, const float* grads, float learning
 int t2_optim_get_state(t2_optim* o, float* m_out, float* v_out, int64_t* step_out);
 int t2_optim_set_state(t2_optim* o, const float* m_in, const float* v_in, int64_t step);
 
+/* ---- Tacotron v1 path (BASELINE.json configs[4]) ---------------------------------
+ * Field meaning: reference hparams.py:14-15,23,27-28,31-47,54-60.  Inference arithmetic (dropout off, batch
+ * norm with moving statistics).  Variable names: tacotron2_amd/weights_v1.py:weight_shapes_v1 (TF GRUCell
+ * layouts: gates/kernel [in+h, 2h] = r | u, candidate/kernel [in+h, h]). */
+typedef struct t2v1_dims {
+    int32_t num_symbols, embedding_dim;
+    int32_t enc_prenet_units[2];       /* EncoderV1 prenet_out_units (tacotron_v1.py:25); [0] == embedding_dim      */
+    int32_t cbhg_out_units, conv_channels, max_filter_width, proj1_channels, proj2_channels, num_highway;
+    int32_t dec_prenet_units[2];       /* DecoderV1 prenet_out_units (tacotron_v1.py:96)                             */
+    int32_t attention_out_units;       /* GRU units = BahdanauAttention num_units (tacotron_v1.py:58-59), <= 256     */
+    int32_t decoder_out_units;         /* OutputProjectionWrapper size = residual GRU units (tacotron_v1.py:70-74)    */
+    int32_t num_mels, outputs_per_step, n_feed_frame;
+    int32_t post_cbhg_out_units, post_conv_channels, post_max_filter_width, post_proj1_channels, post_proj2_channels,
+            post_num_highway, num_freq;
+    float bn_eps;
+} t2v1_dims;
+typedef struct t2v1_model t2v1_model;
+
+/* Validation mirrors the reference's checks: nf <= r (helpers.py:55), even CBHG out_units (modules.py:169),
+ * prenet_out_units[0] == embedding width (tacotron_v1.py:41-44), output_size >= 1 (rnn_wrappers.py:155-156). */
+int t2v1_model_create(t2_ctx* ctx, const t2v1_dims* dims, t2v1_model** out);
+int t2v1_model_set_weight(t2v1_model* m, const char* name, const float* host_ptr, const int64_t* shape, int rank);
+int t2v1_model_finalize(t2v1_model* m);
+int t2v1_model_destroy(t2v1_model* m);
+int t2v1_model_set_option(t2v1_model* m, const char* name, int value);     /* "graph", "chunk" */
+
+/* Embedding.call + EncoderV1.call (tacotron_v1.py:46-49): PreNets -> CBHG.  lens NULL = no sequence_length, which
+ * is how the V1 model_fn calls it (models.py:47).  memory_out dev [B,T_in,cbhg_out_units]. */
+int t2v1_encode(t2v1_model* m, const int64_t* ids, const int64_t* lens, int B, int T_in, float* memory_out);
+int t2v1_encode_embedded(t2v1_model* m, const float* emb, const int64_t* lens, int B, int T_in, float* memory_out);
+
+/* CBHG.call (modules.py:205-229) alone: which = 0 the encoder's CBHG (x dev [B,T,enc_prenet_units[1]]),
+ * 1 the PostNet's (x dev [B,T,num_mels]); out dev [B,T,out_units]. */
+int t2v1_cbhg(t2v1_model* m, int which, const float* x, const int64_t* lens, int B, int T, float* out);
+
+/* PostNet.call (tacotron_v1.py:180-183): mel dev [B,T_out,num_mels] -> linear spectrogram dev [B,T_out,num_freq]. */
+int t2v1_postnet(t2v1_model* m, const float* mel, int B, int T_out, float* spec_out);
+
+/* DecoderV1.call (tacotron_v1.py:118-153): OutputAndStopTokenWrapper(DecoderRNNV1(OutputProjectionWrapper(
+ * AttentionRNN(GRUCell, PreNets, BahdanauAttention)), 2 x ResidualWrapper(GRUCell))) under dynamic_decode with
+ * TrainingHelper / ValidationHelper (_teacher) or StopTokenBasedInferenceHelper (_free).  Arguments and outputs as
+ * t2_decode_teacher / t2_decode_free. */
+int t2v1_decode_teacher(t2v1_model* m, const float* memory, const int64_t* lens, const float* targets, int B, int T_in,
+                        int T_out, int teacher_forcing, float* mel, float* stop, float* align);
+int t2v1_decode_free(t2v1_model* m, const float* memory, const int64_t* lens, int B, int T_in, int max_iters, int min_iters,
+                     float* mel, float* stop, float* align, int* steps_out);
+
 #ifdef __cplusplus
 }
 #endif

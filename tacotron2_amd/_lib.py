@@ -25,6 +25,19 @@ class T2Dims(C.Structure):
     ]
 
 
+class T2V1Dims(C.Structure):
+    _fields_ = [
+        ("num_symbols", C.c_int32), ("embedding_dim", C.c_int32), ("enc_prenet_units", C.c_int32 * 2),
+        ("cbhg_out_units", C.c_int32), ("conv_channels", C.c_int32), ("max_filter_width", C.c_int32),
+        ("proj1_channels", C.c_int32), ("proj2_channels", C.c_int32), ("num_highway", C.c_int32),
+        ("dec_prenet_units", C.c_int32 * 2), ("attention_out_units", C.c_int32), ("decoder_out_units", C.c_int32),
+        ("num_mels", C.c_int32), ("outputs_per_step", C.c_int32), ("n_feed_frame", C.c_int32),
+        ("post_cbhg_out_units", C.c_int32), ("post_conv_channels", C.c_int32), ("post_max_filter_width", C.c_int32),
+        ("post_proj1_channels", C.c_int32), ("post_proj2_channels", C.c_int32), ("post_num_highway", C.c_int32),
+        ("num_freq", C.c_int32), ("bn_eps", C.c_float),
+    ]
+
+
 class T2Error(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libt2mi error {code}: {msg}")
@@ -58,6 +71,17 @@ _SIGS = {
     "t2_decode_free": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]),
     "t2_decode_free_launch": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "t2_decode_free_finish": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "t2v1_model_create": (C.c_int, [_p, C.POINTER(T2V1Dims), C.POINTER(_p)]),
+    "t2v1_model_set_weight": (C.c_int, [_p, C.c_char_p, _p, _i64p, C.c_int]),
+    "t2v1_model_finalize": (C.c_int, [_p]),
+    "t2v1_model_destroy": (C.c_int, [_p]),
+    "t2v1_model_set_option": (C.c_int, [_p, C.c_char_p, C.c_int]),
+    "t2v1_encode": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p]),
+    "t2v1_encode_embedded": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p]),
+    "t2v1_cbhg": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, _p]),
+    "t2v1_postnet": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
+    "t2v1_decode_teacher": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "t2v1_decode_free": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]),
     "t2_spec_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "t2_binary_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "t2_optim_create": (C.c_int, [_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.POINTER(_p)]),

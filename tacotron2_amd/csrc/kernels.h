@@ -1313,3 +1313,96 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
             }
         }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Tacotron v1 cells
+// ------------------------------------------------------------------------------------------------
+// TF GRUCell step in two launches (reference tacotron/rnn_impl.py:38): the reset gate
+// multiplies h BEFORE the candidate matmul, so the candidate GEMM needs every r of the step:
+//   phase 1: [r | u] = sigmoid([x | h] . Wg + bg)   -> writes r*h (frag16 operand of phase 2) and u
+//   phase 2: c = tanh([x | r*h] . Wc + bc);  h' = u*h + (1-u)*c   -> state, output (h' or x_res + h':
+//            tf.nn.rnn_cell.ResidualWrapper, tacotron_v1.py:72-73), optional plain sequence output with
+//            dynamic_rnn's sequence_length semantics (zero output / state copied through past the end).
+struct GruEpi {
+    int H;
+    FragBuf hprev;            // h_{t-1}
+    FragBuf rh;               // r*h destination (phase 1)
+    float* u;                 // plain [MB*16][H]
+    FragBuf hstate;           // h_t destination (phase 2)
+    FragBuf out;              // output destination, base may be null
+    FragBuf xres;             // residual input, base null: none
+    const int* lens;          // optional [B]
+    float* plain_out;         // optional [B][T][ld]
+    int plain_bs, plain_ts, plain_off, reverse;
+};
+
+template <int MB, int PHASE>
+__global__ __launch_bounds__(T2_SKINNY_THREADS) void gru_step_kernel(SkinnyCore a, GruEpi e) {
+    __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
+    f32x4 acc[MB];
+    const int wg = blockIdx.x;
+    const int t = skinny_core<MB, 0>(a, 0, wg, acc, [](int) {});
+    if (t < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
+    __syncthreads();
+    const int ncol = PHASE == 1 ? 2 * e.H : e.H;
+    const float* hprev = frag_slot(e.hprev, t);
+    for (int idx = threadIdx.x; idx < MB * 16 * 16; idx += T2_SKINNY_THREADS) {
+        const int row = idx >> 4, c = idx & 15;
+        const int col = wg * 16 + c;
+        if (row >= a.B || col >= ncol) continue;
+        const float v = red_sum<MB>(red, row, c) + a.bias[0][col];
+        if (PHASE == 1) {
+            const float g = sigmoidf_(v);
+            if (col < e.H) frag_slot(e.rh, t)[frag_idx(row, e.rh.koff + col, MB)] = g * hprev[frag_idx(row, e.hprev.koff + col, MB)];
+            else e.u[(size_t)row * e.H + col - e.H] = g;
+        } else {
+            const float cand = tanhf(v);
+            const float u = e.u[(size_t)row * e.H + col];
+            const float hp = hprev[frag_idx(row, e.hprev.koff + col, MB)];
+            float hn = u * hp + (1.0f - u) * cand;
+            float outv = hn;
+            bool live = true;
+            int len = 0;
+            if (e.lens != nullptr) {
+                len = e.lens[row];
+                live = t < len;
+                if (!live) { hn = hp; outv = 0.f; }
+            }
+            frag_slot(e.hstate, t)[frag_idx(row, e.hstate.koff + col, MB)] = hn;
+            if (e.xres.base != nullptr) outv += frag_slot(e.xres, t)[frag_idx(row, e.xres.koff + col, MB)];
+            if (e.out.base != nullptr) frag_slot(e.out, t)[frag_idx(row, e.out.koff + col, MB)] = outv;
+            if (e.plain_out != nullptr && live) {
+                const int tpos = (e.reverse && e.lens != nullptr) ? (len - 1 - t) : t;
+                e.plain_out[(size_t)row * e.plain_bs + (size_t)tpos * e.plain_ts + e.plain_off + col] = outv;
+            }
+        }
+    }
+}
+
+// tf.layers.MaxPooling1D(pool_size=2, strides=1, padding="SAME") (modules.py:182): y[t] = max(x[t], x[t+1]),
+// the last frame of every utterance passes through.  x, y: [B*T][C]
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, long long Mtot, int T, int C) {
+    const long long n = Mtot * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C;
+        float v = x[i];
+        if ((int)(m % T) + 1 < T) v = fmaxf(v, x[i + C]);
+        y[i] = v;
+    }
+}
+
+// HighwayNet.call (modules.py:124-127): ht = [x.Wh + bh | x.Wt + bt] (one GEMM);  y = relu(h)*sigmoid(t) + x*(1 - sigmoid(t))
+__global__ __launch_bounds__(256) void highway_kernel(const float* __restrict__ ht, const float* __restrict__ x, float* __restrict__ y,
+                                                      long long Mtot, int H) {
+    const long long n = Mtot * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / H;
+        const int c = (int)(i - m * H);
+        const float h = fmaxf(ht[m * 2 * H + c], 0.f);
+        const float tg = sigmoidf_(ht[m * 2 * H + H + c]);
+        y[i] = h * tg + x[i] * (1.0f - tg);
+    }
+}

@@ -363,6 +363,17 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     return T2_OK;
 }
 
+// the attention kernel's dynamic LDS goes beyond the 64 KiB default
+static int set_attention_func_attributes() {
+    const void* fns[] = {
+            (const void*)attention_step_kernel<32, 2, 1, 0>, (const void*)attention_step_kernel<32, 2, 1, 2>, (const void*)attention_step_kernel<32, 2, 1, 4>,
+            (const void*)attention_step_kernel<32, 2, 2, 0>, (const void*)attention_step_kernel<32, 2, 2, 2>, (const void*)attention_step_kernel<32, 2, 2, 4>,
+            (const void*)attention_step_kernel<32, 2, 4, 0>, (const void*)attention_step_kernel<32, 2, 4, 2>, (const void*)attention_step_kernel<32, 2, 4, 4>,
+            (const void*)attention_step_kernel<64, 4, 1, 0>, (const void*)attention_step_kernel<64, 4, 2, 0>, (const void*)attention_step_kernel<64, 4, 4, 0>};
+        for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    return T2_OK;
+}
+
 extern "C" int t2_model_finalize(t2_model* m) {
     if (!m) return fail(T2_EINVAL, "null model");
     if (m->finalized) return T2_OK;
@@ -449,14 +460,7 @@ extern "C" int t2_model_finalize(t2_model* m) {
     T2_TRY(upload(m, &m->post_proj.shift, b->data));
     HIP_TRY(hipHostMalloc((void**)&m->h_ctl, 8 * sizeof(int), hipHostMallocDefault));
     if (d.attention_filters > 64 || U > 256) return fail(T2_EINVAL, "attention_filters <= 64 and attention_dim <= 256 supported");
-    {
-        const void* fns[] = {
-            (const void*)attention_step_kernel<32, 2, 1, 0>, (const void*)attention_step_kernel<32, 2, 1, 2>, (const void*)attention_step_kernel<32, 2, 1, 4>,
-            (const void*)attention_step_kernel<32, 2, 2, 0>, (const void*)attention_step_kernel<32, 2, 2, 2>, (const void*)attention_step_kernel<32, 2, 2, 4>,
-            (const void*)attention_step_kernel<32, 2, 4, 0>, (const void*)attention_step_kernel<32, 2, 4, 2>, (const void*)attention_step_kernel<32, 2, 4, 4>,
-            (const void*)attention_step_kernel<64, 4, 1, 0>, (const void*)attention_step_kernel<64, 4, 2, 0>, (const void*)attention_step_kernel<64, 4, 4, 0>};
-        for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-    }
+    T2_TRY(set_attention_func_attributes());
     m->hw.clear();
     m->finalized = true;
     return T2_OK;
@@ -1304,3 +1308,8 @@ extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
 // losses and optimizer block
 // ------------------------------------------------------------------------------------------------
 #include "train.h"
+
+// ------------------------------------------------------------------------------------------------
+// Tacotron v1 path
+// ------------------------------------------------------------------------------------------------
+#include "v1.h"

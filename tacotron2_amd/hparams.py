@@ -75,3 +75,61 @@ PROFILE_TINY = T2Dims(num_symbols=40, num_mels=5, outputs_per_step=2, n_feed_fra
                       attention_lstm_units=11, decoder_lstm_units=13, attention_dim=6,
                       postnet_layers=3, postnet_kernel=3, postnet_channels=7,
                       zoneout_cell=0.1, zoneout_output=0.2, max_iters=12, min_iters=3)
+
+
+@dataclass(frozen=True)
+class V1Dims:
+    """Tacotron v1 sizes: every field is an entry of the reference's hparams.py (:14-15,23,27-28,31-47,
+    54-60,87) with the reference's default value (BASELINE.json configs[4])."""
+    num_symbols: int = 256
+    num_mels: int = 80
+    num_freq: int = 1025
+    outputs_per_step: int = 2
+    n_feed_frame: int = 2
+    max_iters: int = 500
+    min_iters: int = 10
+    embedding_dim: int = 256
+    # EncoderV1 (tacotron_v1.py:20-39)
+    encoder_prenet_out_units: Tuple[int, int] = (256, 128)
+    cbhg_out_units: int = 256
+    conv_channels: int = 128
+    max_filter_width: int = 16
+    projection1_out_channels: int = 128
+    projection2_out_channels: int = 128
+    num_highway: int = 4
+    # DecoderV1 (tacotron_v1.py:96-103)
+    decoder_prenet_out_units: Tuple[int, int] = (256, 128)
+    attention_out_units: int = 256
+    decoder_out_units: int = 256
+    # PostNet (tacotron_v1.py:158-164)
+    post_net_cbhg_out_units: int = 256
+    post_net_conv_channels: int = 128
+    post_net_max_filter_width: int = 8
+    post_net_projection1_out_channels: int = 256
+    post_net_projection2_out_channels: int = 80
+    post_net_num_highway: int = 4
+    bn_eps: float = 1e-3
+
+    def __post_init__(self):
+        assert self.n_feed_frame <= self.outputs_per_step                        # helpers.py:55
+        assert self.cbhg_out_units % 2 == 0 and self.post_net_cbhg_out_units % 2 == 0      # modules.py:169
+        assert self.encoder_prenet_out_units[0] == self.embedding_dim            # tacotron_v1.py:41-44
+        # shape constraints the TF graph enforces implicitly: CBHG residual (modules.py:214) and
+        # ResidualWrapper (tacotron_v1.py:72-73)
+        assert self.projection2_out_channels == self.encoder_prenet_out_units[-1]
+        assert self.post_net_projection2_out_channels == self.num_mels
+
+    def replace(self, **kw) -> "V1Dims":
+        return replace(self, **kw)
+
+
+#: the reference's hparams.py defaults
+V1_PROFILE = V1Dims()
+
+#: tiny sizes, deliberately not multiples of the kernel tile sizes (even and odd bank widths)
+V1_TINY = V1Dims(num_symbols=30, num_mels=5, num_freq=9, outputs_per_step=2, n_feed_frame=1, max_iters=10, min_iters=3,
+                 embedding_dim=6, encoder_prenet_out_units=(6, 5), cbhg_out_units=8, conv_channels=3, max_filter_width=4,
+                 projection1_out_channels=7, projection2_out_channels=5, num_highway=2,
+                 decoder_prenet_out_units=(7, 6), attention_out_units=9, decoder_out_units=11,
+                 post_net_cbhg_out_units=6, post_net_conv_channels=3, post_net_max_filter_width=3,
+                 post_net_projection1_out_channels=4, post_net_projection2_out_channels=5, post_net_num_highway=2)
