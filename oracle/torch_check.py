@@ -85,3 +85,43 @@ def lsa_step(query, prev_state, keys, values, lengths, wq, conv_k, conv_b, wloc,
     ctx = torch.bmm(al[:, None, :], t(values))[:, 0]
     nxt = al + t(prev_state) if cumulative else al
     return al.numpy(), nxt.numpy(), ctx.numpy()
+
+
+# ---- Tacotron v1 primitives (independent statements for oracle/v1_oracle.py) -----------------------
+def gru_cell_tf(x, h, wg, bg, wc, bc):
+    """TF GRUCell written from the equations of SURVEY.md App. A2 with torch ops (NOT torch.nn.GRU, whose
+    candidate applies the reset gate after the matmul)."""
+    x, h = t(x), t(h)
+    n_in = x.shape[1]
+    wg, wc = t(wg), t(wc)
+    gates = torch.sigmoid(x @ wg[:n_in] + h @ wg[n_in:] + t(bg))
+    H = h.shape[1]
+    r, u = gates[:, :H], gates[:, H:]
+    cand = torch.tanh(x @ wc[:n_in] + (r * h) @ wc[n_in:] + t(bc))
+    return (u * h + (1 - u) * cand).numpy()
+
+
+def maxpool2_same(x):
+    """MaxPooling1D(2, strides=1, 'SAME') through torch.nn.functional.max_pool1d with -inf right padding."""
+    xt = t(x).transpose(1, 2)
+    xt = F.pad(xt, (0, 1), value=float("-inf"))
+    return F.max_pool1d(xt, kernel_size=2, stride=1).transpose(1, 2).numpy()
+
+
+def highway(x, wh, bh, wt, bt):
+    x = t(x)
+    h = torch.relu(F.linear(x, t(wh).T, t(bh)))
+    g = torch.sigmoid(F.linear(x, t(wt).T, t(bt)))
+    return (h * g + x * (1 - g)).numpy()
+
+
+def bahdanau_step(query, keys, values, lengths, wq, v):
+    q = t(query) @ t(wq)
+    score = (t(v) * torch.tanh(t(keys) + q[:, None, :])).sum(-1)
+    if lengths is not None:
+        T = keys.shape[1]
+        mask = torch.arange(T)[None, :] < torch.as_tensor(np.asarray(lengths))[:, None]
+        score = score.masked_fill(~mask, float("-inf"))
+    a = torch.softmax(score, dim=-1)
+    ctx = torch.bmm(a[:, None, :], t(values))[:, 0]
+    return a.numpy(), ctx.numpy()

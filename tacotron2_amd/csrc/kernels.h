@@ -699,11 +699,14 @@ struct AttnArgs {
 
 #define T2_ATTN_THREADS 512
 
+// kernel variants: <FMAX, UPL> = <32, 2> (F <= 32, U <= 128: Tacotron2), <32, 4> (F <= 32, U <= 256: the V1 decoder's
+// plain Bahdanau score runs as F = 1 with a zero location layer), <64, 4> (F <= 64, U <= 256)
 __host__ __device__ inline int attn_upl(int U, int F) { return (F <= 32 && U <= 128) ? 2 : 4; }
+__host__ __device__ inline int attn_fmax(int F) { return F <= 32 ? 32 : 64; }
 
 __host__ __device__ inline int attn_lds_floats(int T, int U, int F, int K) {
     const int FP = (F + 3) & ~3, KP = (K + 3) & ~3, UP = (U + 3) & ~3;
-    const int FMAX = attn_upl(U, F) == 2 ? 32 : 64;
+    const int FMAX = attn_fmax(F);
     return ((T + KP + 16 + 3) & ~3) + KP * FP + ((T + 8) * FMAX) + ((T + 3) & ~3) + 17 * UP + 64 + 2048 + FMAX * 64 * attn_upl(U, F);
 }
 

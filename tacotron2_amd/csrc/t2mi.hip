@@ -369,7 +369,8 @@ static int set_attention_func_attributes() {
             (const void*)attention_step_kernel<32, 2, 1, 0>, (const void*)attention_step_kernel<32, 2, 1, 2>, (const void*)attention_step_kernel<32, 2, 1, 4>,
             (const void*)attention_step_kernel<32, 2, 2, 0>, (const void*)attention_step_kernel<32, 2, 2, 2>, (const void*)attention_step_kernel<32, 2, 2, 4>,
             (const void*)attention_step_kernel<32, 2, 4, 0>, (const void*)attention_step_kernel<32, 2, 4, 2>, (const void*)attention_step_kernel<32, 2, 4, 4>,
-            (const void*)attention_step_kernel<64, 4, 1, 0>, (const void*)attention_step_kernel<64, 4, 2, 0>, (const void*)attention_step_kernel<64, 4, 4, 0>};
+            (const void*)attention_step_kernel<64, 4, 1, 0>, (const void*)attention_step_kernel<64, 4, 2, 0>, (const void*)attention_step_kernel<64, 4, 4, 0>,
+            (const void*)attention_step_kernel<32, 4, 1, 0>, (const void*)attention_step_kernel<32, 4, 2, 0>, (const void*)attention_step_kernel<32, 4, 4, 0>};
         for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     return T2_OK;
 }
@@ -602,12 +603,17 @@ static inline void launch_dense(int MB, dim3 grid, hipStream_t st, const SkinnyC
 }
 
 template <int MB>
-static inline void launch_attention_mb(int B, size_t lds, hipStream_t st, const AttnArgs& a, const PartialJobs& pj, bool small) {
+static inline void launch_attention_mb(int B, size_t lds, hipStream_t st, const AttnArgs& a, const PartialJobs& pj) {
+    const bool small = a.F <= 32 && a.U <= 128;
     constexpr int G = (MB >= 4) ? T2_G4 : 4;
     const int base = pj.n[0] > 0 ? (pj.core[0].kbtot / G) / T2_SKINNY_WAVES : 0;
     const int base1 = pj.n[1] > 0 ? (pj.core[1].kbtot / G) / T2_SKINNY_WAVES : base;
     const dim3 grid(B + pj.n[0] + pj.n[1]), blk(T2_ATTN_THREADS);
-    if (!small) { hipLaunchKernelGGL((attention_step_kernel<64, 4, MB, 0>), grid, blk, lds, st, a, pj); return; }
+    if (!small) {
+        if (a.F <= 32) hipLaunchKernelGGL((attention_step_kernel<32, 4, MB, 0>), grid, blk, lds, st, a, pj);
+        else hipLaunchKernelGGL((attention_step_kernel<64, 4, MB, 0>), grid, blk, lds, st, a, pj);
+        return;
+    }
     const int npw = base == base1 ? base : 0;
     switch (npw) {
         case 2: hipLaunchKernelGGL((attention_step_kernel<32, 2, MB, 2>), grid, blk, lds, st, a, pj); break;
@@ -615,12 +621,12 @@ static inline void launch_attention_mb(int B, size_t lds, hipStream_t st, const 
         default: hipLaunchKernelGGL((attention_step_kernel<32, 2, MB, 0>), grid, blk, lds, st, a, pj); break;
     }
 }
-static inline void launch_attention(int MB, int B, size_t lds, hipStream_t st, const AttnArgs& a, const PartialJobs* jobs, bool small) {
+static inline void launch_attention(int MB, int B, size_t lds, hipStream_t st, const AttnArgs& a, const PartialJobs* jobs) {
     PartialJobs pj{};
     if (jobs) pj = *jobs;
-    if (MB == 1) launch_attention_mb<1>(B, lds, st, a, pj, small);
-    else if (MB == 2) launch_attention_mb<2>(B, lds, st, a, pj, small);
-    else launch_attention_mb<4>(B, lds, st, a, pj, small);
+    if (MB == 1) launch_attention_mb<1>(B, lds, st, a, pj);
+    else if (MB == 2) launch_attention_mb<2>(B, lds, st, a, pj);
+    else launch_attention_mb<4>(B, lds, st, a, pj);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,7 +888,7 @@ extern "C" int t2_state_create(t2_model* m, const float* memory, const int64_t* 
     if (!m->finalized) return fail(T2_ESTATE, "model not finalized");
     T2_TRY(check_batch(B, T_in));
     HIP_TRY(hipSetDevice(m->ctx->device));
-    if (attn_lds_bytes(m->d, T_in) > 160 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention kernel's LDS", T_in);
+    if (attn_lds_bytes(m->d, T_in) > 120 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention kernel's LDS", T_in);
     t2_state* s = nullptr;
     T2_TRY(state_alloc(m, B, T_in, 1, false, &s));
     int r = state_init(s, memory, lens);
@@ -1042,7 +1048,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
             pj.core[0] = job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0); pj.z[0] = s->Z1; pj.n[0] = m->lstm1.n_wg;
             pj.core[1] = job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0); pj.z[1] = s->Z2; pj.n[1] = m->lstm2.n_wg;
         }
-        launch_attention(MB, B, lds, st, a, hoist ? &pj : nullptr, d.attention_filters <= 32 && U <= 128);
+        launch_attention(MB, B, lds, st, a, hoist ? &pj : nullptr);
     } else if (hoist) {      // lstm_only timing runs: the riding jobs as launches of their own
         launch_partial(MB, dim3(m->lstm1.n_wg), st, job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0), s->Z1);
         launch_partial(MB, dim3(m->lstm2.n_wg), st, job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0), s->Z2);
@@ -1114,7 +1120,7 @@ extern "C" int t2_decode_step(t2_model* m, t2_state* s, const float* prev_frames
 static int get_loop_state(t2_model* m, int B, int T, int cap, t2_state** out) {
     for (t2_state* s : m->states)
         if (s->B == B && s->T == T && s->cap == cap) { *out = s; return T2_OK; }
-    if (attn_lds_bytes(m->d, T) > 160 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention kernel's LDS", T);
+    if (attn_lds_bytes(m->d, T) > 120 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention kernel's LDS", T);
     // keep the cache small: drop everything when it grows
     if (m->states.size() >= 4) {
         HIP_TRY(hipStreamSynchronize(m->ctx->stream));

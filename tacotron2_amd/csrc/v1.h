@@ -594,7 +594,7 @@ static int v1_launch_step(t2v1_state* s, int step_off, int mode, int slot_hint) 
         a.ctx_dst[0] = pp(s->XA, s->XA_sz, 1, 0); a.ctx_dst[1] = single(s->XR, 0); a.ctx_plain = s->ctx_plain;
         a.conv_w = m->zeros; a.conv_b = m->zeros; a.wloc = m->zeros; a.v_a = m->v_a; a.b_a = m->zeros;
         a.B = B; a.T = T; a.U = A; a.E = E; a.F = 1; a.K = 1; a.MB = MB; a.cumulative = 0; a.ctl = s->ctl; a.step_off = step_off;
-        launch_attention(MB, B, v1_attn_lds(d, T), st, a, nullptr, A <= 128);
+        launch_attention(MB, B, v1_attn_lds(d, T), st, a, nullptr);
     }
     // 6. OutputProjectionWrapper on concat(h_att, context) (rnn_wrappers.py:180-186)
     {

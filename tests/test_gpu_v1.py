@@ -196,3 +196,30 @@ def test_v1_constructor_errors():
         CBHG(7, 4, 4, 4, 4, 2, False)                                  # modules.py:169
     with pytest.raises(AssertionError):
         V1_PROFILE.replace(n_feed_frame=3)                             # helpers.py:55
+
+
+@pytest.mark.parametrize("name", ["v1_tiny_teacher", "v1_mid_teacher", "v1_mid_free", "v1_ref_teacher"])
+def test_v1_golden_fixtures_through_the_api(name):
+    """Committed fixtures (tests/golden/make_golden_v1.py) through the reference-shaped classes: encoder memory,
+    teacher-forced / free-running mel, stop, alignments, PostNet spectrogram; identical stop-step index."""
+    import os
+    from tests.golden import make_golden_v1 as G
+    from tacotron2_amd.tacotron_v1 import EngineV1, ModeKeys, SingleSpeakerTacotronV1Model, TacotronV1PostNetModel
+    d, w, inp = G.materialize(name, G.cases()[name])
+    gold = np.load(os.path.join(os.path.dirname(G.__file__), name + ".npz"))
+    assert abs(G.weights_checksum(w) - float(gold["weights_checksum"])) < 1e-3 * float(gold["weights_checksum"])
+    eng = EngineV1(d, w)
+    model = SingleSpeakerTacotronV1Model(d, engine=eng)
+    memory = eng.encode(inp["ids"], None)
+    if inp["mode"] == "teacher":
+        mel, stop, st = model.decoder(memory, is_training=False, is_validation=True, teacher_forcing=True,
+                                      memory_sequence_length=inp["lens"], target=inp["targets"])
+        align = st[0].alignment_history.stack().permute(1, 2, 0)
+    else:
+        pred = model.predict({"source": inp["ids"], "source_length": inp["lens"]})
+        mel, stop, align = pred["mel"], pred["stop_token"], pred["alignment"]
+        assert stop.shape[1] == int(gold["steps"])
+    spec = TacotronV1PostNetModel(d, eng).model_fn({"mel": mel}, None, ModeKeys.PREDICT)["predictions"]["spec"]
+    for k, got in (("memory", memory), ("mel", mel), ("stop", stop), ("alignment", align), ("spec", spec)):
+        np.testing.assert_allclose(_np(got), gold[k], atol=ATOL, err_msg=f"{name}:{k}")
+    eng.close()
