@@ -146,7 +146,7 @@ int t2_decode_free_launch(t2_model* m, const float* memory, const int64_t* lens,
 int t2_decode_free_finish(t2_model* m, int* steps_out);
 
 /* Tuning / measurement hooks (no reference counterpart).  Options: "graph" (1: decode loops replay
- * hipGraph chunks, 0: eager launches), "chunk" (decoder steps per graph, 1..64), "splitk" (1: split-K LSTM step for batches > 16), "hoist" (1, default: the recurrent halves of the LSTM gate GEMMs ride as extra workgroups in the attention / projection launches; 0: whole-K LSTM launches), "lstm_only" (1: decode steps launch only the
+ * hipGraph chunks, 0: eager launches), "chunk" (decoder steps per graph, 1..64), "splitk" (1: split-K LSTM step for batches > 16), "hoist" (1, default: the recurrent halves of the LSTM gate GEMMs ride as extra workgroups in the attention / projection launches; 0: whole-K LSTM launches), "att3" (1, default: batches of <= 16 rows put all three riders into the attention launch), "lstm_only" (1: decode steps launch only the
  * LSTM kernels -- timing runs, outputs meaningless), "time_lstm" (1:
  * record HIP events around every decoder LSTM launch in eager mode; resets the counters).
  * Stats: "lstm_launches", "lstm_ms" (sum of event-timed launch durations, synchronises). */

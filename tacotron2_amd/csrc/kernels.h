@@ -423,15 +423,15 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void partial_step_kernel(SkinnyC
     partial_body<MB, NPW>(a, zout, blockIdx.x, red);
 }
 
-// Up to two recurrent-half jobs that ride in front of a small kernel's grid (horizontal fusion): the
+// Up to three recurrent-half jobs that ride in front of a small kernel's grid (horizontal fusion): the
 // attention step (one CU per batch row) and the projection step (a dozen workgroups) leave most of the
 // chip idle, and kernels of different streams / graph branches were measured not to overlap on this
 // stack, so the independent GEMM work is put into the SAME launch: the host kernel's own workgroups
 // come first (they are the critical path), then n0 workgroups of job 0 and n1 of job 1.
 struct PartialJobs {
-    SkinnyCore core[2];
-    float* z[2];
-    int n[2];
+    SkinnyCore core[3];
+    float* z[3];
+    int n[3];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -740,6 +740,7 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
     {
         __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
         const int j = (int)blockIdx.x - a.B;           // the attention rows come first: they are the critical path
+        if (j >= pj.n[0] + pj.n[1]) { partial_body<MB, NPW>(pj.core[2], pj.z[2], j - pj.n[0] - pj.n[1], red); return; }
         if (j >= pj.n[0]) { partial_body<MB, NPW>(pj.core[1], pj.z[1], j - pj.n[0], red); return; }
         if (j >= 0) { partial_body<MB, NPW>(pj.core[0], pj.z[0], j, red); return; }
     }

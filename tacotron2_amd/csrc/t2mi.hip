@@ -100,6 +100,7 @@ struct t2_model {
     int opt_chunk = 16;                 // steps per graph
     int opt_splitk = 0;                 // batches > 16 rows: split-K LSTM step with in-launch reduction
     int opt_hoist = 1;                  // recurrent halves of the LSTM GEMMs ride in the attention / projection launches
+    int opt_att3 = 1;                   // B <= 16: all three riders in the attention launch
     int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
 };
@@ -352,6 +353,10 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     }
     else if (!strcmp(name, "hoist")) {
         m->opt_hoist = value;
+        for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+    }
+    else if (!strcmp(name, "att3")) {
+        m->opt_att3 = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
     else if (!strcmp(name, "lstm_only")) {
@@ -608,13 +613,14 @@ static inline void launch_attention_mb(int B, size_t lds, hipStream_t st, const 
     constexpr int G = (MB >= 4) ? T2_G4 : 4;
     const int base = pj.n[0] > 0 ? (pj.core[0].kbtot / G) / T2_SKINNY_WAVES : 0;
     const int base1 = pj.n[1] > 0 ? (pj.core[1].kbtot / G) / T2_SKINNY_WAVES : base;
-    const dim3 grid(B + pj.n[0] + pj.n[1]), blk(T2_ATTN_THREADS);
+    const int base2 = pj.n[2] > 0 ? (pj.core[2].kbtot / G) / T2_SKINNY_WAVES : base;
+    const dim3 grid(B + pj.n[0] + pj.n[1] + pj.n[2]), blk(T2_ATTN_THREADS);
     if (!small) {
         if (a.F <= 32) hipLaunchKernelGGL((attention_step_kernel<32, 4, MB, 0>), grid, blk, lds, st, a, pj);
         else hipLaunchKernelGGL((attention_step_kernel<64, 4, MB, 0>), grid, blk, lds, st, a, pj);
         return;
     }
-    const int npw = base == base1 ? base : 0;
+    const int npw = (base == base1 && base == base2) ? base : 0;
     switch (npw) {
         case 2: hipLaunchKernelGGL((attention_step_kernel<32, 2, MB, 2>), grid, blk, lds, st, a, pj); break;
         case 4: hipLaunchKernelGGL((attention_step_kernel<32, 2, MB, 4>), grid, blk, lds, st, a, pj); break;
@@ -1001,6 +1007,10 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e);
     }
     const bool hoist = m->opt_hoist != 0;
+    // One row block (B <= 16): the attention launch leaves > 240 CUs idle for ~19 us, so it takes all three state halves
+    // (h1, h2 of this step and h_att for the NEXT step); the context part of the attention LSTM's K range stays in the
+    // LSTM launch and the projection launch carries no rider.  At B = 64 the same placement costs a fourth rider round.
+    const bool att3 = hoist && m->opt_att3 && MB == 1 && !m->opt_lstm_only;
     const bool timing = m->opt_time_lstm && !m->opt_graph;
     // recurrent half of an LSTM layer: [state operands] . kernel[their K range] -> z (partial_body)
     auto job = [&](const Packed& p, int kb_w0, int kb_n, FragBuf src, int off) {
@@ -1015,7 +1025,13 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     {
         SkinnyCore c = core(m->att_lstm);
         LstmEpi e{};
-        if (hoist) {
+        if (att3) {
+            c.kb0 = m->att_lstm.seg_kb[0];
+            c.kbtot = m->att_lstm.seg_kb[0] + KBe;
+            c.seg[0][0] = single(s->xp[np - 1], 0);
+            c.seg[0][1] = pp(s->XA, s->XA_sz, 0, 0);
+            e.zpart = s->ZA;
+        } else if (hoist) {
             c.kbtot = m->att_lstm.seg_kb[0];
             c.seg[0][1] = single(s->xp[np - 1], 0);
             e.zpart = s->ZA;
@@ -1047,6 +1063,10 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         if (hoist) {
             pj.core[0] = job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0); pj.z[0] = s->Z1; pj.n[0] = m->lstm1.n_wg;
             pj.core[1] = job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0); pj.z[1] = s->Z2; pj.n[1] = m->lstm2.n_wg;
+            if (att3) {
+                pj.core[2] = job(m->att_lstm, m->att_lstm.seg_kb[0] + KBe, KBa, pp(s->XA, s->XA_sz, 0, KBe * 16), 1);
+                pj.z[2] = s->ZA; pj.n[2] = m->att_lstm.n_wg;
+            }
         }
         launch_attention(MB, B, lds, st, a, hoist ? &pj : nullptr);
     } else if (hoist) {      // lstm_only timing runs: the riding jobs as launches of their own
@@ -1087,8 +1107,8 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.stop_col = M * r; e.out_stop = io.stop; e.stop_ld = io.stop_ld; e.stop_t_mul = io.stop_t_mul; e.ctl_w = s->ctl;
         // the recurrent half of the attention LSTM of the NEXT step rides behind the projection grid
         PartialJobs pj{};
-        if (hoist) { pj.core[0] = job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1); pj.z[0] = s->ZA; pj.n[0] = m->att_lstm.n_wg; }
-        launch_dense(MB, dim3(m->proj.n_wg), st, c, e, hoist ? &pj : nullptr);
+        if (hoist && !att3) { pj.core[0] = job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1); pj.z[0] = s->ZA; pj.n[0] = m->att_lstm.n_wg; }
+        launch_dense(MB, dim3(m->proj.n_wg), st, c, e, (hoist && !att3) ? &pj : nullptr);
     } else if (hoist) {
         launch_partial(MB, dim3(m->att_lstm.n_wg), st, job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1), s->ZA);
     }
