@@ -131,7 +131,7 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "mel frames/sec (node), Tacotron2 free-running synthesis B=64 per GPU",
+            "metric": "mel frames/sec (node), Tacotron2 decode B=64 at 1/2/4/8 GPUs; batch-1 RTF",
             "value": frames_all / dt_max, "unit": "mel frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -222,7 +222,7 @@ def main():
         except Exception:
             cores = os.cpu_count() or 1
         cores = min(cores, 16)
-        sample_steps = 20
+        sample_steps = S              # the whole step once: ~10-20 s of NumPy work on the box's host cores
         t_a = time.perf_counter()
         mem_o = O.encoder_v2(d, w, O.embedding_lookup(ids, w["embedding"]), lens)
         t_b = time.perf_counter()
@@ -234,13 +234,13 @@ def main():
         cpu_total = (t_b - t_a) + ((t_c - t_b) + (t_d - t_c)) * scale
         out["cpu_baseline"] = {"value": B * S * r / cpu_total, "unit": "mel frames/s", "cores": int(cores),
                                "kind": "port",
-                               "sample": "NumPy oracle (CPU restatement, not TensorFlow), same B=%d batch: encoder once "
+                               "sample": "NumPy oracle (CPU restatement, not TensorFlow), the same B=%d batch once: encoder "
                                          "(%.2fs) + %d of %d decoder steps (%.2fs) + PostNetV2 on those %d frames/utt "
-                                         "(%.2fs); decoder and postnet time scaled x%.0f to the full %d steps"
-                                         % (B, t_b - t_a, sample_steps, S, t_c - t_b, sample_steps * r, t_d - t_c, scale, S)}
+                                         "(%.2fs); scale x%.0f" % (B, t_b - t_a, sample_steps, S, t_c - t_b, sample_steps * r, t_d - t_c, scale)}
         # parity spot check of the timed configuration: first sample_steps steps of the GPU decode
         got = bufs[0][:, :sample_steps * r].cpu().numpy()
-        out["parity_check"] = {"max_abs_mel_diff_first_%d_steps" % sample_steps: float(np.abs(got - mel_o).max())}
+        out["parity_check"] = {"max_abs_mel_diff_first_20_steps": float(np.abs(got[:, :20 * r] - mel_o[:, :20 * r]).max()),
+                               "max_abs_mel_diff_all_%d_free_running_steps" % sample_steps: float(np.abs(got - mel_o).max())}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

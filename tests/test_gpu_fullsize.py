@@ -1,0 +1,109 @@
+"""Parity at BASELINE.json's full sizes (profile P, B = 64 per GPU, ragged T_in in 60..140) and the edge cases of
+the path: directly against the oracle for as many decoder steps as the oracle finishes in seconds, and through
+size-independent properties (batch-row independence, the reference's free-run -> teacher-forcing property)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import t2_oracle as O
+from tacotron2_amd.hparams import PROFILE_P
+from tacotron2_amd.weights import init_weights
+
+ATOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def paper():
+    from tacotron2_amd.engine import Engine
+    d = PROFILE_P
+    w = init_weights(d, seed=77, perturb=True)
+    eng = Engine(d, w)
+    rng = np.random.default_rng(64)
+    B = 64
+    lens = rng.integers(60, 141, size=B).astype(np.int64)
+    lens[5] = 140
+    T = int(lens.max())
+    ids = np.zeros((B, T), np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(32, 91, size=n)
+    yield d, w, eng, ids, lens
+    eng.close()
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("hoist", [1, 0])
+def test_full_size_batch64_against_oracle(paper, hoist):
+    d, w, eng, ids, lens = paper
+    eng.set_option("hoist", hoist)
+    S = 8
+    rng = np.random.default_rng(3)
+    target = rng.uniform(0, 1, (64, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+    memory_o = O.encoder_v2(d, w, O.embedding_lookup(ids, w["embedding"]), lens)
+    memory = eng.encode(ids, lens)
+    np.testing.assert_allclose(_np(memory), memory_o, atol=ATOL)
+    mel_o, stop_o, st = O.decoder_v2(d, w, memory_o, is_validation=True, teacher_forcing=True, memory_sequence_length=lens,
+                                     target=target, max_iters=S)
+    mel, stop, align = eng.decode_teacher(memory, lens, target, teacher_forcing=True)
+    np.testing.assert_allclose(_np(mel), mel_o, atol=ATOL)
+    np.testing.assert_allclose(_np(stop), stop_o, atol=ATOL)
+    np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=ATOL)
+    eng.set_option("hoist", 1)
+
+
+def test_full_size_rows_are_independent(paper):
+    """No tensor is shared across batch rows: rows decoded alone equal the same rows of the B = 64 batch."""
+    d, w, eng, ids, lens = paper
+    S = 24
+    rng = np.random.default_rng(4)
+    target = rng.uniform(0, 1, (64, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+    memory = eng.encode(ids, lens)
+    mel, stop, align = eng.decode_teacher(memory, lens, target, teacher_forcing=True)
+    for b in (0, 17, 63):
+        T_b = int(lens[b])
+        # same padded width: the conv stack ignores lengths, so padding leaks into the last real positions
+        # (modules.py:149-157) and a row re-encoded at its own length would differ there
+        mem_b = eng.encode(ids[b:b + 1], lens[b:b + 1])
+        np.testing.assert_allclose(_np(mem_b)[0], _np(memory)[b], atol=1e-5)
+        mel_b, stop_b, align_b = eng.decode_teacher(mem_b, lens[b:b + 1], target[b:b + 1], teacher_forcing=True)
+        np.testing.assert_allclose(_np(mel_b)[0], _np(mel)[b], atol=1e-4)
+        np.testing.assert_allclose(_np(stop_b)[0], _np(stop)[b], atol=1e-4)
+        np.testing.assert_allclose(_np(align_b)[:, 0, :], _np(align)[:, b, :], atol=1e-5)
+        assert float(np.abs(_np(align)[:, b, T_b:]).max(initial=0.0)) == 0.0          # masked positions get exactly zero weight
+
+
+def test_full_size_free_run_equals_teacher_forced(paper):
+    """tests/decoder_test.py:42-67 at paper sizes, B = 64: the free-running output fed back as the target."""
+    d, w, eng, ids, lens = paper
+    memory = eng.encode(ids, lens)
+    mel_f, stop_f, align_f, n = eng.decode_free(memory, lens, max_iters=20, min_iters=100)      # stop rule cannot fire
+    assert n == 20
+    mel_t, stop_t, align_t = eng.decode_teacher(memory, lens, mel_f, teacher_forcing=True)
+    np.testing.assert_allclose(_np(mel_t), _np(mel_f), atol=1e-5)
+    np.testing.assert_allclose(_np(stop_t), _np(stop_f), atol=1e-5)
+    np.testing.assert_allclose(_np(align_t), _np(align_f), atol=1e-6)
+    post = eng.postnet(mel_f[:8])
+    np.testing.assert_allclose(_np(post), O.postnet_v2(d, w, _np(mel_f[:8])), atol=ATOL)
+
+
+def test_edge_single_position_and_limits(paper):
+    from tacotron2_amd._lib import T2Error
+    d, w, eng, ids, lens = paper
+    one = np.array([[40]], np.int64)
+    mem = eng.encode(one, np.array([1]))
+    mem_o = O.encoder_v2(d, w, O.embedding_lookup(one, w["embedding"]), np.array([1]))
+    np.testing.assert_allclose(_np(mem), mem_o, atol=ATOL)
+    mel, stop, align, n = eng.decode_free(mem, np.array([1]), max_iters=3, min_iters=100)
+    assert n == 3 and np.allclose(_np(align), 1.0)                       # softmax over one position
+    mel_o, _, _ = O.decoder_v2(d.replace(min_iters=100), w, mem_o, memory_sequence_length=np.array([1]), max_iters=3)
+    np.testing.assert_allclose(_np(mel), mel_o, atol=ATOL)
+    with pytest.raises(T2Error) as ei:                                   # longer than the attention kernel's LDS plan
+        eng.decode_free(np.zeros((1, 700, d.enc_units), np.float32), np.array([700]), max_iters=2)
+    assert ei.value.code == -1 and "too long" in ei.value.msg
+    with pytest.raises(T2Error):                                         # length 0 is not a valid memory_sequence_length
+        eng.decode_free(_np(mem), np.array([0]), max_iters=2)
+    with pytest.raises(T2Error):                                         # T_out not a multiple of r
+        eng.decode_teacher(mem, np.array([1]), np.zeros((1, 3, d.num_mels), np.float32))
