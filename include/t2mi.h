@@ -182,6 +182,19 @@ int t2_optim_step(t2_optim* o, float* params, const float* grads, float learning
 int t2_optim_get_state(t2_optim* o, float* m_out, float* v_out, int64_t* step_out);
 int t2_optim_set_state(t2_optim* o, const float* m_in, const float* v_in, int64_t step);
 
+/* ---- training step of the V2 path (BASELINE.json configs[3]) ---------------------------------------------------------
+ * A trainer owns the tape of one (B, T_in, S = T_out / r) teacher-forced training forward and the workspaces of the
+ * backward pass.  Sampled paths (dropout, zoneout) draw from the counter-based generator t2_u01 (csrc/kernels.h) keyed by
+ * `seed`: TensorFlow's stateful random streams cannot be reproduced, the arithmetic around the masks is TF's. */
+typedef struct t2_trainer t2_trainer;
+int t2_trainer_create(t2_model* m, int B, int T_in, int S, t2_trainer** out);
+int t2_trainer_destroy(t2_trainer* tr);
+/* DecoderV1.call(is_training=True) with the V2 cells (tacotron_v1.py:134-150): TrainingHelper (helpers.py:141-184), PreNet
+ * dropout with prenet_drop_rate (modules.py:90,96-98), ZoneoutLSTMCell training branch (modules.py:274-276).  Buffers and
+ * outputs as t2_decode_teacher; targets dev [B, S*r, M]. */
+int t2_train_decoder_forward(t2_trainer* tr, const float* memory, const int64_t* lens, const float* targets,
+                             float prenet_drop_rate, uint32_t seed, float* mel, float* stop, float* align);
+
 /* ---- Tacotron v1 path (BASELINE.json configs[4]) ---------------------------------
  * Field meaning: reference hparams.py:14-15,23,27-28,31-47,54-60.  Inference arithmetic (dropout off, batch
  * norm with moving statistics).  Variable names: tacotron2_amd/weights_v1.py:weight_shapes_v1 (TF GRUCell

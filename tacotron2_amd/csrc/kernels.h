@@ -46,6 +46,27 @@ __host__ __device__ inline size_t frag_idx(int row, int k, int MB) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Counter-based generator of the sampled training paths (PreNet / conv dropout, zoneout): 24 uniform bits per
+// (seed, stream, step, row, column).  TensorFlow's stateful random ops cannot be reproduced; the oracle uses this same
+// function (oracle/t2_oracle.py:rng_u01), TF's arithmetic around it.
+__host__ __device__ inline uint32_t t2_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline float t2_u01(uint32_t seed, uint32_t stream, uint32_t t, uint32_t row, uint32_t col) {
+    uint32_t h = t2_mix32(seed ^ (stream * 0x9E3779B9u));
+    h = t2_mix32(h ^ (t * 0x85EBCA6Bu + 0x165667B1u));
+    h = t2_mix32(h ^ (row * 0xC2B2AE35u + 0x27D4EB2Fu));
+    h = t2_mix32(h ^ (col * 0x9E3779B1u + 0x85EBCA77u));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+// tf.nn.dropout(x, keep_prob) of TF 1.11/1.12: x / keep_prob * floor(keep_prob + uniform)
+__device__ __forceinline__ float dropout_train(float x, float rate, float u) { return (u >= rate) ? x / (1.0f - rate) : 0.0f; }
+#define T2_STREAM_PRENET 1
+#define T2_STREAM_ZONE_ATT 10
+#define T2_STREAM_ZONE_L1 12
+#define T2_STREAM_ZONE_L2 14
+
 // returns the step index of this launch or -1 when the launch must do nothing
 __device__ __forceinline__ int step_index(const int* __restrict__ ctl, int step_off) {
     if (ctl == nullptr) return step_off;
@@ -101,6 +122,15 @@ struct LstmEpi {
     const float* wq;          // [A][U] or null
     float* qpart;             // [n_wg][MB*16][U]
     int U;
+    // training-mode forward (ZoneoutLSTMCell, modules.py:274-276) and the tape of the backward pass (all may be null):
+    int train;                // 1: sampled zoneout masks from t2_u01(seed, stream | stream + 1, t, row, unit)
+    uint32_t seed;
+    int stream;
+    float* tp_z;              // [S][B][4H] gate pre-activations (i | j | f | o), bias included
+    float* tp_cprev;          // [S][B][H] cell state before the step
+    float* tp_cnew;           // [S][B][H] new cell value before zoneout
+    float* tp_hraw;           // [S][B][H] raw output h
+    float* tp_hstate;         // [S][B][H] zoned state h
 };
 
 struct DenseEpi {
@@ -119,6 +149,9 @@ struct DenseEpi {
     int stop_ld;
     int stop_t_mul;
     int* ctl_w;               // writable ctl (same block as core.ctl)
+    float drop_rate;          // > 0: tf.layers.dropout after the activation (PreNet, modules.py:90), training mode
+    uint32_t seed;
+    int stream;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -353,6 +386,17 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
             hn = sigmoidf_(zo) * tanhf(cn);
             float cs = (1.0f - e.zc) * cn + e.zc * cp;
             float hs = (1.0f - e.zh) * hn + e.zh * hp;
+            if (e.train) {                                    // modules.py:274-276
+                cs = (1.0f - e.zc) * dropout_train(cn - cp, e.zc, t2_u01(e.seed, e.stream + 2 * dir, t, row, unit)) + cp;
+                hs = (1.0f - e.zh) * dropout_train(hn - hp, e.zh, t2_u01(e.seed, e.stream + 2 * dir + 1, t, row, unit)) + hp;
+            }
+            if (e.tp_z != nullptr) {
+                const size_t ti = ((size_t)t * a.B + row);
+                float* tz = e.tp_z + ti * 4 * e.H;
+                tz[unit] = zi; tz[e.H + unit] = zj; tz[2 * e.H + unit] = zf; tz[3 * e.H + unit] = zo;
+                e.tp_cprev[ti * e.H + unit] = cp; e.tp_cnew[ti * e.H + unit] = cn;
+                e.tp_hraw[ti * e.H + unit] = hn; e.tp_hstate[ti * e.H + unit] = hs;
+            }
             bool live = true;
             if (e.lens != nullptr) {
                 live = t < len;
@@ -634,6 +678,7 @@ __device__ __forceinline__ void dense_body(const SkinnyCore& a, const DenseEpi& 
         float v = red_sum<MB>(red, row, c);
         if (a.bias[0] != nullptr) v += a.bias[0][col];
         if (e.relu) v = fmaxf(v, 0.f);
+        if (e.drop_rate > 0.f) v = dropout_train(v, e.drop_rate, t2_u01(e.seed, e.stream, t, row, col));
         if (col == e.stop_col) {
             e.out_stop[(size_t)row * e.stop_ld + (size_t)t * e.stop_t_mul] = v;
             if (!(v > 0.f)) atomicOr(s_notstop, 1);       // sigmoid(v) > 0.5  <=>  v > 0
@@ -695,6 +740,9 @@ struct AttnArgs {
     int B, T, U, E, F, K, MB, cumulative;
     const int* ctl;
     int step_off;
+    // tape of the backward pass (may be null): processed query + bias [S][B][U], attention state before the step [S][B][T],
+    // context [S][B][E]
+    float* tp_q; float* tp_state_prev; float* tp_ctx;
 };
 
 #define T2_ATTN_THREADS 512
@@ -903,6 +951,7 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         float sq = a.b_a[tid];
         for (int g = 0; g < PG; ++g) sq += s_q[g * UP + tid];
         s_q[16 * UP + tid] = sq;          // q[u] + b_a[u]
+        if (a.tp_q != nullptr) a.tp_q[((size_t)t_step * a.B + b) * U + tid] = sq;
     }
     __syncthreads();
     // location-layer columns of this lane's units: LDS -> registers
@@ -1022,6 +1071,7 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         s_e[i] = p;
         al[i] = p;
         if (hist) hist[i] = p;
+        if (a.tp_state_prev != nullptr) a.tp_state_prev[((size_t)t_step * a.B + b) * T + i] = s_prev[i + pad_l];
         state[i] = a.cumulative ? (p + s_prev[i + pad_l]) : p;      // :137-140
     }
     __syncthreads();
@@ -1033,6 +1083,7 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         if (d0) d0[frag_idx(b, a.ctx_dst[0].koff + c, a.MB)] = v;
         if (d1) d1[frag_idx(b, a.ctx_dst[1].koff + c, a.MB)] = v;
         if (a.ctx_plain) a.ctx_plain[(size_t)b * E + c] = v;
+        if (a.tp_ctx) a.tp_ctx[((size_t)t_step * a.B + b) * E + c] = v;
     };
     if (vec_ctx) {
         if (v_active) {

@@ -969,6 +969,16 @@ struct StepIO {
     float* stop; int stop_ld; int stop_t_mul;
     float* hist;
     int slot_hint;              // 1: ctl base is even (chunked loops with an even chunk), so t and step_off select the same slots
+    const struct TrainTape* train;   // non-null: training-mode arithmetic (sampled dropout / zoneout) + tape writes
+};
+
+// Tape of one teacher-forced training forward (csrc/train_step.h): plain [S][B][.] arrays read by the backward pass.
+struct TrainTape {
+    uint32_t seed;
+    float prenet_drop_rate;
+    float* xp[T2_MAX_PRENET_LAYERS];          // PreNet outputs after dropout
+    float *z[3], *cprev[3], *cnew[3], *hraw[3], *hstate[3];   // attention LSTM, LSTM 1, LSTM 2
+    float *q, *state_prev, *ctx;              // attention: q + b_a, state before the step, context
 };
 
 static int launch_step(t2_state* s, int step_off, const StepIO& io) {
@@ -1004,6 +1014,11 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         c.seg[0][1] = single(i == 0 ? s->xf : s->xp[i - 1], 0);
         DenseEpi e{};
         e.N = d.prenet_units[i]; e.relu = 1; e.out_frag = single(s->xp[i], 0); e.frag_col0 = 0; e.stop_col = -1;
+        if (io.train) {
+            e.drop_rate = io.train->prenet_drop_rate; e.seed = io.train->seed; e.stream = T2_STREAM_PRENET + i;
+            e.out_plain = io.train->xp[i]; e.plain_ld = d.prenet_units[i]; e.plain_t_stride = (long long)B * d.prenet_units[i];
+            e.plain_ncol = d.prenet_units[i];
+        }
         launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e);
     }
     const bool hoist = m->opt_hoist != 0;
@@ -1019,6 +1034,12 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         c.t_hint = io.slot_hint ? step_off + off : -1;
         c.kb_w0 = kb_w0; c.kbtot = kb_n; c.kb0 = 0; c.seg[0][1] = src;
         return c;
+    };
+    auto taped = [&](LstmEpi& e, int layer, int stream) {
+        if (!io.train) return;
+        e.train = 1; e.seed = io.train->seed; e.stream = stream;
+        e.tp_z = io.train->z[layer]; e.tp_cprev = io.train->cprev[layer]; e.tp_cnew = io.train->cnew[layer];
+        e.tp_hraw = io.train->hraw[layer]; e.tp_hstate = io.train->hstate[layer];
     };
     // 3. attention LSTM on concat(prenet out, previous context)  (AttentionWrapper, App. A6) + this step's
     //    partial query products (tacotron_v2.py:122)
@@ -1045,6 +1066,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.hraw[0] = pp(s->X1, s->X1_sz, 0, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         e.wq = m->wq; e.qpart = s->qpart; e.U = U;
+        taped(e, 0, T2_STREAM_ZONE_ATT);
         timed_lstm(timing, MB, m->att_lstm.n_wg, st, c, e, (m->opt_splitk && !hoist) ? s->tickets : nullptr, s->sk_slabs);
     }
     // 4./5. location-sensitive attention + context
@@ -1057,6 +1079,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
         a.B = B; a.T = s->T; a.U = U; a.E = E; a.F = d.attention_filters; a.K = d.attention_kernel; a.MB = MB;
         a.cumulative = d.cumulative_weights; a.ctl = s->ctl; a.step_off = step_off;
+        if (io.train) { a.tp_q = io.train->q; a.tp_state_prev = io.train->state_prev; a.tp_ctx = io.train->ctx; }
         const size_t lds = attn_lds_bytes(d, s->T);
         // the recurrent halves of the two decoder LSTMs of THIS step ride behind the attention grid
         PartialJobs pj{};
@@ -1083,6 +1106,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.hprev[0] = pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16); e.hstate[0] = pp(s->X1, s->X1_sz, 1, (KBa + KBe) * 16);
         e.hraw[0] = pp(s->X2, s->X2_sz, 0, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+        taped(e, 1, T2_STREAM_ZONE_L1);
         timed_lstm(timing, MB, m->lstm1.n_wg, st, c, e, (m->opt_splitk && !hoist) ? s->tickets + s->sk_tiles : nullptr, s->sk_slabs);
     }
     {
@@ -1094,6 +1118,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.hprev[0] = pp(s->X2, s->X2_sz, 0, s->KBd * 16); e.hstate[0] = pp(s->X2, s->X2_sz, 1, s->KBd * 16);
         e.hraw[0] = single(s->XY, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+        taped(e, 2, T2_STREAM_ZONE_L2);
         timed_lstm(timing, MB, m->lstm2.n_wg, st, c, e, (m->opt_splitk && !hoist) ? s->tickets + 2 * s->sk_tiles : nullptr, s->sk_slabs);
     }
     // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
@@ -1339,3 +1364,8 @@ extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
 // Tacotron v1 path
 // ------------------------------------------------------------------------------------------------
 #include "v1.h"
+
+// ------------------------------------------------------------------------------------------------
+// training step: training-mode forward with a tape, backward pass (BASELINE.json configs[3])
+// ------------------------------------------------------------------------------------------------
+#include "train_step.h"

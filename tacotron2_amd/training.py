@@ -190,3 +190,40 @@ class AdamOptimizer:
             self.close()
         except Exception:
             pass
+
+
+class Trainer:
+    """One t2_trainer: the tape of a (B, T_in, S) teacher-forced training forward of an ``Engine``'s model and the
+    workspaces of its backward pass (include/t2mi.h, "training step")."""
+
+    def __init__(self, engine, B: int, T_in: int, S: int):
+        self.engine, self.B, self.T_in, self.S = engine, int(B), int(T_in), int(S)
+        self._h = C.c_void_p()
+        _lib.check(engine.lib.t2_trainer_create(engine._model, self.B, self.T_in, self.S, C.byref(self._h)))
+
+    def decoder_forward(self, memory, lens, targets, prenet_drop_rate: float = 0.5, seed: int = 0):
+        """DecoderV1.call(is_training=True) with the V2 cells: (mel [B, S*r, M], stop [B, S, 1], alignments [S, B, T_in])."""
+        eng, d = self.engine, self.engine.dims
+        memory, targets = eng._f32(memory), eng._f32(targets)
+        lens = None if lens is None else np.ascontiguousarray(np.asarray(lens), dtype=np.int64)
+        if tuple(memory.shape[:2]) != (self.B, self.T_in) or tuple(targets.shape) != (self.B, self.S * d.outputs_per_step, d.num_mels):
+            raise ValueError("memory / targets do not match the trainer's (B, T_in, S)")
+        mel = torch.empty_like(targets)
+        stop = torch.empty((self.B, self.S), dtype=torch.float32, device=eng.device)
+        align = torch.empty((self.S, self.B, self.T_in), dtype=torch.float32, device=eng.device)
+        with eng._ordered():
+            _lib.check(eng.lib.t2_train_decoder_forward(self._h, memory.data_ptr(), None if lens is None else lens.ctypes.data_as(C.c_void_p),
+                                                        targets.data_ptr(), float(prenet_drop_rate), int(seed) & 0xFFFFFFFF,
+                                                        mel.data_ptr(), stop.data_ptr(), align.data_ptr()))
+        return mel, stop.unsqueeze(-1), align
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.engine, "_model", None):
+            self.engine.lib.t2_trainer_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

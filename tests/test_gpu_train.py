@@ -1,0 +1,54 @@
+"""GPU parity of the training step of the V2 path (BASELINE.json configs[3]) through the C-ABI: training-mode decoder
+forward against the NumPy oracle with the same sampled masks, gradients against torch autograd (oracle/torch_train.py).
+Tolerances: 1e-3 absolute on forward outputs (north_star); gradients 1e-3 relative to the largest entry of each variable's
+gradient (+1e-6 absolute)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import t2_oracle as O
+from tacotron2_amd.hparams import PROFILE_TINY, T2Dims
+from tacotron2_amd.weights import init_weights
+
+MID = T2Dims(num_symbols=64, num_mels=20, outputs_per_step=2, n_feed_frame=2, attention_kernel=31, attention_filters=32,
+             embedding_dim=64, enc_conv_layers=3, enc_kernel=5, enc_units=64, prenet_units=(48, 32), attention_lstm_units=96,
+             decoder_lstm_units=80, attention_dim=32, postnet_layers=5, postnet_kernel=5, postnet_channels=64, max_iters=40, min_iters=10)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _setup(d, B, T, S, seed):
+    from tacotron2_amd.engine import Engine
+    w = init_weights(d, seed, perturb=True)
+    rng = np.random.default_rng(seed)
+    memory = (rng.standard_normal((B, T, d.enc_units)) * 0.5).astype(np.float32)
+    lens = rng.integers(max(1, T // 2), T + 1, size=B).astype(np.int64)
+    lens[0] = T
+    target = rng.uniform(0, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+    return w, Engine(d, w), memory, lens, target
+
+
+@pytest.mark.parametrize("d,B,T,S", [(PROFILE_TINY, 3, 7, 6), (MID, 5, 19, 12), (MID, 33, 11, 7)])
+@pytest.mark.parametrize("hoist", [1, 0])
+def test_training_mode_decoder_forward(d, B, T, S, hoist):
+    from tacotron2_amd.training import Trainer
+    w, eng, memory, lens, target = _setup(d, B, T, S, 5)
+    eng.set_option("hoist", hoist)
+    tr = Trainer(eng, B, T, S)
+    for seed, rate in ((11, 0.5), (12, 0.25)):
+        mel, stop, align = tr.decoder_forward(memory, lens, target, prenet_drop_rate=rate, seed=seed)
+        mel_o, stop_o, st = O.decoder_v2(d, w, memory, is_training=True, memory_sequence_length=lens, target=target,
+                                         train_seed=seed, prenet_drop_rate=rate)
+        np.testing.assert_allclose(_np(mel), mel_o, atol=1e-3)
+        np.testing.assert_allclose(_np(stop), stop_o, atol=1e-3)
+        np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history), atol=1e-3)
+    # the sampled forward is not the inference forward, and it is reproducible
+    mel_i, _, _ = eng.decode_teacher(memory, lens, target, teacher_forcing=True)
+    assert float((mel - mel_i).abs().max()) > 1e-3
+    mel2, _, _ = tr.decoder_forward(memory, lens, target, prenet_drop_rate=0.25, seed=12)
+    assert bool((mel2 == mel).all())
+    tr.close()
+    eng.close()
