@@ -195,6 +195,15 @@ int t2_trainer_destroy(t2_trainer* tr);
 int t2_train_decoder_forward(t2_trainer* tr, const float* memory, const int64_t* lens, const float* targets,
                              float prenet_drop_rate, uint32_t seed, float* mel, float* stop, float* align);
 
+/* Where the gradient of variable `name` (TF layout) goes in the caller's flat gradient buffer (floats, multiple of 4). */
+int t2_trainer_bind_gradient(t2_trainer* tr, const char* name, int64_t offset);
+/* Backward of t2_train_decoder_forward through the losses of model_fn (tacotron/models.py:58-61: spec_loss(mel) +
+ * binary_loss(stop), T1 / T2) -- BPTT over the tape.  done, bin_mask dev [B,S]; spec_mask dev [B,S*r].  Writes the gradient of
+ * every decoder/ and attention/ variable into flat_grads (dev) at the bound offsets, d loss / d memory into dmemory
+ * (dev [B,T_in,enc_units]) and {mel_loss, done_loss, loss} into loss_out (dev [3]). */
+int t2_train_decoder_backward(t2_trainer* tr, const float* done, const float* spec_mask, const float* bin_mask,
+                              float* flat_grads, float* dmemory, float* loss_out);
+
 /* ---- Tacotron v1 path (BASELINE.json configs[4]) ---------------------------------
  * Field meaning: reference hparams.py:14-15,23,27-28,31-47,54-60.  Inference arithmetic (dropout off, batch
  * norm with moving statistics).  Variable names: tacotron2_amd/weights_v1.py:weight_shapes_v1 (TF GRUCell

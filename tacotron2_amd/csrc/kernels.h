@@ -1227,6 +1227,7 @@ struct ConvArgs {
     int Mtot, T, Cin, N, ktaps, pad_l;
     int act;                       // 0 none, 1 relu, 2 tanh
     int vec_a, vec_b;              // float4 paths usable
+    int trans_a;                   // 1 (ktaps = 1 only): A element (m, k) is x[k * ldx + m] -- weight gradients X^T . dZ
 };
 
 #define CG_BM 128
@@ -1262,6 +1263,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 
     auto load_tiles = [&](int kt) {
         const int kbase = kt * CG_BK;
+        if (a.trans_a) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int kk = kbase + b_k0 + p * 8;
+                const int m = m0 + b_nq * 4;
+                float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+                if (kk < Ktot) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (m + c < a.Mtot) tmp[c] = a.x[(size_t)kk * a.ldx + m + c];
+                }
+                ra[p] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+            }
+        } else
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int m = m0 + a_r0 + p * 64;
@@ -1313,6 +1327,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         }
     };
     auto store_tiles = [&](int buf) {
+        if (a.trans_a) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(&As[buf][b_k0 + p * 8][b_nq * 4]) = ra[p];
+        } else
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int r = a_r0 + p * 64;

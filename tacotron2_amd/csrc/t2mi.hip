@@ -467,7 +467,7 @@ extern "C" int t2_model_finalize(t2_model* m) {
     HIP_TRY(hipHostMalloc((void**)&m->h_ctl, 8 * sizeof(int), hipHostMallocDefault));
     if (d.attention_filters > 64 || U > 256) return fail(T2_EINVAL, "attention_filters <= 64 and attention_dim <= 256 supported");
     T2_TRY(set_attention_func_attributes());
-    m->hw.clear();
+    // the host copies stay: a trainer packs the transposed operands of the backward pass from them
     m->finalized = true;
     return T2_OK;
 }

@@ -3,6 +3,309 @@
 // Included by t2mi.hip.
 #pragma once
 
+// ------------------------------------------------------------------------------------------------
+// backward kernels (plain [B][.] gradients; GEMM operands additionally in frag16)
+// ------------------------------------------------------------------------------------------------
+// d(loss)/d(mel, stop) of models.py:58-61: loss = spec_loss + binary_loss, each sum(l * w) / count_nonzero(w broadcast).
+// Writes dY[t][b][M*r + 1] (plain, the tape of the projection's weight gradient).  n_spec / n_bin: device scalars
+// (out3[1] of t2_spec_loss / t2_binary_loss).
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ mel, const float* __restrict__ target,
+                                                        const float* __restrict__ spec_mask, const float* __restrict__ stop,
+                                                        const float* __restrict__ done, const float* __restrict__ bin_mask,
+                                                        const float* __restrict__ n_spec, const float* __restrict__ n_bin,
+                                                        float* __restrict__ dY, int B, int S, int M, int r) {
+    const int N = M * r + 1;
+    const long long n = (long long)S * B * N;
+    const float is = n_spec[0] > 0.f ? 1.0f / n_spec[0] : 0.f, ib = n_bin[0] > 0.f ? 1.0f / n_bin[0] : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % N);
+        const long long tb = i / N;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        float g;
+        if (c < M * r) {
+            const int frame = t * r + c / M;
+            const size_t idx = ((size_t)b * S * r + frame) * M + c % M;
+            const float diff = mel[idx] - target[idx];
+            g = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * spec_mask[(size_t)b * S * r + frame] * is;
+        } else {
+            const float x = stop[(size_t)b * S + t];
+            g = (sigmoidf_(x) - done[(size_t)b * S + t]) * bin_mask[(size_t)b * S + t] * ib;
+        }
+        dY[i] = g;
+    }
+}
+
+// plain [B][K] (row stride ld) -> frag16 operand (rows >= B and k >= K stay zero: buffer zeroed once)
+__global__ __launch_bounds__(256) void plain_to_frag_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int B, int K, int MB) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * K; i += gridDim.x * blockDim.x) {
+        const int row = i / K, k = i - row * K;
+        dst[frag_idx(row, k, MB)] = src[(size_t)row * ld + k];
+    }
+}
+
+// ZoneoutLSTMCell (training branch) backward, one thread per (row, unit).
+//   g_out = g_out0 + g_out1 : gradient of the raw output h
+//   g_hs  = g_hs0 + g_hs1   : gradient of the zoned state h AFTER this step (from step t + 1), null at the last step
+//   g_c                      : gradient of the zoned cell state AFTER this step, in / out (becomes that of step t - 1)
+// Writes dz (plain tape [B][4H] + frag16 operand), g_hp (the part of d/dh_prev that bypasses the cell: (1 - mask_h) g_hs).
+struct LstmBwdArgs {
+    const float *z, *cprev, *cnew;            // tape slices of step t: [B][4H], [B][H], [B][H]
+    const float* g_out0; int ld_out0;
+    const float* g_out1; int ld_out1;
+    const float* g_hs0; int ld_hs0;
+    const float* g_hs1; int ld_hs1;
+    float* g_c;                               // [B][H]
+    float* g_hp;                              // [B][H]
+    float* dz_plain;                          // [B][4H]
+    float* dz_frag;
+    int B, H, MB, t, stream;
+    uint32_t seed;
+    float zc, zh, fb;
+    int first;                                // 1: last time step (no gradient from the future)
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
+    const int n = a.B * a.H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int row = i / a.H, u = i - row * a.H;
+        const float* z = a.z + (size_t)row * 4 * a.H;
+        const float gi = sigmoidf_(z[u]), gj = tanhf(z[a.H + u]), gf = sigmoidf_(z[2 * a.H + u] + a.fb), go = sigmoidf_(z[3 * a.H + u]);
+        const float cp = a.cprev[i], cn = a.cnew[i];
+        const float mc = t2_u01(a.seed, a.stream, a.t, row, u) >= a.zc ? 1.f : 0.f;
+        const float mh = t2_u01(a.seed, a.stream + 1, a.t, row, u) >= a.zh ? 1.f : 0.f;
+        float g_out = 0.f, g_hs = 0.f;
+        if (a.g_out0) g_out += a.g_out0[(size_t)row * a.ld_out0 + u];
+        if (a.g_out1) g_out += a.g_out1[(size_t)row * a.ld_out1 + u];
+        if (!a.first) {
+            if (a.g_hs0) g_hs += a.g_hs0[(size_t)row * a.ld_hs0 + u];
+            if (a.g_hs1) g_hs += a.g_hs1[(size_t)row * a.ld_hs1 + u];
+        }
+        const float g_c = a.first ? 0.f : a.g_c[i];
+        const float tc = tanhf(cn);
+        const float dhn = g_out + mh * g_hs;
+        const float dcn = mc * g_c + dhn * go * (1.f - tc * tc);
+        a.g_c[i] = (1.f - mc) * g_c + dcn * gf;
+        a.g_hp[i] = (1.f - mh) * g_hs;
+        const float dz4[4] = {dcn * gj * gi * (1.f - gi), dcn * gi * (1.f - gj * gj), dcn * cp * gf * (1.f - gf), dhn * tc * go * (1.f - go)};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            a.dz_plain[(size_t)row * 4 * a.H + g * a.H + u] = dz4[g];
+            a.dz_frag[frag_idx(row, g * a.H + u, a.MB)] = dz4[g];
+        }
+    }
+}
+
+// PreNet backward through dropout(relu(.)): y = relu(pre) / keep * mask, so dy/dpre = (y != 0) / keep.
+// g = g0 (row stride ld0); writes plain tape [B][N] and the frag16 operand of the next GEMM.
+__global__ __launch_bounds__(256) void prenet_bwd_kernel(const float* __restrict__ g0, int ld0, const float* __restrict__ y,
+                                                         float inv_keep, float* __restrict__ d_plain, float* __restrict__ d_frag,
+                                                         int B, int N, int MB) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * N; i += gridDim.x * blockDim.x) {
+        const int row = i / N, c = i - row * N;
+        const float v = y[i] != 0.f ? g0[(size_t)row * ld0 + c] * inv_keep : 0.f;
+        d_plain[i] = v;
+        d_frag[frag_idx(row, c, MB)] = v;
+    }
+}
+
+// column sums of a [rows][N] matrix (bias gradients): one thread per column, fixed order
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, long long rows, int N, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    double s = 0.0;
+    for (long long r = 0; r < rows; ++r) s += (double)x[r * N + c];
+    out[c] = (float)s;
+}
+
+// sum over the batch of per-row partial gradients part[b][n] -> out[n]
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ part, int B, long long n, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += part[(size_t)b * n + i];
+        out[i] = s;
+    }
+}
+
+// dmemory = (dvalues + dkeys . Wmem^T is added by a GEMM beforehand) masked by the sequence lengths (values = memory * mask)
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, const int* __restrict__ lens, int B, int T, int E) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)B * T * E; i += (long long)gridDim.x * blockDim.x) {
+        const int pos = (int)((i / E) % T), b = (int)(i / ((long long)E * T));
+        if (pos >= lens[b]) x[i] = 0.f;
+    }
+}
+
+// Location-sensitive attention backward for one step, one workgroup per batch row (reference forward:
+// tacotron_v2.py:118-141).  Recomputes f = conv(state_prev) + b_c, pre = keys + (q + b_a) + f . Wloc, tanh(pre).
+//   in : dctx [B][E] (= d/d context of this step), g_state [B][T] (d/d attention state AFTER this step; in / out)
+//   out: dq [B][U] (plain tape + frag16), dkeys / dvalues accumulators [B][T][.], per-row partial parameter gradients
+struct AttnBwdArgs {
+    const float *keys, *values;               // [B][T][U], [B][T][E]
+    const int* lens;
+    const float *q, *state_prev, *align;      // tape slices of step t: [B][U], [B][T], [B][T]
+    const float* dctx0; int ld_dctx0;         // d context: sum of two sources (LSTM-1 input part, attention-LSTM input of t + 1)
+    const float* dctx1; int ld_dctx1;
+    float* g_state;                           // [B][T]
+    const float *conv_w, *conv_b, *wloc, *v_a;
+    float *dq_plain, *dq_frag;                // [B][U]
+    float *dkeys, *dvalues;                   // [B][T][U], [B][T][E]
+    float *p_convw, *p_convb, *p_wloc, *p_va; // per-row partials [B][K*F], [B][F], [B][F*U], [B][U]
+    int B, T, U, E, F, K, MB, cumulative, first;
+};
+
+#define T2_ABWD_THREADS 256
+__host__ __device__ inline int attn_bwd_lds_floats(int T, int U, int E, int F, int K) {
+    return (T + K + 8) + 4 * (T + 4) + 2 * T * (F + 1) + T * U + F * U + 2 * U + 2 * (T2_ABWD_THREADS / 64) * U + E + 64;
+}
+
+__global__ __launch_bounds__(T2_ABWD_THREADS) void attention_bwd_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = T2_ABWD_THREADS / 64;
+    const int T = a.T, U = a.U, E = a.E, F = a.F, K = a.K, FP = F + 1;
+    const int pad_l = (K - 1) / 2;
+    const int len = a.lens[b];
+    float* s_sp = sm;                         // [T + K + 8]: index i <-> position i - pad_l
+    float* s_a = s_sp + (T + K + 8);          // [T + 4] alignments
+    float* s_da = s_a + (T + 4);              // [T + 4]
+    float* s_de = s_da + (T + 4);             // [T + 4]
+    float* s_ds = s_de + (T + 4);             // [T + 4] d state_prev
+    float* s_f = s_ds + (T + 4);              // [T][FP]
+    float* s_df = s_f + T * FP;               // [T][FP]
+    float* s_du = s_df + T * FP;              // [T][U]
+    float* s_wl = s_du + T * U;               // [F][U]
+    float* s_q = s_wl + F * U;                // [U] q + b_a
+    float* s_v = s_q + U;                     // [U]
+    float* s_dq = s_v + U;                    // [NW][U] per-wave partial sums (summed in wave order: deterministic)
+    float* s_dva = s_dq + NW * U;             // [NW][U]
+    float* s_dctx = s_dva + NW * U;           // [E]
+    float* s_red = s_dctx + E;                // [64]
+    for (int i = tid; i < T + K + 8; i += T2_ABWD_THREADS) {
+        const int p = i - pad_l;
+        s_sp[i] = (p >= 0 && p < T) ? a.state_prev[(size_t)b * T + p] : 0.f;
+    }
+    for (int i = tid; i < T; i += T2_ABWD_THREADS) s_a[i] = a.align[(size_t)b * T + i];
+    for (int i = tid; i < F * U; i += T2_ABWD_THREADS) s_wl[i] = a.wloc[i];
+    for (int i = tid; i < U; i += T2_ABWD_THREADS) { s_q[i] = a.q[(size_t)b * U + i]; s_v[i] = a.v_a[i]; }
+    for (int i = tid; i < E; i += T2_ABWD_THREADS) {
+        float v = 0.f;
+        if (a.dctx0) v += a.dctx0[(size_t)b * a.ld_dctx0 + i];
+        if (a.dctx1) v += a.dctx1[(size_t)b * a.ld_dctx1 + i];
+        s_dctx[i] = v;
+    }
+    __syncthreads();
+    // location features f[j][c] = sum_k w[k][c] * state_prev[j + k - pad_l] + b[c]
+    for (int i = tid; i < T * F; i += T2_ABWD_THREADS) {
+        const int j = i / F, c = i - j * F;
+        float acc = a.conv_b[c];
+        for (int k = 0; k < K; ++k) acc = fmaf(a.conv_w[k * F + c], s_sp[j + k], acc);
+        s_f[j * FP + c] = acc;
+    }
+    // d alignments: da_j = dctx . values[j] + (d state after this step); dvalues[j] += a_j * dctx
+    const float* vals = a.values + (size_t)b * T * E;
+    float* dvals = a.dvalues + (size_t)b * T * E;
+    for (int j = wave; j < T; j += NW) {
+        float acc = 0.f;
+        const float aj = s_a[j];
+        for (int c = lane; c < E; c += 64) {
+            acc = fmaf(s_dctx[c], vals[(size_t)j * E + c], acc);
+            dvals[(size_t)j * E + c] += aj * s_dctx[c];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) s_da[j] = acc + (a.first ? 0.f : a.g_state[(size_t)b * T + j]);
+    }
+    __syncthreads();
+    // softmax backward over the valid positions
+    float part = 0.f;
+    for (int j = tid; j < len; j += T2_ABWD_THREADS) part += s_a[j] * s_da[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    float dot = 0.f;
+    for (int w = 0; w < NW; ++w) dot += s_red[w];
+    for (int j = tid; j < T; j += T2_ABWD_THREADS) s_de[j] = j < len ? s_a[j] * (s_da[j] - dot) : 0.f;
+    __syncthreads();
+    // energies backward: one wave per position, lanes over units
+    const float* keys = a.keys + (size_t)b * T * U;
+    float* dkeys = a.dkeys + (size_t)b * T * U;
+    for (int u0 = 0; u0 < U; u0 += 64) {
+        const int u = u0 + lane;
+        float dq_acc = 0.f, dva_acc = 0.f;
+        for (int j = wave; j < T; j += NW) {
+            float du = 0.f;
+            if (u < U && j < len) {
+                float pre = keys[(size_t)j * U + u] + s_q[u];
+                for (int c = 0; c < F; ++c) pre = fmaf(s_f[j * FP + c], s_wl[c * U + u], pre);
+                const float th = tanhf(pre);
+                const float de = s_de[j];
+                du = de * s_v[u] * (1.f - th * th);
+                dva_acc = fmaf(de, th, dva_acc);
+                dq_acc += du;
+                dkeys[(size_t)j * U + u] += du;
+            }
+            if (u < U) s_du[j * U + u] = du;
+        }
+        if (u < U) { s_dq[wave * U + u] = dq_acc; s_dva[wave * U + u] = dva_acc; }
+    }
+    __syncthreads();
+    // df[j][c] = sum_u du[j][u] * wloc[c][u]
+    for (int i = tid; i < T * F; i += T2_ABWD_THREADS) {
+        const int j = i / F, c = i - j * F;
+        float acc = 0.f;
+        for (int u = 0; u < U; ++u) acc = fmaf(s_du[j * U + u], s_wl[c * U + u], acc);
+        s_df[j * FP + c] = acc;
+    }
+    // d wloc[c][u] += sum_j f[j][c] * du[j][u]
+    float* p_wloc = a.p_wloc + (size_t)b * F * U;
+    for (int i = tid; i < F * U; i += T2_ABWD_THREADS) {
+        const int c = i / U, u = i - c * U;
+        float acc = 0.f;
+        for (int j = 0; j < len; ++j) acc = fmaf(s_f[j * FP + c], s_du[j * U + u], acc);
+        p_wloc[i] += acc;
+    }
+    __syncthreads();
+    // conv backward
+    float* p_convw = a.p_convw + (size_t)b * K * F;
+    for (int i = tid; i < K * F; i += T2_ABWD_THREADS) {
+        const int k = i / F, c = i - k * F;
+        float acc = 0.f;
+        for (int j = 0; j < len; ++j) acc = fmaf(s_sp[j + k], s_df[j * FP + c], acc);
+        p_convw[i] += acc;
+    }
+    for (int c = tid; c < F; c += T2_ABWD_THREADS) {
+        float acc = 0.f;
+        for (int j = 0; j < len; ++j) acc += s_df[j * FP + c];
+        a.p_convb[(size_t)b * F + c] += acc;
+    }
+    for (int i = tid; i < T; i += T2_ABWD_THREADS) {           // d state_prev[i] = sum_{k,c} w[k][c] * df[i - k + pad_l][c]
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const int j = i - k + pad_l;
+            if (j < 0 || j >= len) continue;
+            for (int c = 0; c < F; ++c) acc = fmaf(a.conv_w[k * F + c], s_df[j * FP + c], acc);
+        }
+        s_ds[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < T; i += T2_ABWD_THREADS) {
+        const float carry = (a.cumulative && !a.first) ? a.g_state[(size_t)b * T + i] : 0.f;   // state_t = state_{t-1} + a_t
+        a.g_state[(size_t)b * T + i] = carry + s_ds[i];
+    }
+    for (int u = tid; u < U; u += T2_ABWD_THREADS) {
+        float dq = 0.f, dva = 0.f;
+        for (int w = 0; w < NW; ++w) { dq += s_dq[w * U + u]; dva += s_dva[w * U + u]; }
+        a.dq_plain[(size_t)b * U + u] = dq;
+        a.dq_frag[frag_idx(b, u, a.MB)] = dq;
+        a.p_va[(size_t)b * U + u] += dva;
+    }
+}
+
+
+struct BwdOperand {             // skinny dense operand holding W^T of a TF-layout [rows][cols] variable: K = cols, N = rows
+    Packed p;
+};
+
 struct t2_trainer {
     t2_model* m = nullptr;
     int B = 0, T = 0, S = 0;
@@ -11,13 +314,43 @@ struct t2_trainer {
     TrainTape tape{};
     t2_state* state = nullptr;          // decoder state + staging owned by the trainer (never evicted by other decodes)
     bool have_forward = false;
+    // backward pass
+    std::vector<void*> allocs;
+    Packed projT, lstmT[3], wqT, prenetT[T2_MAX_PRENET_LAYERS];
+    float* wmemT = nullptr;             // [U][E] memory layer transposed (plain)
+    void* bslab = nullptr; size_t bslab_bytes = 0;
+    float *dY = nullptr, *dYf = nullptr, *dz[3] = {}, *dzf[3] = {}, *dq = nullptr, *dqf = nullptr;
+    float *dpre[T2_MAX_PRENET_LAYERS] = {}, *dpref[T2_MAX_PRENET_LAYERS] = {}, *xin = nullptr;
+    float *dX[3] = {}, *dy2 = nullptr, *dhq = nullptr, *dxp = nullptr;
+    float *g_c[3] = {}, *g_hp[3] = {}, *g_state = nullptr;
+    float *dkeys = nullptr, *dvalues = nullptr, *p_convw = nullptr, *p_convb = nullptr, *p_wloc = nullptr, *p_va = nullptr;
+    float *tmp = nullptr, *loss3 = nullptr;
+    std::map<std::string, long long> offsets;      // flat-gradient layout given by the caller
 };
+
+static int trainer_pack_T(t2_trainer* tr, Packed* out, const std::string& name, int rows, int cols, int col0, int ncols) {
+    // W^T of the column range [col0, col0 + ncols) of variable `name` ([rows][cols]) as a skinny dense operand:
+    // reduction over the ncols source columns, one output column per source row
+    t2_model* m = tr->m;
+    const HostWeight* w;
+    T2_TRY(get_w(m, name, &w, {rows, cols}));
+    std::vector<float> t((size_t)ncols * rows);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < ncols; ++c) t[(size_t)c * rows + r] = w->data[(size_t)r * cols + col0 + c];
+    const size_t before = m->allocs.size();
+    T2_TRY(pack_skinny(m, out, t.data(), rows, {{0, ncols}}, 0, rows, nullptr));
+    for (size_t i = before; i < m->allocs.size(); ++i) tr->allocs.push_back(m->allocs[i]);     // owned by the trainer
+    m->allocs.resize(before);
+    return T2_OK;
+}
 
 extern "C" int t2_trainer_destroy(t2_trainer* tr) {
     if (!tr) return T2_OK;
     (void)hipSetDevice(tr->m->ctx->device);
     (void)hipStreamSynchronize(tr->m->ctx->stream);
     if (tr->slab) (void)hipFree(tr->slab);
+    if (tr->bslab) (void)hipFree(tr->bslab);
+    for (void* p : tr->allocs) (void)hipFree(p);
     if (tr->state) state_free(tr->state);
     delete tr;
     return T2_OK;
@@ -89,5 +422,297 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(align, s->o_hist, (size_t)S * B * T_in * 4, hipMemcpyDeviceToDevice, st));
     tr->have_forward = true;
+    return T2_OK;
+}
+
+// ---- backward pass -------------------------------------------------------------------------------------------------------
+static int trainer_setup_backward(t2_trainer* tr) {
+    t2_model* m = tr->m;
+    const t2_dims& d = m->d;
+    const int B = tr->B, T = tr->T, S = tr->S, MB = mb_for(B), R = MB * 16;
+    const int E = d.enc_units, U = d.attention_dim, A = d.attention_lstm_units, D = d.decoder_lstm_units;
+    const int M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame, np = d.num_prenet_layers, N = M * r + 1;
+    const int P_last = d.prenet_units[np - 1];
+    // transposed operands of the per-step data-gradient GEMMs
+    {
+        const HostWeight *wm, *ws;
+        T2_TRY(get_w(m, "decoder/out_projection/kernel", &wm, {D, M * r}));
+        T2_TRY(get_w(m, "decoder/stop_token_projection/kernel", &ws, {D, 1}));
+        std::vector<float> t((size_t)N * D);
+        for (int k = 0; k < D; ++k) {
+            for (int c = 0; c < M * r; ++c) t[(size_t)c * D + k] = wm->data[(size_t)k * M * r + c];
+            t[(size_t)(M * r) * D + k] = ws->data[k];
+        }
+        const size_t before = m->allocs.size();
+        T2_TRY(pack_skinny(m, &tr->projT, t.data(), D, {{0, N}}, 0, D, nullptr));
+        for (size_t i = before; i < m->allocs.size(); ++i) tr->allocs.push_back(m->allocs[i]);
+        m->allocs.resize(before);
+    }
+    T2_TRY(trainer_pack_T(tr, &tr->lstmT[0], "decoder/attention_lstm/kernel", P_last + E + A, 4 * A, 0, 4 * A));
+    T2_TRY(trainer_pack_T(tr, &tr->lstmT[1], "decoder/lstm_1/kernel", A + E + D, 4 * D, 0, 4 * D));
+    T2_TRY(trainer_pack_T(tr, &tr->lstmT[2], "decoder/lstm_2/kernel", D + D, 4 * D, 0, 4 * D));
+    T2_TRY(trainer_pack_T(tr, &tr->wqT, "attention/query_layer/kernel", A, U, 0, U));
+    for (int i = 1; i < np; ++i)
+        T2_TRY(trainer_pack_T(tr, &tr->prenetT[i], "decoder/prenet_" + std::to_string(i) + "/dense/kernel", d.prenet_units[i - 1],
+                              d.prenet_units[i], 0, d.prenet_units[i]));
+    {
+        const HostWeight* w;
+        T2_TRY(get_w(m, "attention/memory_layer/kernel", &w, {E, U}));
+        std::vector<float> t((size_t)U * E);
+        for (int e = 0; e < E; ++e) for (int u = 0; u < U; ++u) t[(size_t)u * E + e] = w->data[(size_t)e * U + u];
+        HIP_TRY(hipMalloc((void**)&tr->wmemT, t.size() * 4));
+        tr->allocs.push_back(tr->wmemT);
+        HIP_TRY(hipMemcpy(tr->wmemT, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
+    // workspaces
+    const int H[3] = {A, D, D};
+    const int KX[3] = {P_last + E + A, A + E + D, D + D};
+    const size_t SB = (size_t)S * B;
+    size_t off = 0;
+    auto carve = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
+    const size_t o_dY = carve(SB * N), o_dYf = carve((size_t)R * pad16(N));
+    size_t o_dz[3], o_dzf[3], o_dX[3], o_gc[3], o_ghp[3], o_dpre[T2_MAX_PRENET_LAYERS], o_dpref[T2_MAX_PRENET_LAYERS];
+    for (int l = 0; l < 3; ++l) {
+        o_dz[l] = carve(SB * 4 * H[l]); o_dzf[l] = carve((size_t)R * pad16(4 * H[l])); o_dX[l] = carve((size_t)B * KX[l]);
+        o_gc[l] = carve((size_t)B * H[l]); o_ghp[l] = carve((size_t)B * H[l]);
+    }
+    const size_t o_dq = carve(SB * U), o_dqf = carve((size_t)R * pad16(U));
+    int pmax = 0;
+    for (int i = 0; i < np; ++i) { o_dpre[i] = carve(SB * d.prenet_units[i]); o_dpref[i] = carve((size_t)R * pad16(d.prenet_units[i])); pmax = std::max(pmax, d.prenet_units[i]); }
+    const size_t o_xin = carve(SB * M * nf), o_dy2 = carve((size_t)B * D), o_dhq = carve((size_t)B * A), o_dxp = carve((size_t)B * pmax);
+    const size_t o_gs = carve((size_t)B * T), o_dk = carve((size_t)B * T * U), o_dv = carve((size_t)B * T * E);
+    const size_t o_pcw = carve((size_t)B * d.attention_kernel * d.attention_filters), o_pcb = carve((size_t)B * d.attention_filters),
+                 o_pwl = carve((size_t)B * d.attention_filters * U), o_pva = carve((size_t)B * U);
+    const size_t o_tmp = carve((size_t)std::max(D * N, 4096)), o_loss = carve(16);
+    tr->bslab_bytes = off;
+    HIP_TRY(hipMalloc(&tr->bslab, off));
+    char* p = (char*)tr->bslab;
+    tr->dY = (float*)(p + o_dY); tr->dYf = (float*)(p + o_dYf);
+    for (int l = 0; l < 3; ++l) {
+        tr->dz[l] = (float*)(p + o_dz[l]); tr->dzf[l] = (float*)(p + o_dzf[l]); tr->dX[l] = (float*)(p + o_dX[l]);
+        tr->g_c[l] = (float*)(p + o_gc[l]); tr->g_hp[l] = (float*)(p + o_ghp[l]);
+    }
+    tr->dq = (float*)(p + o_dq); tr->dqf = (float*)(p + o_dqf);
+    for (int i = 0; i < np; ++i) { tr->dpre[i] = (float*)(p + o_dpre[i]); tr->dpref[i] = (float*)(p + o_dpref[i]); }
+    tr->xin = (float*)(p + o_xin); tr->dy2 = (float*)(p + o_dy2); tr->dhq = (float*)(p + o_dhq); tr->dxp = (float*)(p + o_dxp);
+    tr->g_state = (float*)(p + o_gs); tr->dkeys = (float*)(p + o_dk); tr->dvalues = (float*)(p + o_dv);
+    tr->p_convw = (float*)(p + o_pcw); tr->p_convb = (float*)(p + o_pcb); tr->p_wloc = (float*)(p + o_pwl); tr->p_va = (float*)(p + o_pva);
+    tr->tmp = (float*)(p + o_tmp); tr->loss3 = (float*)(p + o_loss);
+    const size_t lds = (size_t)attn_bwd_lds_floats(T, U, E, d.attention_filters, d.attention_kernel) * 4;
+    if (lds > 150 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention backward kernel's LDS", T);
+    HIP_TRY(hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    return T2_OK;
+}
+
+extern "C" int t2_trainer_bind_gradient(t2_trainer* tr, const char* name, int64_t offset) {
+    if (!tr || !name || offset < 0 || (offset & 3) != 0) return fail(T2_EINVAL, "bad argument (offsets are multiples of 4 floats)");
+    tr->offsets[name] = offset;
+    return T2_OK;
+}
+
+// y[B][N] = x_frag[B][K] . W^T through the skinny dense kernel (no control block: t = 0)
+static void bwd_dense(t2_trainer* tr, const Packed& wT, float* x_frag, float* y, int N) {
+    const int MB = mb_for(tr->B);
+    SkinnyCore c{};
+    c.w[0] = c.w[1] = wT.w; c.bias[0] = c.bias[1] = nullptr;
+    c.kb0 = 0; c.kbtot = wT.kbtot; c.kb_w0 = 0; c.kb_full = wT.kbtot; c.ctl = nullptr; c.step_off = 0; c.t_hint = 0; c.B = tr->B;
+    c.seg[0][1] = FragBuf{x_frag, 0, 1, 0, 0};
+    DenseEpi e{};
+    e.N = N; e.out_frag = FragBuf{nullptr, 0, 1, 0, 0}; e.out_plain = y; e.plain_ld = N; e.plain_t_stride = 0; e.plain_ncol = N; e.stop_col = -1;
+    launch_dense(MB, dim3(wT.n_wg), tr->m->ctx->stream, c, e);
+}
+
+// dst[rows][ncols] (row stride ldd) = A^T . Bm with A [red][lda] (rows columns used), Bm [red][ldb]: weight gradients
+static int bwd_wgrad(t2_trainer* tr, const float* A, int lda, int rows, const float* Bm, int ldb, int ncols, long long red, float* dst, int ldd) {
+    ConvArgs a{};
+    a.x = A; a.ldx = lda; a.w = Bm; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.ldr = 0; a.y = dst; a.ldy = ldd;
+    a.Mtot = rows; a.T = rows; a.Cin = (int)red; a.N = ncols; a.ktaps = 1; a.pad_l = 0; a.act = 0; a.trans_a = 1;
+    a.vec_a = 0;
+    a.vec_b = (ncols % 4 == 0) && (ldb == ncols) && (((uintptr_t)Bm) % 16 == 0);
+    if (ldb != ncols) return fail(T2_EINVAL, "internal: wgrad right operand must be dense");
+    dim3 grid(ceil_div(ncols, CG_BN), ceil_div(rows, CG_BM));
+    hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, tr->m->ctx->stream, a);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+static int grad_dst(t2_trainer* tr, float* flat, const std::string& name, float** out) {
+    auto it = tr->offsets.find(name);
+    if (it == tr->offsets.end()) return fail(T2_ESTATE, "no gradient offset bound for '%s' (t2_trainer_bind_gradient)", name.c_str());
+    *out = flat + it->second;
+    return T2_OK;
+}
+
+// Backward of t2_train_decoder_forward + the two losses of models.py:58-61.  done / bin_mask dev [B][S], spec_mask dev
+// [B][S*r].  Writes the gradient of every decoder / attention variable into flat_grads at the bound offsets (TF layouts),
+// d(loss)/d(memory) into dmemory [B][T_in][E] and {mel_loss, done_loss, loss} into loss_out (dev [3]).
+extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, const float* spec_mask, const float* bin_mask,
+                                         float* flat_grads, float* dmemory, float* loss_out) {
+    if (!tr || !done || !spec_mask || !bin_mask || !flat_grads || !dmemory || !loss_out) return fail(T2_EINVAL, "null argument");
+    if (!tr->have_forward) return fail(T2_ESTATE, "t2_train_decoder_forward has not run");
+    t2_model* m = tr->m;
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    if (!tr->bslab) T2_TRY(trainer_setup_backward(tr));
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    t2_state* s = tr->state;
+    const TrainTape& tp = tr->tape;
+    const int B = tr->B, T = tr->T, S = tr->S, MB = mb_for(B);
+    const int E = d.enc_units, U = d.attention_dim, A = d.attention_lstm_units, D = d.decoder_lstm_units;
+    const int M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame, np = d.num_prenet_layers, N = M * r + 1;
+    const int F = d.attention_filters, K = d.attention_kernel;
+    const int P_last = d.prenet_units[np - 1];
+    const int H[3] = {A, D, D};
+    const int KX[3] = {P_last + E + A, A + E + D, D + D};
+    const int stream_of[3] = {T2_STREAM_ZONE_ATT, T2_STREAM_ZONE_L1, T2_STREAM_ZONE_L2};
+    const size_t SB = (size_t)S * B;
+    HIP_TRY(hipMemsetAsync(tr->bslab, 0, tr->bslab_bytes, st));
+    // losses (T1, T2) and their gradients
+    float* l3 = tr->loss3;
+    T2_TRY(t2_spec_loss(m->ctx, s->o_mel, s->i_targets, spec_mask, B, S * r, M, l3));
+    T2_TRY(t2_binary_loss(m->ctx, s->o_stop, done, bin_mask, B, S, l3 + 4));
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(std::min<long long>(2048, (SB * N + 255) / 256)), dim3(256), 0, st, s->o_mel, s->i_targets,
+                       spec_mask, s->o_stop, done, bin_mask, l3 + 1, l3 + 5, tr->dY, B, S, M, r);
+    auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (n + 255) / 256))); };
+    const size_t lds = (size_t)attn_bwd_lds_floats(T, U, E, F, K) * 4;
+    for (int t = S - 1; t >= 0; --t) {
+        const int first = (t == S - 1) ? 1 : 0;
+        auto lstm_bwd = [&](int l, const float* go0, int ld0, const float* go1, int ld1, const float* gh1, int ldh1) {
+            LstmBwdArgs a{};
+            a.z = tp.z[l] + (size_t)t * B * 4 * H[l]; a.cprev = tp.cprev[l] + (size_t)t * B * H[l]; a.cnew = tp.cnew[l] + (size_t)t * B * H[l];
+            a.g_out0 = go0; a.ld_out0 = ld0; a.g_out1 = go1; a.ld_out1 = ld1;
+            a.g_hs0 = tr->g_hp[l]; a.ld_hs0 = H[l]; a.g_hs1 = gh1; a.ld_hs1 = ldh1;
+            a.g_c = tr->g_c[l]; a.g_hp = tr->g_hp[l];
+            a.dz_plain = tr->dz[l] + (size_t)t * B * 4 * H[l]; a.dz_frag = tr->dzf[l];
+            a.B = B; a.H = H[l]; a.MB = MB; a.t = t; a.stream = stream_of[l]; a.seed = tp.seed;
+            a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias; a.first = first;
+            hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * H[l]), dim3(256), 0, st, a);
+        };
+        // projections
+        hipLaunchKernelGGL(plain_to_frag_kernel, grid1((long long)B * N), dim3(256), 0, st, tr->dY + (size_t)t * B * N, N, tr->dYf, B, N, MB);
+        bwd_dense(tr, tr->projT, tr->dYf, tr->dy2, D);
+        // LSTM 2: input [y1 | h2_prev]
+        lstm_bwd(2, tr->dy2, D, nullptr, 0, tr->dX[2] + D, KX[2]);
+        bwd_dense(tr, tr->lstmT[2], tr->dzf[2], tr->dX[2], KX[2]);
+        // LSTM 1: input [h_att | ctx | h1_prev]
+        lstm_bwd(1, tr->dX[2], KX[2], nullptr, 0, tr->dX[1] + A + E, KX[1]);
+        bwd_dense(tr, tr->lstmT[1], tr->dzf[1], tr->dX[1], KX[1]);
+        // attention
+        {
+            AttnBwdArgs a{};
+            a.keys = s->keys; a.values = s->values; a.lens = s->lens;
+            a.q = tp.q + (size_t)t * B * U; a.state_prev = tp.state_prev + (size_t)t * B * T; a.align = s->o_hist + (size_t)t * B * T;
+            a.dctx0 = tr->dX[1] + A; a.ld_dctx0 = KX[1];
+            a.dctx1 = first ? nullptr : tr->dX[0] + P_last; a.ld_dctx1 = KX[0];
+            a.g_state = tr->g_state; a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a;
+            a.dq_plain = tr->dq + (size_t)t * B * U; a.dq_frag = tr->dqf; a.dkeys = tr->dkeys; a.dvalues = tr->dvalues;
+            a.p_convw = tr->p_convw; a.p_convb = tr->p_convb; a.p_wloc = tr->p_wloc; a.p_va = tr->p_va;
+            a.B = B; a.T = T; a.U = U; a.E = E; a.F = F; a.K = K; a.MB = MB; a.cumulative = d.cumulative_weights; a.first = first;
+            hipLaunchKernelGGL(attention_bwd_kernel, dim3(B), dim3(T2_ABWD_THREADS), lds, st, a);
+        }
+        bwd_dense(tr, tr->wqT, tr->dqf, tr->dhq, A);
+        // attention LSTM: input [prenet out | ctx_prev | h_att_prev]; raw output feeds LSTM 1 and the query layer
+        lstm_bwd(0, tr->dX[1], KX[1], tr->dhq, A, tr->dX[0] + P_last + E, KX[0]);
+        bwd_dense(tr, tr->lstmT[0], tr->dzf[0], tr->dX[0], KX[0]);
+        // PreNets
+        const float inv_keep = 1.0f / (1.0f - tp.prenet_drop_rate);
+        const float* g = tr->dX[0];
+        int ldg = KX[0];
+        for (int i = np - 1; i >= 0; --i) {
+            const int P = d.prenet_units[i];
+            hipLaunchKernelGGL(prenet_bwd_kernel, grid1((long long)B * P), dim3(256), 0, st, g, ldg, tp.xp[i] + (size_t)t * B * P, inv_keep,
+                               tr->dpre[i] + (size_t)t * B * P, tr->dpref[i], B, P, MB);
+            if (i > 0) {
+                bwd_dense(tr, tr->prenetT[i], tr->dpref[i], tr->dxp, d.prenet_units[i - 1]);
+                g = tr->dxp; ldg = d.prenet_units[i - 1];
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    // ---- weight gradients: one GEMM per K segment over all S*B rows of the tape
+    float* g = nullptr;
+    const long long rows1 = (long long)(S - 1) * B;
+    {   // projections
+        T2_TRY(bwd_wgrad(tr, tp.hraw[2], D, D, tr->dY, N, N, SB, tr->tmp, N));
+        T2_TRY(grad_dst(tr, flat_grads, "decoder/out_projection/kernel", &g));
+        HIP_TRY(hipMemcpy2DAsync(g, (size_t)M * r * 4, tr->tmp, (size_t)N * 4, (size_t)M * r * 4, D, hipMemcpyDeviceToDevice, st));
+        T2_TRY(grad_dst(tr, flat_grads, "decoder/stop_token_projection/kernel", &g));
+        HIP_TRY(hipMemcpy2DAsync(g, 4, tr->tmp + M * r, (size_t)N * 4, 4, D, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, tr->dY, (long long)SB, N, tr->dYf);
+        T2_TRY(grad_dst(tr, flat_grads, "decoder/out_projection/bias", &g));
+        HIP_TRY(hipMemcpyAsync(g, tr->dYf, (size_t)M * r * 4, hipMemcpyDeviceToDevice, st));
+        T2_TRY(grad_dst(tr, flat_grads, "decoder/stop_token_projection/bias", &g));
+        HIP_TRY(hipMemcpyAsync(g, tr->dYf + M * r, 4, hipMemcpyDeviceToDevice, st));
+    }
+    const char* lname[3] = {"decoder/attention_lstm", "decoder/lstm_1", "decoder/lstm_2"};
+    for (int l = 0; l < 3; ++l) {
+        const int n4 = 4 * H[l];
+        T2_TRY(grad_dst(tr, flat_grads, std::string(lname[l]) + "/kernel", &g));
+        const float* dz = tr->dz[l];
+        const float* dz1 = dz + (size_t)B * n4;            // rows of steps 1 .. S-1 (operands taken from step t - 1)
+        if (l == 0) {
+            T2_TRY(bwd_wgrad(tr, tp.xp[np - 1], P_last, P_last, dz, n4, n4, SB, g, n4));
+            if (S > 1) {
+                T2_TRY(bwd_wgrad(tr, tp.ctx, E, E, dz1, n4, n4, rows1, g + (size_t)P_last * n4, n4));
+                T2_TRY(bwd_wgrad(tr, tp.hstate[0], A, A, dz1, n4, n4, rows1, g + (size_t)(P_last + E) * n4, n4));
+            }
+        } else if (l == 1) {
+            T2_TRY(bwd_wgrad(tr, tp.hraw[0], A, A, dz, n4, n4, SB, g, n4));
+            T2_TRY(bwd_wgrad(tr, tp.ctx, E, E, dz, n4, n4, SB, g + (size_t)A * n4, n4));
+            if (S > 1) T2_TRY(bwd_wgrad(tr, tp.hstate[1], D, D, dz1, n4, n4, rows1, g + (size_t)(A + E) * n4, n4));
+        } else {
+            T2_TRY(bwd_wgrad(tr, tp.hraw[1], D, D, dz, n4, n4, SB, g, n4));
+            if (S > 1) T2_TRY(bwd_wgrad(tr, tp.hstate[2], D, D, dz1, n4, n4, rows1, g + (size_t)D * n4, n4));
+        }
+        T2_TRY(grad_dst(tr, flat_grads, std::string(lname[l]) + "/bias", &g));
+        hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, st, dz, (long long)SB, n4, g);
+    }
+    // query layer, attention parameters
+    T2_TRY(grad_dst(tr, flat_grads, "attention/query_layer/kernel", &g));
+    T2_TRY(bwd_wgrad(tr, tp.hraw[0], A, A, tr->dq, U, U, SB, g, U));
+    T2_TRY(grad_dst(tr, flat_grads, "attention/attention_bias", &g));
+    hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(U, 256)), dim3(256), 0, st, tr->dq, (long long)SB, U, g);
+    T2_TRY(grad_dst(tr, flat_grads, "attention/attention_variable", &g));
+    hipLaunchKernelGGL(batch_sum_kernel, grid1(U), dim3(256), 0, st, tr->p_va, B, (long long)U, g);
+    T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/kernel", &g));
+    hipLaunchKernelGGL(batch_sum_kernel, grid1(K * F), dim3(256), 0, st, tr->p_convw, B, (long long)K * F, g);
+    T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/bias", &g));
+    hipLaunchKernelGGL(batch_sum_kernel, grid1(F), dim3(256), 0, st, tr->p_convb, B, (long long)F, g);
+    T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_layer/kernel", &g));
+    hipLaunchKernelGGL(batch_sum_kernel, grid1(F * U), dim3(256), 0, st, tr->p_wloc, B, (long long)F * U, g);
+    // PreNets: inputs of layer 0 are the teacher-forced frames (go frame at t = 0)
+    {
+        FeedArgs f{};
+        (void)f;
+        // xin[t][b][:] = targets[b][t - 1][-M*nf:]  (t >= 1); zeros at t = 0 (buffer zeroed above)
+        for (int t = 1; t < S; ++t)
+            HIP_TRY(hipMemcpy2DAsync(tr->xin + (size_t)t * B * M * nf, (size_t)M * nf * 4,
+                                     s->i_targets + (size_t)(t - 1) * r * M + (size_t)M * (r - nf), (size_t)S * r * M * 4,
+                                     (size_t)M * nf * 4, B, hipMemcpyDeviceToDevice, st));
+    }
+    for (int i = 0; i < np; ++i) {
+        const int P = d.prenet_units[i];
+        const int Kin = i == 0 ? M * nf : d.prenet_units[i - 1];
+        const float* x = i == 0 ? tr->xin : tp.xp[i - 1];
+        const std::string pn = "decoder/prenet_" + std::to_string(i) + "/dense";
+        T2_TRY(grad_dst(tr, flat_grads, pn + "/kernel", &g));
+        T2_TRY(bwd_wgrad(tr, x, Kin, Kin, tr->dpre[i], P, P, SB, g, P));
+        T2_TRY(grad_dst(tr, flat_grads, pn + "/bias", &g));
+        hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, tr->dpre[i], (long long)SB, P, g);
+    }
+    // memory layer and d(memory): keys = values . Wmem, values = memory * mask
+    T2_TRY(grad_dst(tr, flat_grads, "attention/memory_layer/kernel", &g));
+    T2_TRY(bwd_wgrad(tr, s->values, E, E, tr->dkeys, U, U, (long long)B * T, g, U));
+    {
+        ConvLayer L;
+        L.w = tr->wmemT; L.k = 1; L.cin = U; L.cout = E;
+        T2_TRY(launch_conv(m, L, tr->dkeys, U, dmemory, E, B * T, B * T, 0, tr->dvalues, E));
+        hipLaunchKernelGGL(mask_rows_kernel, grid1((long long)B * T * E), dim3(256), 0, st, dmemory, s->lens, B, T, E);
+    }
+    // {mel_loss, done_loss, loss}
+    HIP_TRY(hipMemcpyAsync(loss_out, l3 + 2, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(loss_out + 1, l3 + 6, 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(batch_sum_kernel, dim3(1), dim3(256), 0, st, loss_out, 2, 1LL, loss_out + 2);
+    HIP_TRY(hipGetLastError());
     return T2_OK;
 }

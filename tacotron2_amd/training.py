@@ -217,6 +217,28 @@ class Trainer:
                                                         mel.data_ptr(), stop.data_ptr(), align.data_ptr()))
         return mel, stop.unsqueeze(-1), align
 
+    def bind_gradients(self, spec):
+        """spec: training.flatten_spec(weights) -- where each variable's gradient goes in the flat buffer."""
+        self._spec = spec
+        for name, shape, off, size in spec:
+            _lib.check(self.engine.lib.t2_trainer_bind_gradient(self._h, name.encode(), int(off)))
+
+    def decoder_backward(self, done, spec_loss_mask, binary_loss_mask, flat_grads: torch.Tensor):
+        """BPTT of the last decoder_forward through loss = spec_loss(mel) + binary_loss(stop) (models.py:58-61).
+        Fills the decoder/ and attention/ slices of flat_grads; returns (dmemory [B, T_in, E], losses dev [3] = mel, done, total)."""
+        eng, d = self.engine, self.engine.dims
+        done, m1, m2 = eng._f32(done), eng._f32(spec_loss_mask), eng._f32(binary_loss_mask)
+        if tuple(done.shape) != (self.B, self.S) or tuple(m2.shape) != (self.B, self.S) or tuple(m1.shape) != (self.B, self.S * d.outputs_per_step):
+            raise ValueError("label shapes do not match the trainer's (B, S)")
+        if not (flat_grads.is_cuda and flat_grads.dtype == torch.float32 and flat_grads.is_contiguous()):
+            raise ValueError("flat_grads must be a contiguous fp32 device tensor")
+        dmem = torch.empty((self.B, self.T_in, d.enc_units), dtype=torch.float32, device=eng.device)
+        losses = torch.empty(3, dtype=torch.float32, device=eng.device)
+        with eng._ordered():
+            _lib.check(eng.lib.t2_train_decoder_backward(self._h, done.data_ptr(), m1.data_ptr(), m2.data_ptr(), flat_grads.data_ptr(),
+                                                         dmem.data_ptr(), losses.data_ptr()))
+        return dmem, losses
+
     def close(self):
         if getattr(self, "_h", None) and getattr(self.engine, "_model", None):
             self.engine.lib.t2_trainer_destroy(self._h)

@@ -52,3 +52,48 @@ def test_training_mode_decoder_forward(d, B, T, S, hoist):
     assert bool((mel2 == mel).all())
     tr.close()
     eng.close()
+
+
+def _labels(rng, B, S, r):
+    tl = rng.integers(max(2, S * r // 2), S * r + 1, size=B)
+    tl[0] = S * r
+    sl = (tl + r - 1) // r
+    return {"done": (np.arange(S)[None, :] >= (sl[:, None] - 1)).astype(np.float32),
+            "spec_loss_mask": (np.arange(S * r)[None, :] < tl[:, None]).astype(np.float32),
+            "binary_loss_mask": (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)}
+
+
+@pytest.mark.parametrize("d,B,T,S", [(PROFILE_TINY, 3, 7, 5), (MID, 4, 13, 6), (MID, 18, 9, 4)])
+def test_decoder_backward_against_autograd(d, B, T, S):
+    """BPTT through the training-mode decoder: every decoder/ and attention/ gradient and d loss / d memory against
+    torch.autograd on the float64 restatement with the same sampled masks."""
+    import torch
+    from oracle import torch_train as TT
+    from tacotron2_amd import training as TR
+    w, eng, memory, lens, target = _setup(d, B, T, S, 8)
+    rng = np.random.default_rng(1)
+    labels = _labels(rng, B, S, d.outputs_per_step)
+    labels["mel"] = target
+    ref = TT.train_forward_backward(d, w, None, lens, labels, seed=21, prenet_drop_rate=0.5, decoder_only_memory=memory)
+    tr = TR.Trainer(eng, B, T, S)
+    spec = TR.flatten_spec(w)
+    tr.bind_gradients(spec)
+    mel, stop, align = tr.decoder_forward(memory, lens, target, prenet_drop_rate=0.5, seed=21)
+    np.testing.assert_allclose(_np(mel), ref["mel"], atol=1e-3)
+    flat = torch.zeros(TR.flat_size(spec), dtype=torch.float32, device="cuda")
+    dmem, losses = tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat)
+    np.testing.assert_allclose(_np(losses), [ref["mel_loss"], ref["done_loss"], ref["loss"]], rtol=1e-4, atol=1e-6)
+    grads = TR.unflatten(flat, spec)
+    bad = []
+    for name, g_ref in sorted(ref["grads"].items()):
+        if not (name.startswith("decoder/") or name.startswith("attention/")):
+            continue
+        scale = float(np.abs(g_ref).max())
+        err = float(np.abs(grads[name] - g_ref).max())
+        if err > 1e-3 * scale + 1e-6:
+            bad.append((name, err, scale))
+    assert not bad, bad
+    g_ref = ref["grads"]["memory"]
+    assert float(np.abs(_np(dmem) - g_ref).max()) <= 1e-3 * float(np.abs(g_ref).max()) + 1e-6
+    tr.close()
+    eng.close()
