@@ -184,7 +184,7 @@ int t2_optim_set_state(t2_optim* o, const float* m_in, const float* v_in, int64_
 
 /* ---- training step of the V2 path (BASELINE.json configs[3]) ---------------------------------------------------------
  * A trainer owns the tape of one (B, T_in, S = T_out / r) teacher-forced training forward and the workspaces of the
- * backward pass.  Sampled paths (dropout, zoneout) draw from the counter-based generator t2_u01 (csrc/kernels.h) keyed by
+ * backward pass.  Sampled paths (dropout, zoneout) draw from the counter-based generator of csrc/kernels.h (function t2_u01) keyed by
  * `seed`: TensorFlow's stateful random streams cannot be reproduced, the arithmetic around the masks is TF's. */
 typedef struct t2_trainer t2_trainer;
 int t2_trainer_create(t2_model* m, int B, int T_in, int S, t2_trainer** out);
