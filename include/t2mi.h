@@ -195,6 +195,13 @@ int t2_trainer_destroy(t2_trainer* tr);
 int t2_train_decoder_forward(t2_trainer* tr, const float* memory, const int64_t* lens, const float* targets,
                              float prenet_drop_rate, uint32_t seed, float* mel, float* stop, float* align);
 
+/* Embedding.call + EncoderV2.call with is_training = True (tacotron_v2.py:53-63; Conv1d.call modules.py:149-157): every conv
+ * layer normalises with the batch statistics of all B*T_in positions (padding included), then relu, then dropout(drop_rate);
+ * the BiLSTM runs ZoneoutLSTMCell's training branch with sequence lengths.  ids host int64 [B,T_in]; memory_out dev
+ * [B,T_in,enc_units]; bn_stats_out dev (may be NULL): per conv layer [batch mean | biased batch variance], 2*enc_units floats
+ * each -- the moving-statistics update of the step (models.py:75) is moving = 0.99*moving + 0.01*batch on the caller's side. */
+int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, const int64_t* lens, float drop_rate, uint32_t seed,
+                             float* memory_out, float* bn_stats_out);
 /* Where the gradient of variable `name` (TF layout) goes in the caller's flat gradient buffer (floats, multiple of 4). */
 int t2_trainer_bind_gradient(t2_trainer* tr, const char* name, int64_t offset);
 /* Backward of t2_train_decoder_forward through the losses of model_fn (tacotron/models.py:58-61: spec_loss(mel) +

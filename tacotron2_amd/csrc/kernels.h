@@ -390,17 +390,18 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
                 cs = (1.0f - e.zc) * dropout_train(cn - cp, e.zc, t2_u01(e.seed, e.stream + 2 * dir, t, row, unit)) + cp;
                 hs = (1.0f - e.zh) * dropout_train(hn - hp, e.zh, t2_u01(e.seed, e.stream + 2 * dir + 1, t, row, unit)) + hp;
             }
+            bool live = true;
+            if (e.lens != nullptr) {
+                live = t < len;
+                if (!live) { cs = cp; hs = hp; hn = 0.f; }   // dynamic_rnn: zero output, state copied through
+            }
             if (e.tp_z != nullptr) {
                 const size_t ti = ((size_t)t * a.B + row);
                 float* tz = e.tp_z + ti * 4 * e.H;
                 tz[unit] = zi; tz[e.H + unit] = zj; tz[2 * e.H + unit] = zf; tz[3 * e.H + unit] = zo;
                 e.tp_cprev[ti * e.H + unit] = cp; e.tp_cnew[ti * e.H + unit] = cn;
-                e.tp_hraw[ti * e.H + unit] = hn; e.tp_hstate[ti * e.H + unit] = hs;
-            }
-            bool live = true;
-            if (e.lens != nullptr) {
-                live = t < len;
-                if (!live) { cs = cp; hs = hp; hn = 0.f; }   // dynamic_rnn: zero output, state copied through
+                if (e.tp_hraw != nullptr) e.tp_hraw[ti * e.H + unit] = hn;
+                e.tp_hstate[ti * e.H + unit] = hs;
             }
             e.c[dir][(size_t)row * e.Hld + unit] = cs;
             frag_slot(e.hstate[dir], t)[frag_idx(row, e.hstate[dir].koff + unit, MB)] = hs;
@@ -1227,7 +1228,9 @@ struct ConvArgs {
     int Mtot, T, Cin, N, ktaps, pad_l;
     int act;                       // 0 none, 1 relu, 2 tanh
     int vec_a, vec_b;              // float4 paths usable
-    int trans_a;                   // 1 (ktaps = 1 only): A element (m, k) is x[k * ldx + m] -- weight gradients X^T . dZ
+    int trans_a;                   // 1: weight gradient dW = im2col(X)^T . dY: output row mo = (tap j, channel i) of ktaps*Cin rows,
+                                   //    reduction over the `red` rows rr of X / dY (w = dY [red][N]); element = X[rr + j - pad_l][i] within the utterance
+    int red;
 };
 
 #define CG_BM 128
@@ -1241,7 +1244,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * CG_BM, n0 = blockIdx.x * CG_BN;
-    const int Ktot = a.ktaps * a.Cin;
+    const int Ktot = a.trans_a ? a.red : a.ktaps * a.Cin;
     const int nk = (Ktot + CG_BK - 1) / CG_BK;
 
     f32x16 acc[2][2];
@@ -1266,12 +1269,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         if (a.trans_a) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int kk = kbase + b_k0 + p * 8;
-                const int m = m0 + b_nq * 4;
+                const int rr = kbase + b_k0 + p * 8;                 // reduction row
+                const int mo = m0 + b_nq * 4;                        // output rows mo .. mo + 3
                 float tmp[4] = {0.f, 0.f, 0.f, 0.f};
-                if (kk < Ktot) {
+                if (rr < Ktot) {
+                    const int tt = rr % a.T;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) if (m + c < a.Mtot) tmp[c] = a.x[(size_t)kk * a.ldx + m + c];
+                    for (int c = 0; c < 4; ++c) {
+                        if (mo + c < a.Mtot) {
+                            const int j = (mo + c) / a.Cin, i = (mo + c) - j * a.Cin;
+                            const int ts = tt + j - a.pad_l;
+                            if (ts >= 0 && ts < a.T) tmp[c] = a.x[(size_t)(rr + j - a.pad_l) * a.ldx + i];
+                        }
+                    }
                 }
                 ra[p] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
             }

@@ -83,6 +83,7 @@ struct t2_model {
     // device weights
     float* embedding = nullptr;
     std::vector<ConvLayer> enc_convs, post_convs;
+    std::vector<float*> enc_bn_gamma, enc_bn_beta;   // raw batch-norm scale / offset of the encoder convs (training-mode forward)
     ConvLayer post_proj, memory_layer;
     Packed enc_lstm[2];
     Packed prenet[T2_MAX_PRENET_LAYERS];
@@ -393,6 +394,16 @@ extern "C" int t2_model_finalize(t2_model* m) {
     m->enc_convs.resize(d.enc_conv_layers);
     for (int i = 0; i < d.enc_conv_layers; ++i) {
         T2_TRY(make_conv(m, &m->enc_convs[i], "encoder/conv1d_" + std::to_string(i), d.enc_kernel, cin, d.enc_units, true));
+        {
+            const HostWeight *g, *bb;
+            const std::string bp = "encoder/conv1d_" + std::to_string(i) + "/batch_normalization/";
+            T2_TRY(get_w(m, bp + "gamma", &g, {d.enc_units}));
+            T2_TRY(get_w(m, bp + "beta", &bb, {d.enc_units}));
+            float *dg = nullptr, *db = nullptr;
+            T2_TRY(upload(m, &dg, g->data));
+            T2_TRY(upload(m, &db, bb->data));
+            m->enc_bn_gamma.push_back(dg); m->enc_bn_beta.push_back(db);
+        }
         cin = d.enc_units;
     }
     const int He = d.enc_units / 2;

@@ -62,6 +62,7 @@ struct LstmBwdArgs {
     uint32_t seed;
     float zc, zh, fb;
     int first;                                // 1: last time step (no gradient from the future)
+    const int* lens;                          // optional [B]: rows with t >= len copied their state through (dynamic_rnn)
 };
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
@@ -81,6 +82,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
             if (a.g_hs1) g_hs += a.g_hs1[(size_t)row * a.ld_hs1 + u];
         }
         const float g_c = a.first ? 0.f : a.g_c[i];
+        if (a.lens != nullptr && a.t >= a.lens[row]) {          // dead step: state passes through, no output, no gate gradient
+            a.g_c[i] = g_c;
+            a.g_hp[i] = g_hs;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                a.dz_plain[(size_t)row * 4 * a.H + g * a.H + u] = 0.f;
+                a.dz_frag[frag_idx(row, g * a.H + u, a.MB)] = 0.f;
+            }
+            continue;
+        }
         const float tc = tanhf(cn);
         const float dhn = g_out + mh * g_hs;
         const float dcn = mc * g_c + dhn * go * (1.f - tc * tc);
@@ -526,7 +537,7 @@ static void bwd_dense(t2_trainer* tr, const Packed& wT, float* x_frag, float* y,
 static int bwd_wgrad(t2_trainer* tr, const float* A, int lda, int rows, const float* Bm, int ldb, int ncols, long long red, float* dst, int ldd) {
     ConvArgs a{};
     a.x = A; a.ldx = lda; a.w = Bm; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.ldr = 0; a.y = dst; a.ldy = ldd;
-    a.Mtot = rows; a.T = rows; a.Cin = (int)red; a.N = ncols; a.ktaps = 1; a.pad_l = 0; a.act = 0; a.trans_a = 1;
+    a.Mtot = rows; a.T = (int)red; a.Cin = rows; a.N = ncols; a.ktaps = 1; a.pad_l = 0; a.act = 0; a.trans_a = 1; a.red = (int)red;
     a.vec_a = 0;
     a.vec_b = (ncols % 4 == 0) && (ldb == ncols) && (((uintptr_t)Bm) % 16 == 0);
     if (ldb != ncols) return fail(T2_EINVAL, "internal: wgrad right operand must be dense");
@@ -714,5 +725,271 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     HIP_TRY(hipMemcpyAsync(loss_out + 1, l3 + 6, 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(batch_sum_kernel, dim3(1), dim3(256), 0, st, loss_out, 2, 1LL, loss_out + 2);
     HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+// ==========================================================================================================================
+// Encoder: training-mode forward (batch-statistics batch norm, conv dropout, zoneout-sampled BiLSTM) and backward
+// ==========================================================================================================================
+#define T2_STREAM_ENC_CONV 20
+#define T2_STREAM_ZONE_ENC 30
+
+// per-channel batch statistics over all M rows (tf.layers.batch_normalization(training=True): padding rows included),
+// biased variance; one block per 64 channels, 4 row lanes, double accumulators, fixed summation order
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, float eps, float* __restrict__ mean,
+                                                       float* __restrict__ invstd, float* __restrict__ var_out) {
+    __shared__ double s1[4][64], s2[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int m = rl; m < M; m += 4) { const double v = x[(size_t)m * C + c]; a += v; b += v * v; }
+    s1[rl][cl] = a; s2[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const double sum = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl], sq = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
+        const double mu = sum / M, var = fmax(sq / M - mu * mu, 0.0);
+        mean[c] = (float)mu; var_out[c] = (float)var; invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// Conv1d.call after the convolution (modules.py:152-156), training mode: batch norm with batch statistics -> relu -> dropout
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float rate, uint32_t seed,
+                                                       int stream, float* __restrict__ out, long long M, int C) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M * C; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C;
+        const int c = (int)(i - m * C);
+        float v = (y[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        v = fmaxf(v, 0.f);
+        if (rate > 0.f) v = dropout_train(v, rate, t2_u01(seed, stream, 0, (uint32_t)m, c));
+        out[i] = v;
+    }
+}
+
+// d gamma / d beta of the layer above: g = d_out * (out != 0) / keep (relu and dropout), xhat = (y - mean) * invstd
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ d_out, const float* __restrict__ out, const float* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, float inv_keep,
+                                                            int M, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double s1[4][64], s2[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const float mu = mean[c], is = invstd[c];
+        for (int m = rl; m < M; m += 4) {
+            const size_t i = (size_t)m * C + c;
+            const float g = out[i] != 0.f ? d_out[i] * inv_keep : 0.f;
+            a += (double)g * (double)((y[i] - mu) * is);
+            b += (double)g;
+        }
+    }
+    s1[rl][cl] = a; s2[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        dgamma[c] = (float)(s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
+        dbeta[c] = (float)(s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl]);
+    }
+}
+
+// dy = gamma * invstd * (g - dbeta / M - xhat * dgamma / M): gradient of the convolution output through the batch statistics
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ d_out, const float* __restrict__ out, const float* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_keep,
+                                                           long long M, int C, float* __restrict__ dy) {
+    const float invM = 1.0f / (float)M;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M * C; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float g = out[i] != 0.f ? d_out[i] * inv_keep : 0.f;
+        const float xh = (y[i] - mean[c]) * invstd[c];
+        dy[i] = gamma[c] * invstd[c] * (g - dbeta[c] * invM - xh * dgamma[c] * invM);
+    }
+}
+
+// x [B][T][C] -> time-major per-step rows xs[s][b][:] in the order direction `reverse` consumes them (zeros past the length)
+__global__ __launch_bounds__(256) void seq_gather_kernel(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ xs,
+                                                         int B, int T, int C, int reverse) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)T * B * C; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), b = (int)((i / C) % B), s = (int)(i / ((long long)C * B));
+        const int len = lens[b];
+        const int pos = reverse ? len - 1 - s : s;
+        xs[i] = (s < len) ? x[((size_t)b * T + pos) * C + c] : 0.f;
+    }
+}
+
+// gradient of the raw output of step s of one direction: dmemory[b][pos][off + u] for live rows
+__global__ __launch_bounds__(256) void enc_gout_kernel(const float* __restrict__ dmem, const int* __restrict__ lens, float* __restrict__ g,
+                                                       int B, int T, int E, int H, int off, int s, int reverse) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * H; i += gridDim.x * blockDim.x) {
+        const int b = i / H, u = i - b * H;
+        const int len = lens[b];
+        const int pos = reverse ? len - 1 - s : s;
+        g[i] = (s < len) ? dmem[((size_t)b * T + pos) * E + off + u] : 0.f;
+    }
+}
+
+// d(conv stack output)[b][pos][:] += dX[b][:C] of step s (live rows)
+__global__ __launch_bounds__(256) void enc_dx_scatter_kernel(const float* __restrict__ dX, int ld, const int* __restrict__ lens, float* __restrict__ dxc,
+                                                             int B, int T, int C, int s, int reverse) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * C; i += gridDim.x * blockDim.x) {
+        const int b = i / C, c = i - b * C;
+        const int len = lens[b];
+        if (s >= len) continue;
+        const int pos = reverse ? len - 1 - s : s;
+        dxc[((size_t)b * T + pos) * C + c] += dX[(size_t)b * ld + c];
+    }
+}
+
+// d embedding[sym][:] = sum over the rows m with ids[m] == sym of dx[m][:]: one block per symbol, rows in order (deterministic)
+__global__ __launch_bounds__(256) void embedding_grad_kernel(const int* __restrict__ ids, const float* __restrict__ dx, int M, int C, float* __restrict__ demb) {
+    const int sym = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) if (ids[m] == sym) acc += dx[(size_t)m * C + c];
+        demb[(size_t)sym * C + c] = acc;
+    }
+}
+
+struct EncTape {
+    void* slab = nullptr; size_t bytes = 0;
+    int* ids = nullptr; int* lens = nullptr;
+    std::vector<float*> x;            // x[0] = embedding output [M][emb]; x[i + 1] = output of conv layer i after dropout [M][E]
+    std::vector<float*> yraw, mean, invstd, var;
+    float *z[2] = {}, *cprev[2] = {}, *cnew[2] = {}, *hstate[2] = {};     // BiLSTM tape per direction: [T][B][.]
+    float *xf = nullptr, *hfrag = nullptr, *cst = nullptr; int* ctl = nullptr;
+    float drop_rate = 0.f; uint32_t seed = 0;
+    // backward
+    std::vector<ConvLayer> convT;     // flipped / transposed conv kernels of the data gradient
+    Packed lstmT[2];
+    float *xs = nullptr, *gout = nullptr, *dzp = nullptr, *dzf = nullptr, *dX = nullptr, *g_c = nullptr, *g_hp = nullptr;
+    float *dxa = nullptr, *dxb = nullptr, *dgamma = nullptr, *dbeta = nullptr;
+    bool have_forward = false, have_bwd = false;
+};
+
+static std::map<t2_trainer*, EncTape*> g_enc_tapes;      // trainer -> encoder tape (kept outside t2_trainer's layout)
+
+static EncTape* enc_tape_of(t2_trainer* tr) {
+    auto it = g_enc_tapes.find(tr);
+    if (it != g_enc_tapes.end()) return it->second;
+    EncTape* e = new EncTape();
+    g_enc_tapes[tr] = e;
+    return e;
+}
+
+static int enc_tape_alloc(t2_trainer* tr, EncTape* et) {
+    t2_model* m = tr->m;
+    const t2_dims& d = m->d;
+    const int B = tr->B, T = tr->T, MB = mb_for(B), E = d.enc_units, He = E / 2, emb = d.embedding_dim, L = d.enc_conv_layers;
+    const size_t Mtot = (size_t)B * T;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_ids = carve(Mtot * 4), o_lens = carve((size_t)B * 4);
+    std::vector<size_t> o_x(L + 1), o_y(L), o_mu(L), o_is(L), o_var(L);
+    o_x[0] = carve(Mtot * emb * 4);
+    for (int i = 0; i < L; ++i) { o_x[i + 1] = carve(Mtot * E * 4); o_y[i] = carve(Mtot * E * 4); o_mu[i] = carve((size_t)E * 4); o_is[i] = carve((size_t)E * 4); o_var[i] = carve((size_t)E * 4); }
+    size_t o_z[2], o_cp[2], o_cn[2], o_hs[2];
+    for (int dir = 0; dir < 2; ++dir) {
+        o_z[dir] = carve((size_t)T * B * 4 * He * 4); o_cp[dir] = carve((size_t)T * B * He * 4); o_cn[dir] = carve((size_t)T * B * He * 4);
+        o_hs[dir] = carve((size_t)T * B * He * 4);
+    }
+    const int Cx = L > 0 ? E : emb;
+    const int KPc = pad16(Cx), KPh = pad16(He);
+    const size_t per_step = (size_t)MB * 16 * KPc;
+    const size_t o_xf = carve(2 * (size_t)T * per_step * 4), o_h = carve(2 * 2 * (size_t)MB * 16 * KPh * 4), o_c = carve(2 * (size_t)MB * 16 * He * 4);
+    const size_t o_ctl = carve(64);
+    et->bytes = off;
+    HIP_TRY(hipMalloc(&et->slab, off));
+    char* p = (char*)et->slab;
+    et->ids = (int*)(p + o_ids); et->lens = (int*)(p + o_lens);
+    et->x.resize(L + 1); et->yraw.resize(L); et->mean.resize(L); et->invstd.resize(L); et->var.resize(L);
+    et->x[0] = (float*)(p + o_x[0]);
+    for (int i = 0; i < L; ++i) {
+        et->x[i + 1] = (float*)(p + o_x[i + 1]); et->yraw[i] = (float*)(p + o_y[i]); et->mean[i] = (float*)(p + o_mu[i]);
+        et->invstd[i] = (float*)(p + o_is[i]); et->var[i] = (float*)(p + o_var[i]);
+    }
+    for (int dir = 0; dir < 2; ++dir) {
+        et->z[dir] = (float*)(p + o_z[dir]); et->cprev[dir] = (float*)(p + o_cp[dir]); et->cnew[dir] = (float*)(p + o_cn[dir]);
+        et->hstate[dir] = (float*)(p + o_hs[dir]);
+    }
+    et->xf = (float*)(p + o_xf); et->hfrag = (float*)(p + o_h); et->cst = (float*)(p + o_c); et->ctl = (int*)(p + o_ctl);
+    return T2_OK;
+}
+
+// Embedding.call + EncoderV2.call with is_training = True (tacotron_v2.py:53-63; Conv1d.call modules.py:149-157):
+// conv -> batch norm on the batch statistics of all B*T positions -> relu -> dropout(drop_rate); BiLSTM of ZoneoutLSTMCells in
+// their training branch with sequence lengths.  ids host int64 [B][T_in]; memory_out dev [B][T_in][enc_units].
+// bn_stats_out (dev, may be null): per conv layer [mean | biased variance], 2 * enc_units floats each (the moving-statistics
+// update of the step, models.py:75, is the caller's: moving = 0.99 * moving + 0.01 * batch).
+extern "C" int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, const int64_t* lens, float drop_rate, uint32_t seed,
+                                        float* memory_out, float* bn_stats_out) {
+    if (!tr || !ids || !memory_out) return fail(T2_EINVAL, "null argument");
+    if (!(drop_rate >= 0.f && drop_rate < 1.f)) return fail(T2_EINVAL, "drop rate must be in [0, 1)");
+    t2_model* m = tr->m;
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int B = tr->B, T = tr->T, MB = mb_for(B), E = d.enc_units, He = E / 2, emb = d.embedding_dim, L = d.enc_conv_layers;
+    const int Mtot = B * T;
+    EncTape* et = enc_tape_of(tr);
+    if (!et->slab) T2_TRY(enc_tape_alloc(tr, et));
+    std::vector<int> h_lens(B), h_ids(Mtot);
+    for (int b = 0; b < B; ++b) {
+        const int64_t l = lens ? lens[b] : T;
+        if (l < 0 || l > T) return fail(T2_EINVAL, "sequence length %lld outside 0..%d", (long long)l, T);
+        h_lens[b] = (int)l;
+    }
+    for (int i = 0; i < Mtot; ++i) {
+        if (ids[i] < 0 || ids[i] >= d.num_symbols) return fail(T2_ERANGE, "embedding id %lld outside [0, %d) (modules.py:65-66)", (long long)ids[i], d.num_symbols);
+        h_ids[i] = (int)ids[i];
+    }
+    HIP_TRY(hipMemcpyAsync(et->lens, h_lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(et->ids, h_ids.data(), (size_t)Mtot * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    et->drop_rate = drop_rate; et->seed = seed;
+    auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
+    hipLaunchKernelGGL(embedding_kernel, grid1((long long)Mtot * emb), dim3(256), 0, st, et->ids, m->embedding, et->x[0], Mtot, emb);
+    int cin = emb;
+    for (int i = 0; i < L; ++i) {
+        ConvLayer raw = m->enc_convs[i];
+        raw.scale = nullptr; raw.shift = nullptr;               // the batch statistics replace the folded moving statistics
+        T2_TRY(launch_conv(m, raw, et->x[i], cin, et->yraw[i], E, Mtot, T, 0, nullptr, 0));
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(E, 64)), dim3(256), 0, st, et->yraw[i], Mtot, E, d.bn_eps, et->mean[i], et->invstd[i], et->var[i]);
+        hipLaunchKernelGGL(bn_apply_kernel, grid1((long long)Mtot * E), dim3(256), 0, st, et->yraw[i], et->mean[i], et->invstd[i],
+                           m->enc_bn_gamma[i], m->enc_bn_beta[i], drop_rate, seed, T2_STREAM_ENC_CONV + i, et->x[i + 1], (long long)Mtot, E);
+        if (bn_stats_out) {
+            HIP_TRY(hipMemcpyAsync(bn_stats_out + (size_t)i * 2 * E, et->mean[i], (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(bn_stats_out + (size_t)i * 2 * E + E, et->var[i], (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+        }
+        cin = E;
+    }
+    const int Cx = cin, KPc = pad16(Cx), KPh = pad16(He);
+    const size_t per_step = (size_t)MB * 16 * KPc;
+    hipLaunchKernelGGL(seq_to_frag_kernel, grid1(2LL * T * per_step), dim3(256), 0, st, et->x[L], et->lens, et->xf, B, T, Cx, MB, KPc);
+    HIP_TRY(hipMemsetAsync(memory_out, 0, (size_t)Mtot * E * 4, st));
+    HIP_TRY(hipMemsetAsync(et->hfrag, 0, 2 * 2 * (size_t)MB * 16 * KPh * 4, st));
+    HIP_TRY(hipMemsetAsync(et->cst, 0, 2 * (size_t)MB * 16 * He * 4, st));
+    const int h_ctl[8] = {0, 0, T, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(et->ctl, h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int hsz = MB * 16 * KPh;
+    for (int s = 0; s < T; ++s)
+        for (int dir = 0; dir < 2; ++dir) {
+            SkinnyCore c{};
+            LstmEpi e{};
+            c.w[0] = c.w[1] = m->enc_lstm[dir].w; c.bias[0] = c.bias[1] = m->enc_lstm[dir].bias;
+            c.seg[0][0] = FragBuf{et->xf + (size_t)dir * T * per_step, (int)per_step, T, 0, 0};
+            c.seg[0][1] = FragBuf{et->hfrag + (size_t)dir * 2 * hsz, hsz, 2, 0, 0};
+            c.kb0 = KPc / 16; c.kbtot = m->enc_lstm[dir].kbtot; c.kb_w0 = 0; c.kb_full = c.kbtot; c.ctl = et->ctl; c.step_off = s; c.t_hint = s; c.B = B;
+            e.c[0] = et->cst + (size_t)dir * MB * 16 * He;
+            e.hprev[0] = FragBuf{et->hfrag + (size_t)dir * 2 * hsz, hsz, 2, 0, 0};
+            e.hstate[0] = FragBuf{et->hfrag + (size_t)dir * 2 * hsz, hsz, 2, 1, 0};
+            e.hraw[0] = FragBuf{nullptr, 0, 1, 0, 0};
+            e.plain_off[0] = dir * He; e.reverse[0] = dir;
+            e.H = He; e.Hld = He; e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
+            e.lens = et->lens; e.plain_out = memory_out; e.plain_bs = T * E; e.plain_ts = E;
+            e.train = 1; e.seed = seed; e.stream = T2_STREAM_ZONE_ENC + 2 * dir;
+            e.tp_z = et->z[dir]; e.tp_cprev = et->cprev[dir]; e.tp_cnew = et->cnew[dir]; e.tp_hraw = nullptr; e.tp_hstate = et->hstate[dir];
+            launch_lstm<true>(MB, dim3(m->enc_lstm[dir].n_wg, 1), st, c, e);
+        }
+    HIP_TRY(hipGetLastError());
+    et->have_forward = true;
     return T2_OK;
 }

@@ -217,6 +217,21 @@ class Trainer:
                                                         mel.data_ptr(), stop.data_ptr(), align.data_ptr()))
         return mel, stop.unsqueeze(-1), align
 
+    def encoder_forward(self, ids, lens, drop_rate: float = 0.5, seed: int = 0):
+        """Embedding + EncoderV2 in training mode: (memory [B, T_in, E], batch-norm statistics [layers, 2, E] = mean | variance)."""
+        eng, d = self.engine, self.engine.dims
+        ids = np.ascontiguousarray(np.asarray(ids), dtype=np.int64)
+        lens = None if lens is None else np.ascontiguousarray(np.asarray(lens), dtype=np.int64)
+        if ids.shape != (self.B, self.T_in):
+            raise ValueError("ids do not match the trainer's (B, T_in)")
+        memory = torch.empty((self.B, self.T_in, d.enc_units), dtype=torch.float32, device=eng.device)
+        stats = torch.empty((max(d.enc_conv_layers, 1), 2, d.enc_units), dtype=torch.float32, device=eng.device)
+        with eng._ordered():
+            _lib.check(eng.lib.t2_train_encoder_forward(self._h, ids.ctypes.data_as(C.c_void_p),
+                                                        None if lens is None else lens.ctypes.data_as(C.c_void_p), float(drop_rate),
+                                                        int(seed) & 0xFFFFFFFF, memory.data_ptr(), stats.data_ptr()))
+        return memory, stats[:d.enc_conv_layers]
+
     def bind_gradients(self, spec):
         """spec: training.flatten_spec(weights) -- where each variable's gradient goes in the flat buffer."""
         self._spec = spec

@@ -97,3 +97,31 @@ def test_decoder_backward_against_autograd(d, B, T, S):
     assert float(np.abs(_np(dmem) - g_ref).max()) <= 1e-3 * float(np.abs(g_ref).max()) + 1e-6
     tr.close()
     eng.close()
+
+
+@pytest.mark.parametrize("d,B,T", [(PROFILE_TINY, 3, 7), (MID, 5, 19), (MID, 20, 9)])
+def test_training_mode_encoder_forward(d, B, T):
+    """Batch-statistics batch norm, conv dropout and the zoneout-sampled BiLSTM against the float64 torch restatement."""
+    import torch
+    from oracle import torch_train as TT
+    from tacotron2_amd.engine import Engine
+    from tacotron2_amd.training import Trainer
+    w = init_weights(d, 4, perturb=True)
+    eng = Engine(d, w)
+    rng = np.random.default_rng(T)
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    lens = rng.integers(max(1, T // 2), T + 1, size=B).astype(np.int64)
+    lens[0] = T
+    W = {k: TT._t(v) for k, v in w.items()}
+    mem_ref, stats_ref = TT.encoder_train(d, W, W["embedding"][torch.as_tensor(ids)], lens, seed=31, drop_rate=0.25)
+    tr = Trainer(eng, B, T, 2)
+    memory, stats = tr.encoder_forward(ids, lens, drop_rate=0.25, seed=31)
+    np.testing.assert_allclose(_np(memory), mem_ref.numpy(), atol=1e-3)
+    for i in range(d.enc_conv_layers):
+        mu, var = stats_ref[f"encoder/conv1d_{i}"]
+        np.testing.assert_allclose(_np(stats[i, 0]), mu.numpy(), atol=1e-4)
+        np.testing.assert_allclose(_np(stats[i, 1]), var.numpy(), rtol=1e-3, atol=1e-6)
+    mem_inf = eng.encode(ids, lens)
+    assert float((memory - mem_inf).abs().max()) > 1e-3          # not the inference arithmetic
+    tr.close()
+    eng.close()
