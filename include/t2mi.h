@@ -202,6 +202,10 @@ int t2_train_decoder_forward(t2_trainer* tr, const float* memory, const int64_t*
  * each -- the moving-statistics update of the step (models.py:75) is moving = 0.99*moving + 0.01*batch on the caller's side. */
 int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, const int64_t* lens, float drop_rate, uint32_t seed,
                              float* memory_out, float* bn_stats_out);
+/* Backward of t2_train_encoder_forward: dmemory dev [B,T_in,enc_units] (from t2_train_decoder_backward) -> gradients of
+ * `embedding`, encoder/conv1d_i/{kernel, batch_normalization/gamma, beta} (through the batch statistics) and the BiLSTM
+ * kernels / biases into flat_grads at the bound offsets. */
+int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, float* flat_grads);
 /* Where the gradient of variable `name` (TF layout) goes in the caller's flat gradient buffer (floats, multiple of 4). */
 int t2_trainer_bind_gradient(t2_trainer* tr, const char* name, int64_t offset);
 /* Backward of t2_train_decoder_forward through the losses of model_fn (tacotron/models.py:58-61: spec_loss(mel) +

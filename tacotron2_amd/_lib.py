@@ -86,6 +86,7 @@ _SIGS = {
     "t2_trainer_destroy": (C.c_int, [_p]),
     "t2_train_decoder_forward": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_uint32, _p, _p, _p]),
     "t2_train_encoder_forward": (C.c_int, [_p, _p, _p, C.c_float, C.c_uint32, _p, _p]),
+    "t2_train_encoder_backward": (C.c_int, [_p, _p, _p]),
     "t2_trainer_bind_gradient": (C.c_int, [_p, C.c_char_p, C.c_int64]),
     "t2_train_decoder_backward": (C.c_int, [_p, _p, _p, _p, _p, _p, _p]),
     "t2_spec_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),

@@ -355,10 +355,13 @@ static int trainer_pack_T(t2_trainer* tr, Packed* out, const std::string& name, 
     return T2_OK;
 }
 
+static void enc_tape_release(t2_trainer* tr);
+
 extern "C" int t2_trainer_destroy(t2_trainer* tr) {
     if (!tr) return T2_OK;
     (void)hipSetDevice(tr->m->ctx->device);
     (void)hipStreamSynchronize(tr->m->ctx->stream);
+    enc_tape_release(tr);
     if (tr->slab) (void)hipFree(tr->slab);
     if (tr->bslab) (void)hipFree(tr->bslab);
     for (void* p : tr->allocs) (void)hipFree(p);
@@ -866,6 +869,14 @@ struct EncTape {
 
 static std::map<t2_trainer*, EncTape*> g_enc_tapes;      // trainer -> encoder tape (kept outside t2_trainer's layout)
 
+static void enc_tape_release(t2_trainer* tr) {
+    auto it = g_enc_tapes.find(tr);
+    if (it == g_enc_tapes.end()) return;
+    if (it->second->slab) (void)hipFree(it->second->slab);
+    delete it->second;
+    g_enc_tapes.erase(it);
+}
+
 static EncTape* enc_tape_of(t2_trainer* tr) {
     auto it = g_enc_tapes.find(tr);
     if (it != g_enc_tapes.end()) return it->second;
@@ -991,5 +1002,134 @@ extern "C" int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, cons
         }
     HIP_TRY(hipGetLastError());
     et->have_forward = true;
+    return T2_OK;
+}
+
+static int enc_setup_backward(t2_trainer* tr, EncTape* et) {
+    t2_model* m = tr->m;
+    const t2_dims& d = m->d;
+    const int B = tr->B, T = tr->T, MB = mb_for(B), R = MB * 16, E = d.enc_units, He = E / 2, emb = d.embedding_dim, L = d.enc_conv_layers;
+    const int Cx = L > 0 ? E : emb;
+    const char* dirs[2] = {"fw", "bw"};
+    for (int dir = 0; dir < 2; ++dir)
+        T2_TRY(trainer_pack_T(tr, &et->lstmT[dir], std::string("encoder/bidirectional_rnn/") + dirs[dir] + "/lstm_cell/kernel", Cx + He, 4 * He, 0, 4 * He));
+    et->convT.resize(L);
+    int cin = emb;
+    for (int i = 0; i < L; ++i) {
+        const HostWeight* w;
+        const int k = d.enc_kernel;
+        T2_TRY(get_w(m, "encoder/conv1d_" + std::to_string(i) + "/kernel", &w, {k, cin, E}));
+        std::vector<float> t((size_t)k * E * cin);
+        for (int j = 0; j < k; ++j)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int co = 0; co < E; ++co) t[((size_t)(k - 1 - j) * E + co) * cin + ci] = w->data[((size_t)j * cin + ci) * E + co];
+        ConvLayer& Lc = et->convT[i];
+        Lc.k = k; Lc.cin = E; Lc.cout = cin;
+        HIP_TRY(hipMalloc((void**)&Lc.w, t.size() * 4));
+        tr->allocs.push_back(Lc.w);
+        HIP_TRY(hipMemcpy(Lc.w, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        cin = E;
+    }
+    const size_t Mtot = (size_t)B * T;
+    const int cmax = std::max(E, emb);
+    size_t off = 0;
+    auto carve = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
+    const size_t o_xs = carve((size_t)T * B * Cx), o_go = carve((size_t)B * He), o_dzp = carve((size_t)T * B * 4 * He), o_dzf = carve((size_t)R * pad16(4 * He));
+    const size_t o_dX = carve((size_t)B * (Cx + He)), o_gc = carve((size_t)B * He), o_ghp = carve((size_t)B * He);
+    const size_t o_a = carve(Mtot * cmax), o_b = carve(Mtot * cmax), o_dg = carve(E), o_db = carve(E);
+    void* p0 = nullptr;
+    HIP_TRY(hipMalloc(&p0, off));
+    tr->allocs.push_back(p0);
+    HIP_TRY(hipMemset(p0, 0, off));
+    char* p = (char*)p0;
+    et->xs = (float*)(p + o_xs); et->gout = (float*)(p + o_go); et->dzp = (float*)(p + o_dzp); et->dzf = (float*)(p + o_dzf);
+    et->dX = (float*)(p + o_dX); et->g_c = (float*)(p + o_gc); et->g_hp = (float*)(p + o_ghp);
+    et->dxa = (float*)(p + o_a); et->dxb = (float*)(p + o_b); et->dgamma = (float*)(p + o_dg); et->dbeta = (float*)(p + o_db);
+    et->have_bwd = true;
+    return T2_OK;
+}
+
+// Backward of t2_train_encoder_forward: dmemory dev [B][T_in][enc_units] (d loss / d memory, e.g. from
+// t2_train_decoder_backward) -> gradients of embedding, encoder/conv1d_i/{kernel, batch_normalization/gamma, beta} and the
+// BiLSTM kernels / biases, written into flat_grads at the bound offsets.
+extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, float* flat_grads) {
+    if (!tr || !dmemory || !flat_grads) return fail(T2_EINVAL, "null argument");
+    t2_model* m = tr->m;
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    EncTape* et = enc_tape_of(tr);
+    if (!et->have_forward) return fail(T2_ESTATE, "t2_train_encoder_forward has not run");
+    if (!et->have_bwd) T2_TRY(enc_setup_backward(tr, et));
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int B = tr->B, T = tr->T, MB = mb_for(B), R = MB * 16, E = d.enc_units, He = E / 2, emb = d.embedding_dim, L = d.enc_conv_layers;
+    const int Cx = L > 0 ? E : emb, Mtot = B * T;
+    auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
+    float* g = nullptr;
+    HIP_TRY(hipMemsetAsync(et->dxa, 0, (size_t)Mtot * Cx * 4, st));
+    const char* dirs[2] = {"fw", "bw"};
+    for (int dir = 0; dir < 2; ++dir) {
+        hipLaunchKernelGGL(seq_gather_kernel, grid1((long long)T * B * Cx), dim3(256), 0, st, et->x[L], et->lens, et->xs, B, T, Cx, dir);
+        HIP_TRY(hipMemsetAsync(et->dzf, 0, (size_t)R * pad16(4 * He) * 4, st));
+        for (int s = T - 1; s >= 0; --s) {
+            hipLaunchKernelGGL(enc_gout_kernel, grid1((long long)B * He), dim3(256), 0, st, dmemory, et->lens, et->gout, B, T, E, He, dir * He, s, dir);
+            LstmBwdArgs a{};
+            a.z = et->z[dir] + (size_t)s * B * 4 * He; a.cprev = et->cprev[dir] + (size_t)s * B * He; a.cnew = et->cnew[dir] + (size_t)s * B * He;
+            a.g_out0 = et->gout; a.ld_out0 = He; a.g_out1 = nullptr;
+            a.g_hs0 = et->g_hp; a.ld_hs0 = He; a.g_hs1 = et->dX + Cx; a.ld_hs1 = Cx + He;
+            a.g_c = et->g_c; a.g_hp = et->g_hp; a.dz_plain = et->dzp + (size_t)s * B * 4 * He; a.dz_frag = et->dzf;
+            a.B = B; a.H = He; a.MB = MB; a.t = s; a.stream = T2_STREAM_ZONE_ENC + 2 * dir; a.seed = et->seed;
+            a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias; a.first = (s == T - 1) ? 1 : 0; a.lens = et->lens;
+            hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * He), dim3(256), 0, st, a);
+            bwd_dense(tr, et->lstmT[dir], et->dzf, et->dX, Cx + He);
+            hipLaunchKernelGGL(enc_dx_scatter_kernel, grid1((long long)B * Cx), dim3(256), 0, st, et->dX, Cx + He, et->lens, et->dxa, B, T, Cx, s, dir);
+        }
+        const std::string pn = std::string("encoder/bidirectional_rnn/") + dirs[dir] + "/lstm_cell";
+        const int n4 = 4 * He;
+        T2_TRY(grad_dst(tr, flat_grads, pn + "/kernel", &g));
+        T2_TRY(bwd_wgrad(tr, et->xs, Cx, Cx, et->dzp, n4, n4, (long long)T * B, g, n4));
+        if (T > 1) T2_TRY(bwd_wgrad(tr, et->hstate[dir], He, He, et->dzp + (size_t)B * n4, n4, n4, (long long)(T - 1) * B, g + (size_t)Cx * n4, n4));
+        else HIP_TRY(hipMemsetAsync(g + (size_t)Cx * n4, 0, (size_t)He * n4 * 4, st));
+        T2_TRY(grad_dst(tr, flat_grads, pn + "/bias", &g));
+        hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, st, et->dzp, (long long)T * B, n4, g);
+    }
+    // conv stack: dropout / relu / batch-statistics batch norm / convolution, last layer first
+    float* d_out = et->dxa;
+    float* other = et->dxb;
+    const float inv_keep = 1.0f / (1.0f - et->drop_rate);
+    for (int i = L - 1; i >= 0; --i) {
+        const int cin = i == 0 ? emb : E, k = d.enc_kernel, pad_l = (k - 1) / 2;
+        const std::string pn = "encoder/conv1d_" + std::to_string(i);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(E, 64)), dim3(256), 0, st, d_out, et->x[i + 1], et->yraw[i], et->mean[i], et->invstd[i],
+                           inv_keep, Mtot, E, et->dgamma, et->dbeta);
+        T2_TRY(grad_dst(tr, flat_grads, pn + "/batch_normalization/gamma", &g));
+        HIP_TRY(hipMemcpyAsync(g, et->dgamma, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+        T2_TRY(grad_dst(tr, flat_grads, pn + "/batch_normalization/beta", &g));
+        HIP_TRY(hipMemcpyAsync(g, et->dbeta, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((long long)Mtot * E), dim3(256), 0, st, d_out, et->x[i + 1], et->yraw[i], et->mean[i], et->invstd[i],
+                           m->enc_bn_gamma[i], et->dgamma, et->dbeta, inv_keep, (long long)Mtot, E, other);
+        // weight gradient: im2col(x_i)^T . dy
+        T2_TRY(grad_dst(tr, flat_grads, pn + "/kernel", &g));
+        {
+            ConvArgs a{};
+            a.x = et->x[i]; a.ldx = cin; a.w = other; a.y = g; a.ldy = E;
+            a.Mtot = k * cin; a.T = T; a.Cin = cin; a.N = E; a.ktaps = k; a.pad_l = pad_l; a.act = 0; a.trans_a = 1; a.red = Mtot;
+            a.vec_a = 0; a.vec_b = (E % 4 == 0) && (((uintptr_t)other) % 16 == 0);
+            hipLaunchKernelGGL(conv_gemm_kernel, dim3(ceil_div(E, CG_BN), ceil_div(k * cin, CG_BM)), dim3(256), 0, st, a);
+        }
+        // data gradient: correlation of dy with the flipped, transposed kernel
+        {
+            const ConvLayer& Lc = et->convT[i];
+            ConvArgs a{};
+            a.x = other; a.ldx = E; a.w = Lc.w; a.y = d_out; a.ldy = cin;
+            a.Mtot = Mtot; a.T = T; a.Cin = E; a.N = cin; a.ktaps = k; a.pad_l = k - 1 - pad_l; a.act = 0;
+            a.vec_a = (E % 4 == 0) && (((uintptr_t)other) % 16 == 0);
+            a.vec_b = (cin % 4 == 0) && (((uintptr_t)Lc.w) % 16 == 0);
+            hipLaunchKernelGGL(conv_gemm_kernel, dim3(ceil_div(cin, CG_BN), ceil_div(Mtot, CG_BM)), dim3(256), 0, st, a);
+        }
+        // d_out now holds d x_i ([M][cin]); `other` is free again
+    }
+    T2_TRY(grad_dst(tr, flat_grads, "embedding", &g));
+    hipLaunchKernelGGL(embedding_grad_kernel, dim3(d.num_symbols), dim3(256), 0, st, et->ids, d_out, Mtot, emb, g);
+    HIP_TRY(hipGetLastError());
     return T2_OK;
 }

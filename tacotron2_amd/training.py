@@ -254,6 +254,13 @@ class Trainer:
                                                          dmem.data_ptr(), losses.data_ptr()))
         return dmem, losses
 
+    def encoder_backward(self, dmemory: torch.Tensor, flat_grads: torch.Tensor):
+        """Backward of the last encoder_forward: fills the embedding and encoder/ slices of flat_grads."""
+        eng = self.engine
+        dmemory = eng._f32(dmemory)
+        with eng._ordered():
+            _lib.check(eng.lib.t2_train_encoder_backward(self._h, dmemory.data_ptr(), flat_grads.data_ptr()))
+
     def close(self):
         if getattr(self, "_h", None) and getattr(self.engine, "_model", None):
             self.engine.lib.t2_trainer_destroy(self._h)

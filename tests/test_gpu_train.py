@@ -125,3 +125,46 @@ def test_training_mode_encoder_forward(d, B, T):
     assert float((memory - mem_inf).abs().max()) > 1e-3          # not the inference arithmetic
     tr.close()
     eng.close()
+
+
+@pytest.mark.parametrize("d,B,T,S", [(PROFILE_TINY, 3, 7, 5), (MID, 4, 13, 6), (MID, 18, 9, 4)])
+def test_full_training_step_gradients_against_autograd(d, B, T, S):
+    """Embedding + encoder + decoder in training mode, both losses, and the gradient of EVERY trainable variable of the loss
+    (PostNetV2 is not in the reference's loss: models.py:58-61) against torch.autograd."""
+    import torch
+    from oracle import torch_train as TT
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    w = init_weights(d, 6, perturb=True)
+    eng = Engine(d, w)
+    rng = np.random.default_rng(B)
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    lens = rng.integers(max(1, T // 2), T + 1, size=B).astype(np.int64)
+    lens[0] = T
+    labels = _labels(rng, B, S, d.outputs_per_step)
+    labels["mel"] = rng.uniform(0, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+    ref = TT.train_forward_backward(d, w, ids, lens, labels, seed=17, prenet_drop_rate=0.5, encoder_drop_rate=0.25)
+    tr = TR.Trainer(eng, B, T, S)
+    spec = TR.flatten_spec(w)
+    tr.bind_gradients(spec)
+    memory, _ = tr.encoder_forward(ids, lens, drop_rate=0.25, seed=17)
+    np.testing.assert_allclose(_np(memory), ref["memory"], atol=1e-3)
+    mel, stop, align = tr.decoder_forward(memory, lens, labels["mel"], prenet_drop_rate=0.5, seed=17)
+    np.testing.assert_allclose(_np(mel), ref["mel"], atol=1e-3)
+    flat = torch.zeros(TR.flat_size(spec), dtype=torch.float32, device="cuda")
+    dmem, losses = tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat)
+    tr.encoder_backward(dmem, flat)
+    assert abs(float(losses[2]) - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+    grads = TR.unflatten(flat, spec)
+    bad = []
+    for name, g_ref in sorted(ref["grads"].items()):
+        scale = float(np.abs(g_ref).max())
+        err = float(np.abs(grads[name] - g_ref).max())
+        if err > 1e-3 * scale + 1e-6:
+            bad.append((name, err, scale))
+    assert not bad, bad
+    for name in grads:                                   # variables outside the loss get exactly zero
+        if name.startswith("postnet/") or name.endswith("moving_mean") or name.endswith("moving_variance"):
+            assert not grads[name].any()
+    tr.close()
+    eng.close()
