@@ -206,6 +206,13 @@ int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, const int64_t* 
  * `embedding`, encoder/conv1d_i/{kernel, batch_normalization/gamma, beta} (through the batch statistics) and the BiLSTM
  * kernels / biases into flat_grads at the bound offsets. */
 int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, float* flat_grads);
+/* After the optimizer step: rebuild every device copy of the weights (packed operands, folded batch norms, the transposed
+ * operands of the backward pass) from the flat parameter buffer (dev; layout = the bound offsets, TF layouts).  The inference
+ * entry points of the same model see the new weights too. */
+int t2_trainer_load_params(t2_trainer* tr, const float* flat_params);
+/* The UPDATE_OPS of the step (tacotron/models.py:75): moving = momentum*moving + (1-momentum)*batch for the encoder's batch
+ * norms (variance with Bessel's correction), in place in the flat parameter buffer; statistics of the last encoder forward. */
+int t2_trainer_update_moving_stats(t2_trainer* tr, float* flat_params, float momentum);
 /* Where the gradient of variable `name` (TF layout) goes in the caller's flat gradient buffer (floats, multiple of 4). */
 int t2_trainer_bind_gradient(t2_trainer* tr, const char* name, int64_t offset);
 /* Backward of t2_train_decoder_forward through the losses of model_fn (tacotron/models.py:58-61: spec_loss(mel) +

@@ -64,6 +64,8 @@ struct Packed {            // skinny-GEMM operand
     float* bias = nullptr; // LSTM: [n_wg][16]; dense: [N]
     int n_wg = 0, kbtot = 0, nseg = 0;
     int seg_kb[T2_MAX_SEG] = {0, 0, 0};
+    int seg_first[T2_MAX_SEG] = {0, 0, 0}, seg_rows[T2_MAX_SEG] = {0, 0, 0};   // source rows of each K segment
+    int lstm_units = 0;    // > 0: LSTM column order (4 units x 4 gates per workgroup)
     int N = 0;             // LSTM: hidden units; dense: columns
 };
 
@@ -194,8 +196,10 @@ static int pack_skinny(t2_model* m, Packed* p, const float* W, int ncol_src, con
     p->n_wg = lstm ? ceil_div(lstm_units, 4) : ceil_div(ncols, 16);
     p->nseg = (int)segs.size();
     p->kbtot = 0;
+    p->lstm_units = lstm_units;
     for (int s = 0; s < p->nseg; ++s) {
         p->seg_kb[s] = pad16(segs[s].second) / 16;
+        p->seg_first[s] = segs[s].first; p->seg_rows[s] = segs[s].second;
         p->kbtot += p->seg_kb[s];
     }
     std::vector<float> out((size_t)p->n_wg * p->kbtot * 256, 0.f);

@@ -1133,3 +1133,234 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
     HIP_TRY(hipGetLastError());
     return T2_OK;
 }
+
+// ==========================================================================================================================
+// Parameters on the device: after the optimizer has updated the flat fp32 parameter buffer, every kernel-native copy of the
+// weights (packed skinny operands, folded batch-norm affines, the transposed operands of the backward pass) is rebuilt from it
+// on the GPU -- the device-side mirror of t2_model_finalize / trainer_setup_backward.
+// ==========================================================================================================================
+struct PackDesc {
+    const float* src; long long sk, sc;       // element (k, col) of the operand = src[k * sk + col * sc]
+    int nseg, seg_first[T2_MAX_SEG], seg_rows[T2_MAX_SEG], seg_kb[T2_MAX_SEG];
+    int kbtot, n_wg, lstm_units, ncols;
+};
+
+__global__ __launch_bounds__(256) void pack_skinny_dev_kernel(float* __restrict__ dst, PackDesc d) {
+    const long long n = (long long)d.n_wg * d.kbtot * 256;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        const long long gk = idx >> 8;
+        const int kb = (int)(gk % d.kbtot), g = (int)(gk / d.kbtot);
+        const int kg = lane >> 4, c = lane & 15;
+        int col;
+        if (d.lstm_units > 0) {
+            const int gate = c >> 2, u = 4 * g + (c & 3);
+            col = u < d.lstm_units ? gate * d.lstm_units + u : -1;
+        } else {
+            col = 16 * g + c;
+            if (col >= d.ncols) col = -1;
+        }
+        int s = 0, kb0 = 0;
+        while (s + 1 < d.nseg && kb >= kb0 + d.seg_kb[s]) { kb0 += d.seg_kb[s]; ++s; }
+        const int k = (kb - kb0) * 16 + kg * 4 + j;
+        float v = 0.f;
+        if (col >= 0 && k < d.seg_rows[s]) v = d.src[(long long)(d.seg_first[s] + k) * d.sk + (long long)col * d.sc];
+        dst[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_bias_pack_kernel(float* __restrict__ dst, const float* __restrict__ bias, int n_wg, int H) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_wg * 16; i += gridDim.x * blockDim.x) {
+        const int g = i >> 4, c = i & 15, gate = c >> 2, u = 4 * g + (c & 3);
+        dst[i] = u < H ? bias[gate * H + u] : 0.f;
+    }
+}
+
+// dst[r][c] (row stride ldd) = src[c][r] (row stride lds): rows x cols of dst
+__global__ __launch_bounds__(256) void transpose_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int rows, int cols) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)rows * cols; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+        dst[(size_t)r * ldd + c] = src[(size_t)c * lds + r];
+    }
+}
+
+// inference batch norm folded to scale / shift (make_conv)
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                                      float* scale, float* shift, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    const float sc = gamma[i] / sqrtf(var[i] + eps);
+    scale[i] = sc; shift[i] = beta[i] - mean[i] * sc;
+}
+
+// conv kernel [k][cin][cout] -> [k][cout][cin] with the taps reversed (data gradient of a SAME convolution)
+__global__ __launch_bounds__(256) void conv_flip_kernel(float* __restrict__ dst, const float* __restrict__ src, int k, int cin, int cout) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)k * cin * cout; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout), ci = (int)((i / cout) % cin), j = (int)(i / ((long long)cout * cin));
+        dst[((size_t)(k - 1 - j) * cout + co) * cin + ci] = src[i];
+    }
+}
+
+// tf.layers.batch_normalization moving statistics (the UPDATE_OPS of models.py:75): moving = momentum * moving + (1 - momentum) *
+// batch, the variance with Bessel's correction as TF's fused kernel does
+__global__ __launch_bounds__(256) void bn_moving_update_kernel(float* mov_mean, float* mov_var, const float* mean, const float* var, float momentum,
+                                                               float bessel, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    mov_mean[i] = momentum * mov_mean[i] + (1.f - momentum) * mean[i];
+    mov_var[i] = momentum * mov_var[i] + (1.f - momentum) * var[i] * bessel;
+}
+
+static int flat_src(t2_trainer* tr, const float* flat, const std::string& name, const float** out) {
+    auto it = tr->offsets.find(name);
+    if (it == tr->offsets.end()) return fail(T2_ESTATE, "no offset bound for '%s' (t2_trainer_bind_gradient)", name.c_str());
+    *out = flat + it->second;
+    return T2_OK;
+}
+
+static void repack(hipStream_t st, const Packed& p, const float* src, long long sk, long long sc, int ncols) {
+    PackDesc d{};
+    d.src = src; d.sk = sk; d.sc = sc; d.nseg = p.nseg; d.kbtot = p.kbtot; d.n_wg = p.n_wg; d.lstm_units = p.lstm_units; d.ncols = ncols;
+    for (int s = 0; s < p.nseg; ++s) { d.seg_first[s] = p.seg_first[s]; d.seg_rows[s] = p.seg_rows[s]; d.seg_kb[s] = p.seg_kb[s]; }
+    const long long n = (long long)p.n_wg * p.kbtot * 256;
+    hipLaunchKernelGGL(pack_skinny_dev_kernel, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, st, p.w, d);
+}
+
+// Rebuild every device copy of the weights from the flat parameter buffer (layout = the offsets bound with
+// t2_trainer_bind_gradient; TF layouts).  Called after the optimizer step; inference entry points of the same model see the
+// new weights too.
+extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
+    if (!tr || !flat) return fail(T2_EINVAL, "null argument");
+    t2_model* m = tr->m;
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    if (!tr->bslab) T2_TRY(trainer_setup_backward(tr));
+    EncTape* et = enc_tape_of(tr);
+    if (!et->slab) T2_TRY(enc_tape_alloc(tr, et));
+    if (!et->have_bwd) T2_TRY(enc_setup_backward(tr, et));
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int E = d.enc_units, He = E / 2, U = d.attention_dim, A = d.attention_lstm_units, D = d.decoder_lstm_units, emb = d.embedding_dim;
+    const int F = d.attention_filters, K = d.attention_kernel, M = d.num_mels, r = d.outputs_per_step, np = d.num_prenet_layers, L = d.enc_conv_layers;
+    const float *w, *b;
+    auto copy = [&](float* dst, const float* src, size_t n) -> int { HIP_TRY(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st)); return T2_OK; };
+    auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
+    T2_TRY(flat_src(tr, flat, "embedding", &w));
+    T2_TRY(copy(m->embedding, w, (size_t)d.num_symbols * emb));
+    int cin = emb;
+    for (int i = 0; i < L; ++i) {
+        const std::string pn = "encoder/conv1d_" + std::to_string(i);
+        const float *g, *be, *mu, *var;
+        T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
+        T2_TRY(copy(m->enc_convs[i].w, w, (size_t)d.enc_kernel * cin * E));
+        hipLaunchKernelGGL(conv_flip_kernel, grid1((long long)d.enc_kernel * cin * E), dim3(256), 0, st, et->convT[i].w, w, d.enc_kernel, cin, E);
+        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/gamma", &g));
+        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/beta", &be));
+        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_mean", &mu));
+        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_variance", &var));
+        T2_TRY(copy(m->enc_bn_gamma[i], g, E));
+        T2_TRY(copy(m->enc_bn_beta[i], be, E));
+        hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, st, g, be, mu, var, d.bn_eps, m->enc_convs[i].scale, m->enc_convs[i].shift, E);
+        cin = E;
+    }
+    const char* dirs[2] = {"fw", "bw"};
+    for (int dir = 0; dir < 2; ++dir) {
+        const std::string pn = std::string("encoder/bidirectional_rnn/") + dirs[dir] + "/lstm_cell";
+        T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
+        T2_TRY(flat_src(tr, flat, pn + "/bias", &b));
+        repack(st, m->enc_lstm[dir], w, 4 * He, 1, 0);
+        hipLaunchKernelGGL(lstm_bias_pack_kernel, grid1(m->enc_lstm[dir].n_wg * 16), dim3(256), 0, st, m->enc_lstm[dir].bias, b, m->enc_lstm[dir].n_wg, He);
+        repack(st, et->lstmT[dir], w, 1, 4 * He, cin + He);
+    }
+    T2_TRY(flat_src(tr, flat, "attention/memory_layer/kernel", &w));
+    T2_TRY(copy(m->memory_layer.w, w, (size_t)E * U));
+    hipLaunchKernelGGL(transpose_kernel, grid1((long long)U * E), dim3(256), 0, st, tr->wmemT, E, w, U, U, E);
+    T2_TRY(flat_src(tr, flat, "attention/query_layer/kernel", &w));
+    T2_TRY(copy(m->wq, w, (size_t)A * U));
+    repack(st, tr->wqT, w, 1, U, A);
+    T2_TRY(flat_src(tr, flat, "attention/location_features_convolution/kernel", &w)); T2_TRY(copy(m->conv_w, w, (size_t)K * F));
+    T2_TRY(flat_src(tr, flat, "attention/location_features_convolution/bias", &w)); T2_TRY(copy(m->conv_b, w, F));
+    T2_TRY(flat_src(tr, flat, "attention/location_features_layer/kernel", &w)); T2_TRY(copy(m->wloc, w, (size_t)F * U));
+    T2_TRY(flat_src(tr, flat, "attention/attention_variable", &w)); T2_TRY(copy(m->v_a, w, U));
+    T2_TRY(flat_src(tr, flat, "attention/attention_bias", &w)); T2_TRY(copy(m->b_a, w, U));
+    int pin = M * d.n_feed_frame;
+    for (int i = 0; i < np; ++i) {
+        const std::string pn = "decoder/prenet_" + std::to_string(i) + "/dense";
+        T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
+        T2_TRY(flat_src(tr, flat, pn + "/bias", &b));
+        repack(st, m->prenet[i], w, d.prenet_units[i], 1, d.prenet_units[i]);
+        T2_TRY(copy(m->prenet[i].bias, b, d.prenet_units[i]));
+        if (i > 0) repack(st, tr->prenetT[i], w, 1, d.prenet_units[i], d.prenet_units[i - 1]);
+        pin = d.prenet_units[i];
+    }
+    const char* lname[3] = {"decoder/attention_lstm", "decoder/lstm_1", "decoder/lstm_2"};
+    Packed* lp[3] = {&m->att_lstm, &m->lstm1, &m->lstm2};
+    const int Hh[3] = {A, D, D};
+    const int KXs[3] = {pin + E + A, A + E + D, D + D};
+    for (int l = 0; l < 3; ++l) {
+        T2_TRY(flat_src(tr, flat, std::string(lname[l]) + "/kernel", &w));
+        T2_TRY(flat_src(tr, flat, std::string(lname[l]) + "/bias", &b));
+        repack(st, *lp[l], w, 4 * Hh[l], 1, 0);
+        hipLaunchKernelGGL(lstm_bias_pack_kernel, grid1(lp[l]->n_wg * 16), dim3(256), 0, st, lp[l]->bias, b, lp[l]->n_wg, Hh[l]);
+        repack(st, tr->lstmT[l], w, 1, 4 * Hh[l], KXs[l]);
+    }
+    {   // projections: concatenated [D][M*r + 1] operand and its transpose
+        const int N = M * r + 1;
+        const float *wm, *bm, *ws, *bs;
+        T2_TRY(flat_src(tr, flat, "decoder/out_projection/kernel", &wm));
+        T2_TRY(flat_src(tr, flat, "decoder/out_projection/bias", &bm));
+        T2_TRY(flat_src(tr, flat, "decoder/stop_token_projection/kernel", &ws));
+        T2_TRY(flat_src(tr, flat, "decoder/stop_token_projection/bias", &bs));
+        float* wc = tr->tmp;                                      // [D][N]
+        HIP_TRY(hipMemcpy2DAsync(wc, (size_t)N * 4, wm, (size_t)M * r * 4, (size_t)M * r * 4, D, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpy2DAsync(wc + M * r, (size_t)N * 4, ws, 4, 4, D, hipMemcpyDeviceToDevice, st));
+        repack(st, m->proj, wc, N, 1, N);
+        repack(st, tr->projT, wc, 1, N, D);
+        T2_TRY(copy(m->proj.bias, bm, (size_t)M * r));
+        T2_TRY(copy(m->proj.bias + M * r, bs, 1));
+    }
+    cin = M;
+    for (int i = 1; i <= d.postnet_layers; ++i) {
+        const std::string pn = "postnet/conv1d_" + std::to_string(i);
+        const float *g, *be, *mu, *var;
+        ConvLayer& Lc = m->post_convs[i - 1];
+        T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
+        T2_TRY(copy(Lc.w, w, (size_t)d.postnet_kernel * cin * d.postnet_channels));
+        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/gamma", &g));
+        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/beta", &be));
+        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_mean", &mu));
+        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_variance", &var));
+        hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(d.postnet_channels, 256)), dim3(256), 0, st, g, be, mu, var, d.bn_eps, Lc.scale, Lc.shift, d.postnet_channels);
+        cin = d.postnet_channels;
+    }
+    T2_TRY(flat_src(tr, flat, "postnet/projection/kernel", &w));
+    T2_TRY(copy(m->post_proj.w, w, (size_t)d.postnet_channels * M));
+    T2_TRY(flat_src(tr, flat, "postnet/projection/bias", &b));
+    T2_TRY(copy(m->post_proj.shift, b, M));
+    // cached decode graphs hold no weight pointers that moved: buffers are updated in place
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+// The UPDATE_OPS of the training step (models.py:75): moving statistics of the encoder's batch norms from the last
+// t2_train_encoder_forward, in place in the flat parameter buffer.
+extern "C" int t2_trainer_update_moving_stats(t2_trainer* tr, float* flat, float momentum) {
+    if (!tr || !flat) return fail(T2_EINVAL, "null argument");
+    t2_model* m = tr->m;
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    EncTape* et = enc_tape_of(tr);
+    if (!et->have_forward) return fail(T2_ESTATE, "t2_train_encoder_forward has not run");
+    const t2_dims& d = m->d;
+    const int E = d.enc_units;
+    const long long n = (long long)tr->B * tr->T;
+    const float bessel = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
+    for (int i = 0; i < d.enc_conv_layers; ++i) {
+        const std::string pn = "encoder/conv1d_" + std::to_string(i) + "/batch_normalization/";
+        const float *mu, *var;
+        T2_TRY(flat_src(tr, flat, pn + "moving_mean", &mu));
+        T2_TRY(flat_src(tr, flat, pn + "moving_variance", &var));
+        hipLaunchKernelGGL(bn_moving_update_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, m->ctx->stream, (float*)mu, (float*)var, et->mean[i], et->var[i],
+                           momentum, bessel, E);
+    }
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}

@@ -261,6 +261,32 @@ class Trainer:
         with eng._ordered():
             _lib.check(eng.lib.t2_train_encoder_backward(self._h, dmemory.data_ptr(), flat_grads.data_ptr()))
 
+    def load_params(self, flat_params: torch.Tensor):
+        """Rebuild every device copy of the weights from the flat parameter buffer (after the optimizer step)."""
+        with self.engine._ordered():
+            _lib.check(self.engine.lib.t2_trainer_load_params(self._h, flat_params.data_ptr()))
+
+    def update_moving_stats(self, flat_params: torch.Tensor, momentum: float = 0.99):
+        """tf.layers.batch_normalization's UPDATE_OPS (models.py:75) for the encoder convs, in place in flat_params."""
+        with self.engine._ordered():
+            _lib.check(self.engine.lib.t2_trainer_update_moving_stats(self._h, flat_params.data_ptr(), float(momentum)))
+
+    def train_step(self, optimizer, flat_params, flat_grads, features, labels, global_step=0, seed=0, prenet_drop_rate=0.5,
+                   encoder_drop_rate=0.5, clip_norm=1.0, group=None):
+        """model_fn(mode=TRAIN) of the reference (models.py:44-76) for the V2 blocks: training-mode forward, loss = spec_loss +
+        binary_loss, backward, gradient all-reduce over the data-parallel group (RCCL), clip_by_global_norm + Adam, moving
+        statistics, weights refreshed on the device.  Returns (global_step + 1, losses dev [3] = mel, done, total)."""
+        flat_grads.zero_()
+        memory, _ = self.encoder_forward(features["source"], features["source_length"], drop_rate=encoder_drop_rate, seed=seed)
+        self.decoder_forward(memory, features["source_length"], labels["mel"], prenet_drop_rate=prenet_drop_rate, seed=seed)
+        dmem, losses = self.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat_grads)
+        self.encoder_backward(dmem, flat_grads)
+        scale = allreduce_gradients(flat_grads, group)
+        step = optimizer.apply_gradients(flat_grads, flat_params, global_step=global_step, clip_norm=clip_norm, grad_scale=scale)
+        self.update_moving_stats(flat_params)
+        self.load_params(flat_params)
+        return step, losses
+
     def close(self):
         if getattr(self, "_h", None) and getattr(self.engine, "_model", None):
             self.engine.lib.t2_trainer_destroy(self._h)

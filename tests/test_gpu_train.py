@@ -168,3 +168,77 @@ def test_full_training_step_gradients_against_autograd(d, B, T, S):
             assert not grads[name].any()
     tr.close()
     eng.close()
+
+
+def test_load_params_and_training_loop_against_oracle():
+    """Device-side weight refresh is exact, and two full training steps (forward, backward, global-norm clip, TF-form Adam,
+    moving statistics, refresh) track the oracle loop (torch autograd gradients + NumPy optimizer block)."""
+    import torch
+    from oracle import torch_train as TT
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    d, B, T, S = MID, 6, 11, 5
+    w = init_weights(d, 13, perturb=True)
+    eng = Engine(d, w)
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    lens = rng.integers(T // 2, T + 1, size=B).astype(np.int64)
+    lens[0] = T
+    labels = _labels(rng, B, S, d.outputs_per_step)
+    labels["mel"] = rng.uniform(0, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+    feats = {"source": ids, "source_length": lens}
+    spec = TR.flatten_spec(w)
+    tr = TR.Trainer(eng, B, T, S)
+    tr.bind_gradients(spec)
+    flat = torch.tensor(TR.flatten(w, spec), device="cuda")
+    # 1. refresh from the same parameters: same inference results (the folded batch-norm affine is recomputed on the device: 1 ulp)
+    mem0 = eng.encode(ids, lens)
+    mel0, _, _ = eng.decode_teacher(mem0, lens, labels["mel"])
+    post0 = eng.postnet(mel0)
+    tr.load_params(flat)
+    mem1 = eng.encode(ids, lens)
+    mel1, _, _ = eng.decode_teacher(mem1, lens, labels["mel"])
+    for a0, a1 in ((mem0, mem1), (mel0, mel1), (post0, eng.postnet(mel1))):
+        assert float((a0 - a1).abs().max()) < 2e-6
+    # 2. two training steps
+    lr = 1e-3
+    opt = TR.AdamOptimizer(eng, flat.numel(), learning_rate=lr)
+    grads = torch.zeros_like(flat)
+    w_ref = {k: v.copy() for k, v in w.items()}
+    m_ref = {k: np.zeros_like(v) for k, v in w.items()}
+    v_ref = {k: np.zeros_like(v) for k, v in w.items()}
+    step = 0
+    for it in range(2):
+        ref = TT.train_forward_backward(d, w_ref, ids, lens, labels, seed=40 + it, prenet_drop_rate=0.5, encoder_drop_rate=0.5)
+        step, losses = tr.train_step(opt, flat, grads, feats, labels, global_step=step, seed=40 + it)
+        assert abs(float(losses[2]) - ref["loss"]) < 2e-4 * max(1.0, abs(ref["loss"])), (it, float(losses[2]), ref["loss"])
+        names = sorted(w_ref)
+        g_list = [ref["grads"].get(k, np.zeros_like(w_ref[k])) for k in names]
+        clipped, _ = O.clip_by_global_norm(g_list, 1.0)
+        n_rows = B * T
+        for k, g in zip(names, clipped):
+            w_ref[k], m_ref[k], v_ref[k] = O.adam_apply(w_ref[k], g, m_ref[k], v_ref[k], it + 1, lr)
+        for i in range(d.enc_conv_layers):                       # UPDATE_OPS
+            p = f"encoder/conv1d_{i}/batch_normalization"
+            mu, var = ref["bn_stats"][f"encoder/conv1d_{i}"]
+            w_ref[f"{p}/moving_mean"] = (0.99 * w_ref[f"{p}/moving_mean"] + 0.01 * mu).astype(np.float32)
+            w_ref[f"{p}/moving_variance"] = (0.99 * w_ref[f"{p}/moving_variance"] + 0.01 * var * n_rows / (n_rows - 1)).astype(np.float32)
+    assert step == 2
+    got = TR.unflatten(flat, spec)
+    for k in ("encoder/conv1d_0/batch_normalization/moving_mean", "encoder/conv1d_2/batch_normalization/moving_variance"):
+        np.testing.assert_allclose(got[k], w_ref[k], rtol=1e-4, atol=1e-6)
+    # parameters moved by at most lr per step and agree with the oracle loop where the gradient is well above the noise
+    for k in ("decoder/lstm_1/kernel", "attention/query_layer/kernel", "encoder/conv1d_1/kernel", "embedding"):
+        assert float(np.abs(got[k] - w[k]).max()) <= 2.05 * lr
+        np.testing.assert_allclose(got[k], w_ref[k], atol=0.25 * lr)
+    # 3. the refreshed model is the model of the new parameters
+    eng2 = Engine(d, got)
+    mem_a, mem_b = eng.encode(ids, lens), eng2.encode(ids, lens)
+    np.testing.assert_allclose(_np(mem_a), _np(mem_b), atol=1e-6)
+    mel_a, _, _ = eng.decode_teacher(mem_a, lens, labels["mel"])
+    mel_b, _, _ = eng2.decode_teacher(mem_b, lens, labels["mel"])
+    np.testing.assert_allclose(_np(mel_a), _np(mel_b), atol=1e-6)
+    np.testing.assert_allclose(_np(eng.postnet(mel_a)), _np(eng2.postnet(mel_b)), atol=1e-6)
+    for o in (tr, eng2, eng):
+        o.close()
+    opt.close()
