@@ -119,13 +119,19 @@ __global__ __launch_bounds__(256) void prenet_bwd_kernel(const float* __restrict
     }
 }
 
-// column sums of a [rows][N] matrix (bias gradients): one thread per column, fixed order
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, long long rows, int N, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// column sums of a [rows][N] matrix (bias gradients), fixed order: stage 1 sums T2_CS_CHUNKS row ranges (64 columns x 4 row
+// lanes per block, double accumulators), stage 2 (batch_sum_kernel) adds the range partials in order
+#define T2_CS_CHUNKS 64
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, long long rows, int N, float* __restrict__ part) {
+    __shared__ double s1[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const long long per = (rows + T2_CS_CHUNKS - 1) / T2_CS_CHUNKS, r0 = blockIdx.y * per, r1 = rows < r0 + per ? rows : r0 + per;
     double s = 0.0;
-    for (long long r = 0; r < rows; ++r) s += (double)x[r * N + c];
-    out[c] = (float)s;
+    if (c < N)
+        for (long long r = r0 + rl; r < r1; r += 4) s += (double)x[r * N + c];
+    s1[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (float)(s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
 }
 
 // sum over the batch of per-row partial gradients part[b][n] -> out[n]
@@ -145,173 +151,373 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, c
     }
 }
 
-// Location-sensitive attention backward for one step, one workgroup per batch row (reference forward:
-// tacotron_v2.py:118-141).  Recomputes f = conv(state_prev) + b_c, pre = keys + (q + b_a) + f . Wloc, tanh(pre).
-//   in : dctx [B][E] (= d/d context of this step), g_state [B][T] (d/d attention state AFTER this step; in / out)
-//   out: dq [B][U] (plain tape + frag16), dkeys / dvalues accumulators [B][T][.], per-row partial parameter gradients
+// ---- location-sensitive attention backward (reference forward: tacotron_v2.py:118-141) -------------------------------
+// The recurrence only needs dq (-> attention LSTM) and d(state_prev) per step; everything else is deferred to tape-wide
+// kernels.  Per step: attention_bwd_kernel, one workgroup per (row, chunk of T2_AB_J positions), recomputes
+// f = conv(state_prev) + b_c, pre = keys + (q + b_a) + f . Wloc, tanh(pre) for its chunk and writes
+//   de [B][T] (d energies, kept tape-wide), dctx [B][E] (kept tape-wide: d values = sum_t a_t (x) dctx_t),
+//   per-chunk partial dq [U] and partial d(state_prev) over the chunk + conv halo;
+// attention_bwd_finish_kernel sums the partials in chunk order (deterministic) into dq (plain + frag16) and g_state.
+// The softmax-backward dot sum_j a_j da_j equals dctx . ctx_t + a . g_state (ctx_t = sum_j a_j values_j is on the tape),
+// which lets every chunk work without the other chunks' da.
+// After the loop attention_param_grad_kernel walks the tape per (row, chunk), recomputes du from de and accumulates
+// d keys and the parameter gradients (v_a, Wloc, conv kernel / bias).
+#define T2_AB_J 16
+#define T2_AB_THREADS 256
+
+struct AbLds {
+    float *sp, *cw, *cb, *wl, *wlT, *f, *du, *df, *dfp, *q, *v, *de;
+    int FP, US;
+};
+
+__host__ __device__ inline int ab_us(int F) {             // u-splits of the df reduction so that all threads work
+    const int items = (T2_AB_J / 4) * F;
+    const int us = T2_AB_THREADS / items;
+    return us < 1 ? 1 : (us > 8 ? 8 : us);
+}
+__host__ __device__ inline int ab_r4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int ab_common_floats(int U, int F, int K) {
+    const int FP = F + 1;
+    return ab_r4(T2_AB_J + K + 8) + ab_r4(K * FP) + ab_r4(F) + ab_r4(F * U) + ab_r4(U * FP) + 2 * ab_r4(T2_AB_J * FP) + ab_r4(T2_AB_J * U) +
+           ab_r4(ab_us(F) * T2_AB_J * FP) + 2 * ab_r4(U) + ab_r4(T2_AB_J);
+}
+__device__ inline float* ab_carve(float* sm, int U, int F, int K, AbLds& L) {
+    const int FP = F + 1;
+    L.FP = FP; L.US = ab_us(F);
+    float* p = sm;
+    L.sp = p; p += ab_r4(T2_AB_J + K + 8);
+    L.cw = p; p += ab_r4(K * FP);
+    L.cb = p; p += ab_r4(F);
+    L.wl = p; p += ab_r4(F * U);
+    L.wlT = p; p += ab_r4(U * FP);
+    L.f = p; p += ab_r4(T2_AB_J * FP);
+    L.df = p; p += ab_r4(T2_AB_J * FP);
+    L.du = p; p += ab_r4(T2_AB_J * U);
+    L.dfp = p; p += ab_r4(L.US * T2_AB_J * FP);
+    L.q = p; p += ab_r4(U);
+    L.v = p; p += ab_r4(U);
+    L.de = p; p += ab_r4(T2_AB_J);
+    return p;
+}
+
+__device__ inline void ab_load_consts(const AbLds& L, const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+                                      const float* __restrict__ wloc, const float* __restrict__ v_a, int U, int F, int K, int tid) {
+    const int FP = L.FP;
+    for (int i = tid; i < K * F; i += T2_AB_THREADS) { const int k = i / F, c = i - k * F; L.cw[k * FP + c] = conv_w[i]; }
+    for (int i = tid; i < F; i += T2_AB_THREADS) L.cb[i] = conv_b[i];
+    for (int i = tid; i < F * U; i += T2_AB_THREADS) {
+        const int c = i / U, u = i - c * U;
+        const float w = wloc[i];
+        L.wl[i] = w; L.wlT[u * FP + c] = w;
+    }
+    for (int i = tid; i < U; i += T2_AB_THREADS) L.v[i] = v_a[i];
+}
+
+// sp[i] <-> attention state before the step at position j0 - pad_l + i
+__device__ inline void ab_load_step(const AbLds& L, const float* __restrict__ state_prev_row, const float* __restrict__ q_row, int j0, int T,
+                                    int U, int K, int tid) {
+    const int pad_l = (K - 1) / 2;
+    for (int i = tid; i < T2_AB_J + K - 1; i += T2_AB_THREADS) {
+        const int p = j0 - pad_l + i;
+        L.sp[i] = (p >= 0 && p < T) ? state_prev_row[p] : 0.f;
+    }
+    for (int i = tid; i < U; i += T2_AB_THREADS) L.q[i] = q_row[i];
+}
+
+__device__ inline void ab_features(const AbLds& L, int F, int K, int tid) {
+    const int FP = L.FP;
+    for (int i = tid; i < T2_AB_J * F; i += T2_AB_THREADS) {
+        const int j = i / F, c = i - j * F;
+        float acc = L.cb[c];
+        for (int k = 0; k < K; ++k) acc = fmaf(L.cw[k * FP + c], L.sp[j + k], acc);
+        L.f[j * FP + c] = acc;
+    }
+}
+
+// du[j][u] = de[j] * v[u] * (1 - tanh(pre)^2) for the jn valid positions of the chunk (zero beyond); thread tile: one unit x
+// four positions.  ACC: also accumulate d keys (registers, dk[4][4]) and the per-(position group, unit) part of d v_a (LDS).
+template <bool ACC>
+__device__ inline void ab_du(const AbLds& L, const float* __restrict__ keys_chunk, int jn, int U, int F, int tid, float (*dk)[4], float* s_dva) {
+    const int FP = L.FP;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int idx = tid + m * T2_AB_THREADS;
+        if (idx < (T2_AB_J / 4) * U) {
+            const int jq = idx / U, u = idx - jq * U, jb = jq * 4;
+            float pre[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) pre[jj] = (jb + jj < jn) ? keys_chunk[(size_t)(jb + jj) * U + u] + L.q[u] : 0.f;
+            for (int c = 0; c < F; ++c) {
+                const float w = L.wl[c * U + u];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) pre[jj] = fmaf(L.f[(jb + jj) * FP + c], w, pre[jj]);
+            }
+            const float vu = L.v[u];
+            float dva = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                float d = 0.f;
+                if (jb + jj < jn) {
+                    const float th = tanhf(pre[jj]), de = L.de[jb + jj];
+                    d = de * vu * (1.f - th * th);
+                    dva = fmaf(de, th, dva);
+                }
+                L.du[(jb + jj) * U + u] = d;
+                if (ACC) dk[m][jj] += d;
+            }
+            if (ACC) s_dva[idx] += dva;
+        }
+    }
+}
+
+// df[j][c] = sum_u du[j][u] * wloc[c][u]; thread tile: one filter x four positions x one u-range, partials summed in range order
+__device__ inline void ab_df(const AbLds& L, int U, int F, int tid) {
+    const int FP = L.FP, US = L.US, items = (T2_AB_J / 4) * F, ur = (U + US - 1) / US;
+    for (int idx = tid; idx < items * US; idx += T2_AB_THREADS) {
+        const int us = idx / items, r = idx - us * items, jq = r / F, c = r - jq * F, jb = jq * 4;
+        const int u0 = us * ur, u1 = min(U, u0 + ur);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int u = u0; u < u1; ++u) {
+            const float w = L.wlT[u * FP + c];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = fmaf(L.du[(jb + jj) * U + u], w, acc[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) L.dfp[(us * T2_AB_J + jb + jj) * FP + c] = acc[jj];
+    }
+    __syncthreads();
+    for (int i = tid; i < T2_AB_J * F; i += T2_AB_THREADS) {
+        const int j = i / F, c = i - j * F;
+        float s = 0.f;
+        for (int us = 0; us < US; ++us) s += L.dfp[(us * T2_AB_J + j) * FP + c];
+        L.df[j * FP + c] = s;
+    }
+}
+
 struct AttnBwdArgs {
     const float *keys, *values;               // [B][T][U], [B][T][E]
     const int* lens;
-    const float *q, *state_prev, *align;      // tape slices of step t: [B][U], [B][T], [B][T]
+    const float *q, *state_prev, *align, *ctx; // tape slices of step t: [B][U] (bias included), [B][T], [B][T], [B][E]
     const float* dctx0; int ld_dctx0;         // d context: sum of two sources (LSTM-1 input part, attention-LSTM input of t + 1)
     const float* dctx1; int ld_dctx1;
-    float* g_state;                           // [B][T]
+    const float* g_state;                     // [B][T] d / d attention state after this step
     const float *conv_w, *conv_b, *wloc, *v_a;
-    float *dq_plain, *dq_frag;                // [B][U]
-    float *dkeys, *dvalues;                   // [B][T][U], [B][T][E]
-    float *p_convw, *p_convb, *p_wloc, *p_va; // per-row partials [B][K*F], [B][F], [B][F*U], [B][U]
-    int B, T, U, E, F, K, MB, cumulative, first;
+    float* de;                                // [B][T] this step's slice of the tape-wide d energies
+    float* dctx_sum; long long ld_dctx_sum;   // row b at dctx_sum + b * ld: this step's slice of the tape-wide d context
+    float *part_dq, *part_ds;                 // [B][NJ][U], [B][NJ][J + K - 1]
+    int B, T, U, E, F, K, NJ, first;
 };
 
-#define T2_ABWD_THREADS 256
-__host__ __device__ inline int attn_bwd_lds_floats(int T, int U, int E, int F, int K) {
-    return (T + K + 8) + 4 * (T + 4) + 2 * T * (F + 1) + T * U + F * U + 2 * U + 2 * (T2_ABWD_THREADS / 64) * U + E + 64;
-}
+__host__ __device__ inline int attn_bwd_lds_floats(int U, int E, int F, int K) { return ab_common_floats(U, F, K) + ab_r4(E) + 64; }
 
-__global__ __launch_bounds__(T2_ABWD_THREADS) void attention_bwd_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = T2_ABWD_THREADS / 64;
-    const int T = a.T, U = a.U, E = a.E, F = a.F, K = a.K, FP = F + 1;
-    const int pad_l = (K - 1) / 2;
-    const int len = a.lens[b];
-    float* s_sp = sm;                         // [T + K + 8]: index i <-> position i - pad_l
-    float* s_a = s_sp + (T + K + 8);          // [T + 4] alignments
-    float* s_da = s_a + (T + 4);              // [T + 4]
-    float* s_de = s_da + (T + 4);             // [T + 4]
-    float* s_ds = s_de + (T + 4);             // [T + 4] d state_prev
-    float* s_f = s_ds + (T + 4);              // [T][FP]
-    float* s_df = s_f + T * FP;               // [T][FP]
-    float* s_du = s_df + T * FP;              // [T][U]
-    float* s_wl = s_du + T * U;               // [F][U]
-    float* s_q = s_wl + F * U;                // [U] q + b_a
-    float* s_v = s_q + U;                     // [U]
-    float* s_dq = s_v + U;                    // [NW][U] per-wave partial sums (summed in wave order: deterministic)
-    float* s_dva = s_dq + NW * U;             // [NW][U]
-    float* s_dctx = s_dva + NW * U;           // [E]
-    float* s_red = s_dctx + E;                // [64]
-    for (int i = tid; i < T + K + 8; i += T2_ABWD_THREADS) {
-        const int p = i - pad_l;
-        s_sp[i] = (p >= 0 && p < T) ? a.state_prev[(size_t)b * T + p] : 0.f;
-    }
-    for (int i = tid; i < T; i += T2_ABWD_THREADS) s_a[i] = a.align[(size_t)b * T + i];
-    for (int i = tid; i < F * U; i += T2_ABWD_THREADS) s_wl[i] = a.wloc[i];
-    for (int i = tid; i < U; i += T2_ABWD_THREADS) { s_q[i] = a.q[(size_t)b * U + i]; s_v[i] = a.v_a[i]; }
-    for (int i = tid; i < E; i += T2_ABWD_THREADS) {
+    const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = T2_AB_THREADS / 64, J = T2_AB_J;
+    const int T = a.T, U = a.U, E = a.E, F = a.F, K = a.K;
+    const int len = a.lens[b], j0 = ch * J;
+    if (ch > 0 && j0 >= len) return;          // masked chunk: its partials stay zero (workspace zeroed per call)
+    const int jn = max(0, min(J, len - j0));
+    AbLds L;
+    float* s_dctx = ab_carve(sm, U, F, K, L);
+    float* s_red = s_dctx + ab_r4(E);         // [NW] dot partials, [16..32) da
+    ab_load_consts(L, a.conv_w, a.conv_b, a.wloc, a.v_a, U, F, K, tid);
+    ab_load_step(L, a.state_prev + (size_t)b * T, a.q + (size_t)b * U, j0, T, U, K, tid);
+    float part = 0.f;
+    for (int i = tid; i < E; i += T2_AB_THREADS) {
         float v = 0.f;
         if (a.dctx0) v += a.dctx0[(size_t)b * a.ld_dctx0 + i];
         if (a.dctx1) v += a.dctx1[(size_t)b * a.ld_dctx1 + i];
         s_dctx[i] = v;
+        if (ch == 0) a.dctx_sum[(size_t)b * a.ld_dctx_sum + i] = v;
+        part = fmaf(v, a.ctx[(size_t)b * E + i], part);
     }
-    __syncthreads();
-    // location features f[j][c] = sum_k w[k][c] * state_prev[j + k - pad_l] + b[c]
-    for (int i = tid; i < T * F; i += T2_ABWD_THREADS) {
-        const int j = i / F, c = i - j * F;
-        float acc = a.conv_b[c];
-        for (int k = 0; k < K; ++k) acc = fmaf(a.conv_w[k * F + c], s_sp[j + k], acc);
-        s_f[j * FP + c] = acc;
-    }
-    // d alignments: da_j = dctx . values[j] + (d state after this step); dvalues[j] += a_j * dctx
-    const float* vals = a.values + (size_t)b * T * E;
-    float* dvals = a.dvalues + (size_t)b * T * E;
-    for (int j = wave; j < T; j += NW) {
-        float acc = 0.f;
-        const float aj = s_a[j];
-        for (int c = lane; c < E; c += 64) {
-            acc = fmaf(s_dctx[c], vals[(size_t)j * E + c], acc);
-            dvals[(size_t)j * E + c] += aj * s_dctx[c];
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) s_da[j] = acc + (a.first ? 0.f : a.g_state[(size_t)b * T + j]);
-    }
-    __syncthreads();
-    // softmax backward over the valid positions
-    float part = 0.f;
-    for (int j = tid; j < len; j += T2_ABWD_THREADS) part += s_a[j] * s_da[j];
+    if (!a.first)
+        for (int j = tid; j < len; j += T2_AB_THREADS) part = fmaf(a.align[(size_t)b * T + j], a.g_state[(size_t)b * T + j], part);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if (lane == 0) s_red[wave] = part;
     __syncthreads();
-    float dot = 0.f;
-    for (int w = 0; w < NW; ++w) dot += s_red[w];
-    for (int j = tid; j < T; j += T2_ABWD_THREADS) s_de[j] = j < len ? s_a[j] * (s_da[j] - dot) : 0.f;
+    ab_features(L, F, K, tid);
+    // d alignments of the chunk: da_j = dctx . values[j] + d state after this step
+    const float* vals = a.values + ((size_t)b * T + j0) * E;
+    for (int j = wave; j < jn; j += NW) {
+        float acc = 0.f;
+        for (int c = lane; c < E; c += 64) acc = fmaf(s_dctx[c], vals[(size_t)j * E + c], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) s_red[16 + j] = acc + (a.first ? 0.f : a.g_state[(size_t)b * T + j0 + j]);
+    }
     __syncthreads();
-    // energies backward: one wave per position, lanes over units
-    const float* keys = a.keys + (size_t)b * T * U;
-    float* dkeys = a.dkeys + (size_t)b * T * U;
-    for (int u0 = 0; u0 < U; u0 += 64) {
-        const int u = u0 + lane;
-        float dq_acc = 0.f, dva_acc = 0.f;
-        for (int j = wave; j < T; j += NW) {
-            float du = 0.f;
-            if (u < U && j < len) {
-                float pre = keys[(size_t)j * U + u] + s_q[u];
-                for (int c = 0; c < F; ++c) pre = fmaf(s_f[j * FP + c], s_wl[c * U + u], pre);
-                const float th = tanhf(pre);
-                const float de = s_de[j];
-                du = de * s_v[u] * (1.f - th * th);
-                dva_acc = fmaf(de, th, dva_acc);
-                dq_acc += du;
-                dkeys[(size_t)j * U + u] += du;
-            }
-            if (u < U) s_du[j * U + u] = du;
+    if (tid < J) {
+        float dot = 0.f;
+        for (int w = 0; w < NW; ++w) dot += s_red[w];
+        const float de = tid < jn ? a.align[(size_t)b * T + j0 + tid] * (s_red[16 + tid] - dot) : 0.f;
+        L.de[tid] = de;
+        if (j0 + tid < T) a.de[(size_t)b * T + j0 + tid] = de;
+    }
+    __syncthreads();
+    ab_du<false>(L, a.keys + ((size_t)b * T + j0) * U, jn, U, F, tid, nullptr, nullptr);
+    __syncthreads();
+    for (int u = tid; u < U; u += T2_AB_THREADS) {
+        float s = 0.f;
+        for (int j = 0; j < J; ++j) s += L.du[j * U + u];
+        a.part_dq[((size_t)b * a.NJ + ch) * U + u] = s;
+    }
+    ab_df(L, U, F, tid);
+    __syncthreads();
+    // partial d state_prev over the chunk + halo: ds[i] = sum_{j, c} w[i - j][c] * df[j][c], i <-> position j0 - pad_l + i
+    const int NI = J + K - 1, FP = L.FP;
+    for (int i0 = 0; i0 < NI; i0 += T2_AB_THREADS / 4) {
+        const int i = i0 + (tid >> 2), cg = tid & 3;
+        float acc = 0.f;
+        if (i < NI) {
+            const int ja = max(0, i - K + 1), jb = min(jn - 1, i);
+            for (int j = ja; j <= jb; ++j)
+                for (int c = cg; c < F; c += 4) acc = fmaf(L.cw[(i - j) * FP + c], L.df[j * FP + c], acc);
         }
-        if (u < U) { s_dq[wave * U + u] = dq_acc; s_dva[wave * U + u] = dva_acc; }
-    }
-    __syncthreads();
-    // df[j][c] = sum_u du[j][u] * wloc[c][u]
-    for (int i = tid; i < T * F; i += T2_ABWD_THREADS) {
-        const int j = i / F, c = i - j * F;
-        float acc = 0.f;
-        for (int u = 0; u < U; ++u) acc = fmaf(s_du[j * U + u], s_wl[c * U + u], acc);
-        s_df[j * FP + c] = acc;
-    }
-    // d wloc[c][u] += sum_j f[j][c] * du[j][u]
-    float* p_wloc = a.p_wloc + (size_t)b * F * U;
-    for (int i = tid; i < F * U; i += T2_ABWD_THREADS) {
-        const int c = i / U, u = i - c * U;
-        float acc = 0.f;
-        for (int j = 0; j < len; ++j) acc = fmaf(s_f[j * FP + c], s_du[j * U + u], acc);
-        p_wloc[i] += acc;
-    }
-    __syncthreads();
-    // conv backward
-    float* p_convw = a.p_convw + (size_t)b * K * F;
-    for (int i = tid; i < K * F; i += T2_ABWD_THREADS) {
-        const int k = i / F, c = i - k * F;
-        float acc = 0.f;
-        for (int j = 0; j < len; ++j) acc = fmaf(s_sp[j + k], s_df[j * FP + c], acc);
-        p_convw[i] += acc;
-    }
-    for (int c = tid; c < F; c += T2_ABWD_THREADS) {
-        float acc = 0.f;
-        for (int j = 0; j < len; ++j) acc += s_df[j * FP + c];
-        a.p_convb[(size_t)b * F + c] += acc;
-    }
-    for (int i = tid; i < T; i += T2_ABWD_THREADS) {           // d state_prev[i] = sum_{k,c} w[k][c] * df[i - k + pad_l][c]
-        float acc = 0.f;
-        for (int k = 0; k < K; ++k) {
-            const int j = i - k + pad_l;
-            if (j < 0 || j >= len) continue;
-            for (int c = 0; c < F; ++c) acc = fmaf(a.conv_w[k * F + c], s_df[j * FP + c], acc);
-        }
-        s_ds[i] = acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < T; i += T2_ABWD_THREADS) {
-        const float carry = (a.cumulative && !a.first) ? a.g_state[(size_t)b * T + i] : 0.f;   // state_t = state_{t-1} + a_t
-        a.g_state[(size_t)b * T + i] = carry + s_ds[i];
-    }
-    for (int u = tid; u < U; u += T2_ABWD_THREADS) {
-        float dq = 0.f, dva = 0.f;
-        for (int w = 0; w < NW; ++w) { dq += s_dq[w * U + u]; dva += s_dva[w * U + u]; }
-        a.dq_plain[(size_t)b * U + u] = dq;
-        a.dq_frag[frag_idx(b, u, a.MB)] = dq;
-        a.p_va[(size_t)b * U + u] += dva;
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (i < NI && cg == 0) a.part_ds[((size_t)b * a.NJ + ch) * NI + i] = acc;
     }
 }
 
+struct AttnBwdFinishArgs {
+    const float *part_dq, *part_ds;
+    float *dq_plain, *dq_frag, *g_state;
+    int B, T, U, K, NJ, MB, cumulative, first;
+};
+
+__global__ __launch_bounds__(256) void attention_bwd_finish_kernel(AttnBwdFinishArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x, NI = T2_AB_J + a.K - 1, pad_l = (a.K - 1) / 2;
+    for (int u = tid; u < a.U; u += 256) {
+        float s = 0.f;
+        for (int ch = 0; ch < a.NJ; ++ch) s += a.part_dq[((size_t)b * a.NJ + ch) * a.U + u];
+        a.dq_plain[(size_t)b * a.U + u] = s;
+        a.dq_frag[frag_idx(b, u, a.MB)] = s;
+    }
+    for (int p = tid; p < a.T; p += 256) {
+        float s = (a.cumulative && !a.first) ? a.g_state[(size_t)b * a.T + p] : 0.f;    // state_t = state_{t-1} + a_t
+        for (int ch = 0; ch < a.NJ; ++ch) {
+            const int i = p - (ch * T2_AB_J - pad_l);
+            if (i >= 0 && i < NI) s += a.part_ds[((size_t)b * a.NJ + ch) * NI + i];
+        }
+        a.g_state[(size_t)b * a.T + p] = s;
+    }
+}
+
+// Tape-wide part: one workgroup per (chunk, row, step segment) walks its steps, recomputes du from the taped de / q /
+// state_prev and accumulates d keys (registers) and the per-workgroup partial parameter gradients (LDS).
+struct AttnParamArgs {
+    const float* keys; const int* lens;
+    const float *q, *state_prev, *de;         // tape-wide [S][B][U], [S][B][T], [S][B][T]
+    const float *conv_w, *conv_b, *wloc, *v_a;
+    float* dkeys_part;                        // [NS][B][T][U]
+    float *p_convw, *p_convb, *p_wloc, *p_va; // [NP][K*F], [NP][F], [NP][F*U], [NP][U]; NP = NS * B * NJ
+    int B, T, U, F, K, NJ, S, NS;
+};
+
+__host__ __device__ inline int attn_param_lds_floats(int U, int F, int K) {
+    return ab_common_floats(U, F, K) + ab_r4(F * U) + ab_r4(K * F) + ab_r4(F) + ab_r4((T2_AB_J / 4) * U);
+}
+
+__global__ __launch_bounds__(T2_AB_THREADS) void attention_param_grad_kernel(AttnParamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ch = blockIdx.x, b = blockIdx.y, ns = blockIdx.z, tid = threadIdx.x;
+    constexpr int J = T2_AB_J;
+    const int T = a.T, U = a.U, F = a.F, K = a.K, B = a.B;
+    const int len = a.lens[b], j0 = ch * J;
+    if (j0 >= len) return;                    // masked chunk: outputs stay zero (workspace zeroed per call)
+    const int jn = min(J, len - j0);
+    AbLds L;
+    float* s_dwl = ab_carve(sm, U, F, K, L);
+    float* s_dcw = s_dwl + ab_r4(F * U);
+    float* s_dcb = s_dcw + ab_r4(K * F);
+    float* s_dva = s_dcb + ab_r4(F);
+    const int FP = L.FP;
+    ab_load_consts(L, a.conv_w, a.conv_b, a.wloc, a.v_a, U, F, K, tid);
+    for (int i = tid; i < F * U; i += T2_AB_THREADS) s_dwl[i] = 0.f;
+    for (int i = tid; i < K * F; i += T2_AB_THREADS) s_dcw[i] = 0.f;
+    for (int i = tid; i < F; i += T2_AB_THREADS) s_dcb[i] = 0.f;
+    for (int i = tid; i < (J / 4) * U; i += T2_AB_THREADS) s_dva[i] = 0.f;
+    float dk[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dk[m][jj] = 0.f;
+    const int per = (a.S + a.NS - 1) / a.NS, t0 = ns * per, t1 = min(a.S, t0 + per);
+    const float* keys_chunk = a.keys + ((size_t)b * T + j0) * U;
+    const int FG = (F + 3) / 4;
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();
+        ab_load_step(L, a.state_prev + ((size_t)t * B + b) * T, a.q + ((size_t)t * B + b) * U, j0, T, U, K, tid);
+        if (tid < J) L.de[tid] = tid < jn ? a.de[((size_t)t * B + b) * T + j0 + tid] : 0.f;
+        __syncthreads();
+        ab_features(L, F, K, tid);
+        __syncthreads();
+        ab_du<true>(L, keys_chunk, jn, U, F, tid, dk, s_dva);
+        __syncthreads();
+        ab_df(L, U, F, tid);
+        // d Wloc[c][u] += sum_j f[j][c] * du[j][u]; thread tile: one unit x four filters
+        for (int idx = tid; idx < FG * U; idx += T2_AB_THREADS) {
+            const int cq = idx / U, u = idx - cq * U, c0 = cq * 4;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < jn; ++j) {
+                const float d = L.du[j * U + u];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) acc[cc] = fmaf(L.f[j * FP + min(c0 + cc, F - 1)], d, acc[cc]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                if (c0 + cc < F) s_dwl[(c0 + cc) * U + u] += acc[cc];
+        }
+        __syncthreads();
+        for (int i = tid; i < K * F; i += T2_AB_THREADS) {
+            const int k = i / F, c = i - k * F;
+            float acc = 0.f;
+            for (int j = 0; j < jn; ++j) acc = fmaf(L.sp[j + k], L.df[j * FP + c], acc);
+            s_dcw[i] += acc;
+        }
+        for (int c = tid; c < F; c += T2_AB_THREADS) {
+            float acc = 0.f;
+            for (int j = 0; j < jn; ++j) acc += L.df[j * FP + c];
+            s_dcb[c] += acc;
+        }
+    }
+    __syncthreads();
+    float* dkp = a.dkeys_part + (((size_t)ns * B + b) * T + j0) * U;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int idx = tid + m * T2_AB_THREADS;
+        if (idx < (J / 4) * U) {
+            const int jq = idx / U, u = idx - jq * U;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jq * 4 + jj < jn) dkp[(size_t)(jq * 4 + jj) * U + u] = dk[m][jj];
+        }
+    }
+    const size_t wg = ((size_t)ns * B + b) * a.NJ + ch;
+    for (int i = tid; i < F * U; i += T2_AB_THREADS) a.p_wloc[wg * F * U + i] = s_dwl[i];
+    for (int i = tid; i < K * F; i += T2_AB_THREADS) a.p_convw[wg * K * F + i] = s_dcw[i];
+    for (int i = tid; i < F; i += T2_AB_THREADS) a.p_convb[wg * F + i] = s_dcb[i];
+    for (int u = tid; u < U; u += T2_AB_THREADS) {
+        float s = 0.f;
+        for (int jq = 0; jq < J / 4; ++jq) s += s_dva[jq * U + u];
+        a.p_va[wg * U + u] = s;
+    }
+}
+
+// xin[t][b][:] = targets[b][t - 1][-M*nf:] (t >= 1), zeros at t = 0: inputs of PreNet layer 0 over the whole tape
+__global__ __launch_bounds__(256) void feed_gather_kernel(const float* __restrict__ targets, float* __restrict__ xin, int B, int S, int M, int r, int nf) {
+    const int W = M * nf;
+    const long long n = (long long)S * B * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % W);
+        const long long tb = i / W;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        xin[i] = t == 0 ? 0.f : targets[((size_t)b * S + (t - 1)) * r * M + (size_t)M * (r - nf) + c];
+    }
+}
 
 struct BwdOperand {             // skinny dense operand holding W^T of a TF-layout [rows][cols] variable: K = cols, N = rows
     Packed p;
@@ -335,7 +541,10 @@ struct t2_trainer {
     float *dX[3] = {}, *dy2 = nullptr, *dhq = nullptr, *dxp = nullptr;
     float *g_c[3] = {}, *g_hp[3] = {}, *g_state = nullptr;
     float *dkeys = nullptr, *dvalues = nullptr, *p_convw = nullptr, *p_convb = nullptr, *p_wloc = nullptr, *p_va = nullptr;
+    float *de_all = nullptr, *dctx_all = nullptr, *part_dq = nullptr, *part_ds = nullptr, *dkeys_part = nullptr;
+    int NJ = 0, NS = 1;                 // attention backward: position chunks per row, step segments of the tape-wide kernel
     float *tmp = nullptr, *loss3 = nullptr;
+    float* cs_part = nullptr; int cs_cols = 0;     // column-sum partials [T2_CS_CHUNKS][cs_cols]
     std::map<std::string, long long> offsets;      // flat-gradient layout given by the caller
 };
 
@@ -364,6 +573,7 @@ extern "C" int t2_trainer_destroy(t2_trainer* tr) {
     enc_tape_release(tr);
     if (tr->slab) (void)hipFree(tr->slab);
     if (tr->bslab) (void)hipFree(tr->bslab);
+    if (tr->cs_part) (void)hipFree(tr->cs_part);
     for (void* p : tr->allocs) (void)hipFree(p);
     if (tr->state) state_free(tr->state);
     delete tr;
@@ -495,8 +705,13 @@ static int trainer_setup_backward(t2_trainer* tr) {
     for (int i = 0; i < np; ++i) { o_dpre[i] = carve(SB * d.prenet_units[i]); o_dpref[i] = carve((size_t)R * pad16(d.prenet_units[i])); pmax = std::max(pmax, d.prenet_units[i]); }
     const size_t o_xin = carve(SB * M * nf), o_dy2 = carve((size_t)B * D), o_dhq = carve((size_t)B * A), o_dxp = carve((size_t)B * pmax);
     const size_t o_gs = carve((size_t)B * T), o_dk = carve((size_t)B * T * U), o_dv = carve((size_t)B * T * E);
-    const size_t o_pcw = carve((size_t)B * d.attention_kernel * d.attention_filters), o_pcb = carve((size_t)B * d.attention_filters),
-                 o_pwl = carve((size_t)B * d.attention_filters * U), o_pva = carve((size_t)B * U);
+    const int NJ = ceil_div(T, T2_AB_J), NS = std::max(1, std::min({8, S, ceil_div(512, NJ * B)}));
+    const size_t NP = (size_t)NS * B * NJ;
+    tr->NJ = NJ; tr->NS = NS;
+    const size_t o_pcw = carve(NP * d.attention_kernel * d.attention_filters), o_pcb = carve(NP * d.attention_filters),
+                 o_pwl = carve(NP * d.attention_filters * U), o_pva = carve(NP * U);
+    const size_t o_de = carve(SB * T), o_dctx = carve(SB * E), o_pdq = carve((size_t)B * NJ * U),
+                 o_pds = carve((size_t)B * NJ * (T2_AB_J + d.attention_kernel - 1)), o_dkp = carve((size_t)NS * B * T * U);
     const size_t o_tmp = carve((size_t)std::max(D * N, 4096)), o_loss = carve(16);
     tr->bslab_bytes = off;
     HIP_TRY(hipMalloc(&tr->bslab, off));
@@ -512,15 +727,32 @@ static int trainer_setup_backward(t2_trainer* tr) {
     tr->g_state = (float*)(p + o_gs); tr->dkeys = (float*)(p + o_dk); tr->dvalues = (float*)(p + o_dv);
     tr->p_convw = (float*)(p + o_pcw); tr->p_convb = (float*)(p + o_pcb); tr->p_wloc = (float*)(p + o_pwl); tr->p_va = (float*)(p + o_pva);
     tr->tmp = (float*)(p + o_tmp); tr->loss3 = (float*)(p + o_loss);
-    const size_t lds = (size_t)attn_bwd_lds_floats(T, U, E, d.attention_filters, d.attention_kernel) * 4;
-    if (lds > 150 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention backward kernel's LDS", T);
+    tr->de_all = (float*)(p + o_de); tr->dctx_all = (float*)(p + o_dctx); tr->part_dq = (float*)(p + o_pdq); tr->part_ds = (float*)(p + o_pds);
+    tr->dkeys_part = (float*)(p + o_dkp);
+    const size_t lds = (size_t)std::max(attn_bwd_lds_floats(U, E, d.attention_filters, d.attention_kernel),
+                                        attn_param_lds_floats(U, d.attention_filters, d.attention_kernel)) * 4;
+    if (lds > 150 * 1024) return fail(T2_EINVAL, "attention dimensions too large for the attention backward kernels' LDS");
     HIP_TRY(hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)attention_param_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return T2_OK;
 }
 
 extern "C" int t2_trainer_bind_gradient(t2_trainer* tr, const char* name, int64_t offset) {
     if (!tr || !name || offset < 0 || (offset & 3) != 0) return fail(T2_EINVAL, "bad argument (offsets are multiples of 4 floats)");
     tr->offsets[name] = offset;
+    return T2_OK;
+}
+
+// out[N] = column sums of x [rows][N]
+static int col_sum(t2_trainer* tr, const float* x, long long rows, int N, float* out) {
+    if (N > tr->cs_cols) {
+        if (tr->cs_part) { HIP_TRY(hipStreamSynchronize(tr->m->ctx->stream)); (void)hipFree(tr->cs_part); tr->cs_part = nullptr; }
+        tr->cs_cols = std::max(N, 4096);
+        HIP_TRY(hipMalloc((void**)&tr->cs_part, (size_t)T2_CS_CHUNKS * tr->cs_cols * 4));
+    }
+    hipStream_t st = tr->m->ctx->stream;
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(ceil_div(N, 64), T2_CS_CHUNKS), dim3(256), 0, st, x, rows, N, tr->cs_part);
+    hipLaunchKernelGGL(batch_sum_kernel, dim3(std::max(1, std::min(1024, ceil_div(N, 256)))), dim3(256), 0, st, tr->cs_part, T2_CS_CHUNKS, (long long)N, out);
     return T2_OK;
 }
 
@@ -588,7 +820,8 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     hipLaunchKernelGGL(loss_grad_kernel, dim3(std::min<long long>(2048, (SB * N + 255) / 256)), dim3(256), 0, st, s->o_mel, s->i_targets,
                        spec_mask, s->o_stop, done, bin_mask, l3 + 1, l3 + 5, tr->dY, B, S, M, r);
     auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (n + 255) / 256))); };
-    const size_t lds = (size_t)attn_bwd_lds_floats(T, U, E, F, K) * 4;
+    const size_t lds = (size_t)attn_bwd_lds_floats(U, E, F, K) * 4;
+    const int NJ = tr->NJ, NS = tr->NS;
     for (int t = S - 1; t >= 0; --t) {
         const int first = (t == S - 1) ? 1 : 0;
         auto lstm_bwd = [&](int l, const float* go0, int ld0, const float* go1, int ld1, const float* gh1, int ldh1) {
@@ -616,13 +849,18 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
             AttnBwdArgs a{};
             a.keys = s->keys; a.values = s->values; a.lens = s->lens;
             a.q = tp.q + (size_t)t * B * U; a.state_prev = tp.state_prev + (size_t)t * B * T; a.align = s->o_hist + (size_t)t * B * T;
+            a.ctx = tp.ctx + (size_t)t * B * E;
             a.dctx0 = tr->dX[1] + A; a.ld_dctx0 = KX[1];
             a.dctx1 = first ? nullptr : tr->dX[0] + P_last; a.ld_dctx1 = KX[0];
             a.g_state = tr->g_state; a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a;
-            a.dq_plain = tr->dq + (size_t)t * B * U; a.dq_frag = tr->dqf; a.dkeys = tr->dkeys; a.dvalues = tr->dvalues;
-            a.p_convw = tr->p_convw; a.p_convb = tr->p_convb; a.p_wloc = tr->p_wloc; a.p_va = tr->p_va;
-            a.B = B; a.T = T; a.U = U; a.E = E; a.F = F; a.K = K; a.MB = MB; a.cumulative = d.cumulative_weights; a.first = first;
-            hipLaunchKernelGGL(attention_bwd_kernel, dim3(B), dim3(T2_ABWD_THREADS), lds, st, a);
+            a.de = tr->de_all + (size_t)t * B * T; a.dctx_sum = tr->dctx_all + (size_t)t * E; a.ld_dctx_sum = (long long)S * E;
+            a.part_dq = tr->part_dq; a.part_ds = tr->part_ds;
+            a.B = B; a.T = T; a.U = U; a.E = E; a.F = F; a.K = K; a.NJ = NJ; a.first = first;
+            hipLaunchKernelGGL(attention_bwd_kernel, dim3(NJ, B), dim3(T2_AB_THREADS), lds, st, a);
+            AttnBwdFinishArgs f{};
+            f.part_dq = tr->part_dq; f.part_ds = tr->part_ds; f.dq_plain = tr->dq + (size_t)t * B * U; f.dq_frag = tr->dqf; f.g_state = tr->g_state;
+            f.B = B; f.T = T; f.U = U; f.K = K; f.NJ = NJ; f.MB = MB; f.cumulative = d.cumulative_weights; f.first = first;
+            hipLaunchKernelGGL(attention_bwd_finish_kernel, dim3(B), dim3(256), 0, st, f);
         }
         bwd_dense(tr, tr->wqT, tr->dqf, tr->dhq, A);
         // attention LSTM: input [prenet out | ctx_prev | h_att_prev]; raw output feeds LSTM 1 and the query layer
@@ -652,7 +890,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         HIP_TRY(hipMemcpy2DAsync(g, (size_t)M * r * 4, tr->tmp, (size_t)N * 4, (size_t)M * r * 4, D, hipMemcpyDeviceToDevice, st));
         T2_TRY(grad_dst(tr, flat_grads, "decoder/stop_token_projection/kernel", &g));
         HIP_TRY(hipMemcpy2DAsync(g, 4, tr->tmp + M * r, (size_t)N * 4, 4, D, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, tr->dY, (long long)SB, N, tr->dYf);
+        T2_TRY(col_sum(tr, tr->dY, (long long)SB, N, tr->dYf));
         T2_TRY(grad_dst(tr, flat_grads, "decoder/out_projection/bias", &g));
         HIP_TRY(hipMemcpyAsync(g, tr->dYf, (size_t)M * r * 4, hipMemcpyDeviceToDevice, st));
         T2_TRY(grad_dst(tr, flat_grads, "decoder/stop_token_projection/bias", &g));
@@ -679,30 +917,37 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
             if (S > 1) T2_TRY(bwd_wgrad(tr, tp.hstate[2], D, D, dz1, n4, n4, rows1, g + (size_t)D * n4, n4));
         }
         T2_TRY(grad_dst(tr, flat_grads, std::string(lname[l]) + "/bias", &g));
-        hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, st, dz, (long long)SB, n4, g);
+        T2_TRY(col_sum(tr, dz, (long long)SB, n4, g));
     }
     // query layer, attention parameters
     T2_TRY(grad_dst(tr, flat_grads, "attention/query_layer/kernel", &g));
     T2_TRY(bwd_wgrad(tr, tp.hraw[0], A, A, tr->dq, U, U, SB, g, U));
     T2_TRY(grad_dst(tr, flat_grads, "attention/attention_bias", &g));
-    hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(U, 256)), dim3(256), 0, st, tr->dq, (long long)SB, U, g);
-    T2_TRY(grad_dst(tr, flat_grads, "attention/attention_variable", &g));
-    hipLaunchKernelGGL(batch_sum_kernel, grid1(U), dim3(256), 0, st, tr->p_va, B, (long long)U, g);
-    T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/kernel", &g));
-    hipLaunchKernelGGL(batch_sum_kernel, grid1(K * F), dim3(256), 0, st, tr->p_convw, B, (long long)K * F, g);
-    T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/bias", &g));
-    hipLaunchKernelGGL(batch_sum_kernel, grid1(F), dim3(256), 0, st, tr->p_convb, B, (long long)F, g);
-    T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_layer/kernel", &g));
-    hipLaunchKernelGGL(batch_sum_kernel, grid1(F * U), dim3(256), 0, st, tr->p_wloc, B, (long long)F * U, g);
+    T2_TRY(col_sum(tr, tr->dq, (long long)SB, U, g));
+    {   // tape-wide attention pass: d keys and the parameter gradients from the taped d energies
+        AttnParamArgs a{};
+        a.keys = s->keys; a.lens = s->lens; a.q = tp.q; a.state_prev = tp.state_prev; a.de = tr->de_all;
+        a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a;
+        a.dkeys_part = tr->dkeys_part; a.p_convw = tr->p_convw; a.p_convb = tr->p_convb; a.p_wloc = tr->p_wloc; a.p_va = tr->p_va;
+        a.B = B; a.T = T; a.U = U; a.F = F; a.K = K; a.NJ = NJ; a.S = S; a.NS = NS;
+        hipLaunchKernelGGL(attention_param_grad_kernel, dim3(NJ, B, NS), dim3(T2_AB_THREADS), (size_t)attn_param_lds_floats(U, F, K) * 4, st, a);
+        const int NP = NS * B * NJ;
+        hipLaunchKernelGGL(batch_sum_kernel, grid1((long long)B * T * U), dim3(256), 0, st, tr->dkeys_part, NS, (long long)B * T * U, tr->dkeys);
+        T2_TRY(grad_dst(tr, flat_grads, "attention/attention_variable", &g));
+        hipLaunchKernelGGL(batch_sum_kernel, grid1(U), dim3(256), 0, st, tr->p_va, NP, (long long)U, g);
+        T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/kernel", &g));
+        hipLaunchKernelGGL(batch_sum_kernel, grid1(K * F), dim3(256), 0, st, tr->p_convw, NP, (long long)K * F, g);
+        T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/bias", &g));
+        hipLaunchKernelGGL(batch_sum_kernel, grid1(F), dim3(256), 0, st, tr->p_convb, NP, (long long)F, g);
+        T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_layer/kernel", &g));
+        hipLaunchKernelGGL(batch_sum_kernel, grid1(F * U), dim3(256), 0, st, tr->p_wloc, NP, (long long)F * U, g);
+        // d values[b][j][:] = sum_t a_t[b][j] * dctx_t[b][:]: one [T x S] . [S x E] product per row
+        for (int b = 0; b < B; ++b)
+            T2_TRY(bwd_wgrad(tr, s->o_hist + (size_t)b * T, B * T, T, tr->dctx_all + (size_t)b * S * E, E, E, S, tr->dvalues + (size_t)b * T * E, E));
+    }
     // PreNets: inputs of layer 0 are the teacher-forced frames (go frame at t = 0)
     {
-        FeedArgs f{};
-        (void)f;
-        // xin[t][b][:] = targets[b][t - 1][-M*nf:]  (t >= 1); zeros at t = 0 (buffer zeroed above)
-        for (int t = 1; t < S; ++t)
-            HIP_TRY(hipMemcpy2DAsync(tr->xin + (size_t)t * B * M * nf, (size_t)M * nf * 4,
-                                     s->i_targets + (size_t)(t - 1) * r * M + (size_t)M * (r - nf), (size_t)S * r * M * 4,
-                                     (size_t)M * nf * 4, B, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(feed_gather_kernel, grid1((long long)SB * M * nf), dim3(256), 0, st, s->i_targets, tr->xin, B, S, M, r, nf);
     }
     for (int i = 0; i < np; ++i) {
         const int P = d.prenet_units[i];
@@ -712,7 +957,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         T2_TRY(grad_dst(tr, flat_grads, pn + "/kernel", &g));
         T2_TRY(bwd_wgrad(tr, x, Kin, Kin, tr->dpre[i], P, P, SB, g, P));
         T2_TRY(grad_dst(tr, flat_grads, pn + "/bias", &g));
-        hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, tr->dpre[i], (long long)SB, P, g);
+        T2_TRY(col_sum(tr, tr->dpre[i], (long long)SB, P, g));
     }
     // memory layer and d(memory): keys = values . Wmem, values = memory * mask
     T2_TRY(grad_dst(tr, flat_grads, "attention/memory_layer/kernel", &g));
@@ -1090,7 +1335,7 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
         if (T > 1) T2_TRY(bwd_wgrad(tr, et->hstate[dir], He, He, et->dzp + (size_t)B * n4, n4, n4, (long long)(T - 1) * B, g + (size_t)Cx * n4, n4));
         else HIP_TRY(hipMemsetAsync(g + (size_t)Cx * n4, 0, (size_t)He * n4 * 4, st));
         T2_TRY(grad_dst(tr, flat_grads, pn + "/bias", &g));
-        hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, st, et->dzp, (long long)T * B, n4, g);
+        T2_TRY(col_sum(tr, et->dzp, (long long)T * B, n4, g));
     }
     // conv stack: dropout / relu / batch-statistics batch norm / convolution, last layer first
     float* d_out = et->dxa;
