@@ -1231,6 +1231,8 @@ struct ConvArgs {
     int trans_a;                   // 1: weight gradient dW = im2col(X)^T . dY: output row mo = (tap j, channel i) of ktaps*Cin rows,
                                    //    reduction over the `red` rows rr of X / dY (w = dY [red][N]); element = X[rr + j - pad_l][i] within the utterance
     int red;
+    int splits;                    // > 1: split-K over gridDim.z; raw partial sums go to part[z][Mtot][N] (no epilogue), summed in
+    float* part;                   //      split order by a second kernel (deterministic)
 };
 
 #define CG_BM 128
@@ -1246,6 +1248,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const int m0 = blockIdx.y * CG_BM, n0 = blockIdx.x * CG_BN;
     const int Ktot = a.trans_a ? a.red : a.ktaps * a.Cin;
     const int nk = (Ktot + CG_BK - 1) / CG_BK;
+    const int nz = a.splits > 1 ? a.splits : 1, z = a.splits > 1 ? (int)blockIdx.z : 0;
+    const int kt0 = (int)((long long)nk * z / nz), kt1 = (int)((long long)nk * (z + 1) / nz);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -1272,7 +1276,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                 const int rr = kbase + b_k0 + p * 8;                 // reduction row
                 const int mo = m0 + b_nq * 4;                        // output rows mo .. mo + 3
                 float tmp[4] = {0.f, 0.f, 0.f, 0.f};
-                if (rr < Ktot) {
+                if (rr < Ktot && a.vec_a) {                         // Cin % 4 == 0: the four rows share the tap
+                    if (mo < a.Mtot) {
+                        const int j = mo / a.Cin, i = mo - j * a.Cin;
+                        const int ts = rr % a.T + j - a.pad_l;
+                        if (ts >= 0 && ts < a.T) {
+                            const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)(rr + j - a.pad_l) * a.ldx + i);
+                            tmp[0] = v.x; tmp[1] = v.y; tmp[2] = v.z; tmp[3] = v.w;
+                        }
+                    }
+                } else if (rr < Ktot) {
                     const int tt = rr % a.T;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -1354,13 +1367,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
             *reinterpret_cast<float4*>(&Bs[buf][b_k0 + p * 8][b_nq * 4]) = rbv[p];
     };
 
-    load_tiles(0);
-    store_tiles(0);
+    if (kt0 < kt1) {
+        load_tiles(kt0);
+        store_tiles(0);
+    }
     __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tiles(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < CG_BK; ks += 2) {
             const float a0 = As[buf][ks + lh][wm * 64 + l31];
@@ -1372,8 +1387,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        if (kt + 1 < kt1) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+    if (a.splits > 1) {
+        float* part = a.part + (size_t)z * a.Mtot * a.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                if (n >= a.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < a.Mtot) part[(size_t)m * a.N + n] = acc[i][j][r];
+                }
+            }
+        return;
     }
     // epilogue: D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll

@@ -7,13 +7,14 @@
 // backward kernels (plain [B][.] gradients; GEMM operands additionally in frag16)
 // ------------------------------------------------------------------------------------------------
 // d(loss)/d(mel, stop) of models.py:58-61: loss = spec_loss + binary_loss, each sum(l * w) / count_nonzero(w broadcast).
-// Writes dY[t][b][M*r + 1] (plain, the tape of the projection's weight gradient).  n_spec / n_bin: device scalars
+// Writes dY[t][b][M*r + 1] (plain, the tape of the projection's weight gradient) and the same rows as per-step frag16 operands.  n_spec / n_bin: device scalars
 // (out3[1] of t2_spec_loss / t2_binary_loss).
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ mel, const float* __restrict__ target,
                                                         const float* __restrict__ spec_mask, const float* __restrict__ stop,
                                                         const float* __restrict__ done, const float* __restrict__ bin_mask,
                                                         const float* __restrict__ n_spec, const float* __restrict__ n_bin,
-                                                        float* __restrict__ dY, int B, int S, int M, int r) {
+                                                        float* __restrict__ dY, float* __restrict__ dYf, long long frag_stride, int MB,
+                                                        int B, int S, int M, int r) {
     const int N = M * r + 1;
     const long long n = (long long)S * B * N;
     const float is = n_spec[0] > 0.f ? 1.0f / n_spec[0] : 0.f, ib = n_bin[0] > 0.f ? 1.0f / n_bin[0] : 0.f;
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
             g = (sigmoidf_(x) - done[(size_t)b * S + t]) * bin_mask[(size_t)b * S + t] * ib;
         }
         dY[i] = g;
+        dYf[(size_t)t * frag_stride + frag_idx(b, c, MB)] = g;     // frag16 operand of the step's projection backward
     }
 }
 
@@ -65,43 +67,91 @@ struct LstmBwdArgs {
     const int* lens;                          // optional [B]: rows with t >= len copied their state through (dynamic_rnn)
 };
 
+// one (row, unit) element; g_extra: a part of the raw-output gradient the caller holds in a register
+__device__ __forceinline__ void lstm_bwd_elem(const LstmBwdArgs& a, int row, int u, float g_extra) {
+    const int i = row * a.H + u;
+    const float* z = a.z + (size_t)row * 4 * a.H;
+    const float gi = sigmoidf_(z[u]), gj = tanhf(z[a.H + u]), gf = sigmoidf_(z[2 * a.H + u] + a.fb), go = sigmoidf_(z[3 * a.H + u]);
+    const float cp = a.cprev[i], cn = a.cnew[i];
+    const float mc = t2_u01(a.seed, a.stream, a.t, row, u) >= a.zc ? 1.f : 0.f;
+    const float mh = t2_u01(a.seed, a.stream + 1, a.t, row, u) >= a.zh ? 1.f : 0.f;
+    float g_out = g_extra, g_hs = 0.f;
+    if (a.g_out0) g_out += a.g_out0[(size_t)row * a.ld_out0 + u];
+    if (a.g_out1) g_out += a.g_out1[(size_t)row * a.ld_out1 + u];
+    if (!a.first) {
+        if (a.g_hs0) g_hs += a.g_hs0[(size_t)row * a.ld_hs0 + u];
+        if (a.g_hs1) g_hs += a.g_hs1[(size_t)row * a.ld_hs1 + u];
+    }
+    const float g_c = a.first ? 0.f : a.g_c[i];
+    if (a.lens != nullptr && a.t >= a.lens[row]) {          // dead step: state passes through, no output, no gate gradient
+        a.g_c[i] = g_c;
+        a.g_hp[i] = g_hs;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            a.dz_plain[(size_t)row * 4 * a.H + g * a.H + u] = 0.f;
+            a.dz_frag[frag_idx(row, g * a.H + u, a.MB)] = 0.f;
+        }
+        return;
+    }
+    const float tc = tanhf(cn);
+    const float dhn = g_out + mh * g_hs;
+    const float dcn = mc * g_c + dhn * go * (1.f - tc * tc);
+    a.g_c[i] = (1.f - mc) * g_c + dcn * gf;
+    a.g_hp[i] = (1.f - mh) * g_hs;
+    const float dz4[4] = {dcn * gj * gi * (1.f - gi), dcn * gi * (1.f - gj * gj), dcn * cp * gf * (1.f - gf), dhn * tc * go * (1.f - go)};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        a.dz_plain[(size_t)row * 4 * a.H + g * a.H + u] = dz4[g];
+        a.dz_frag[frag_idx(row, g * a.H + u, a.MB)] = dz4[g];
+    }
+}
+
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     const int n = a.B * a.H;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int row = i / a.H, u = i - row * a.H;
-        const float* z = a.z + (size_t)row * 4 * a.H;
-        const float gi = sigmoidf_(z[u]), gj = tanhf(z[a.H + u]), gf = sigmoidf_(z[2 * a.H + u] + a.fb), go = sigmoidf_(z[3 * a.H + u]);
-        const float cp = a.cprev[i], cn = a.cnew[i];
-        const float mc = t2_u01(a.seed, a.stream, a.t, row, u) >= a.zc ? 1.f : 0.f;
-        const float mh = t2_u01(a.seed, a.stream + 1, a.t, row, u) >= a.zh ? 1.f : 0.f;
-        float g_out = 0.f, g_hs = 0.f;
-        if (a.g_out0) g_out += a.g_out0[(size_t)row * a.ld_out0 + u];
-        if (a.g_out1) g_out += a.g_out1[(size_t)row * a.ld_out1 + u];
-        if (!a.first) {
-            if (a.g_hs0) g_hs += a.g_hs0[(size_t)row * a.ld_hs0 + u];
-            if (a.g_hs1) g_hs += a.g_hs1[(size_t)row * a.ld_hs1 + u];
-        }
-        const float g_c = a.first ? 0.f : a.g_c[i];
-        if (a.lens != nullptr && a.t >= a.lens[row]) {          // dead step: state passes through, no output, no gate gradient
-            a.g_c[i] = g_c;
-            a.g_hp[i] = g_hs;
+        const int row = i / a.H;
+        lstm_bwd_elem(a, row, i - row * a.H, 0.f);
+    }
+}
+
+// Data-gradient GEMM of the backward recurrence, y[B][N] = x_frag[B][K] . W^T (skinny core, 16 columns per workgroup), with
+// the elementwise stage that consumes y fused into the epilogue:
+//   mode 1: ZoneoutLSTMCell backward of the layer whose raw-output gradient the columns [0, lb.H) are (g_extra = y);
+//   mode 2: PreNet backward through dropout(relu(.)) on the columns [0, pn_P): d = (out != 0) ? y / keep : 0.
+struct BwdEpi {
+    int N;
+    float* out_plain; int plain_ld;          // y itself, may be null
+    int mode;
+    LstmBwdArgs lb;
+    const float* pn_y; float pn_inv_keep; float *pn_plain, *pn_frag; int pn_P;
+};
+
+template <int MB>
+__global__ __launch_bounds__(T2_SKINNY_THREADS) void bwd_dense_kernel(SkinnyCore a, BwdEpi e) {
+    __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
+    f32x4 acc[MB];
+    const int wg = blockIdx.x;
+    const int t = skinny_core<MB, 0>(a, 0, wg, acc, [](int) {});
+    if (t < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                a.dz_plain[(size_t)row * 4 * a.H + g * a.H + u] = 0.f;
-                a.dz_frag[frag_idx(row, g * a.H + u, a.MB)] = 0.f;
+    for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MB * 16 * 16; idx += T2_SKINNY_THREADS) {
+        const int row = idx >> 4, c = idx & 15;
+        const int col = wg * 16 + c;
+        if (row >= a.B || col >= e.N) continue;
+        const float v = red_sum<MB>(red, row, c);
+        if (e.out_plain != nullptr) e.out_plain[(size_t)row * e.plain_ld + col] = v;
+        if (e.mode == 1) {
+            if (col < e.lb.H) lstm_bwd_elem(e.lb, row, col, v);
+        } else if (e.mode == 2) {
+            if (col < e.pn_P) {
+                const size_t i = (size_t)row * e.pn_P + col;
+                const float dd = e.pn_y[i] != 0.f ? v * e.pn_inv_keep : 0.f;
+                e.pn_plain[i] = dd;
+                e.pn_frag[frag_idx(row, col, MB)] = dd;
             }
-            continue;
-        }
-        const float tc = tanhf(cn);
-        const float dhn = g_out + mh * g_hs;
-        const float dcn = mc * g_c + dhn * go * (1.f - tc * tc);
-        a.g_c[i] = (1.f - mc) * g_c + dcn * gf;
-        a.g_hp[i] = (1.f - mh) * g_hs;
-        const float dz4[4] = {dcn * gj * gi * (1.f - gi), dcn * gi * (1.f - gj * gj), dcn * cp * gf * (1.f - gf), dhn * tc * go * (1.f - go)};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            a.dz_plain[(size_t)row * 4 * a.H + g * a.H + u] = dz4[g];
-            a.dz_frag[frag_idx(row, g * a.H + u, a.MB)] = dz4[g];
         }
     }
 }
@@ -122,6 +172,7 @@ __global__ __launch_bounds__(256) void prenet_bwd_kernel(const float* __restrict
 // column sums of a [rows][N] matrix (bias gradients), fixed order: stage 1 sums T2_CS_CHUNKS row ranges (64 columns x 4 row
 // lanes per block, double accumulators), stage 2 (batch_sum_kernel) adds the range partials in order
 #define T2_CS_CHUNKS 64
+#define T2_BN_CHUNKS 32      // row ranges of the batch-norm reductions (bn_stats_kernel, bn_bwd_reduce_kernel)
 __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, long long rows, int N, float* __restrict__ part) {
     __shared__ double s1[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
@@ -162,11 +213,22 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, c
 // which lets every chunk work without the other chunks' da.
 // After the loop attention_param_grad_kernel walks the tape per (row, chunk), recomputes du from de and accumulates
 // d keys and the parameter gradients (v_a, Wloc, conv kernel / bias).
+// Global-memory latency (about 1000 cycles a round trip) dominated the first version of these kernels: every load batch is
+// now issued before its first use, the parameters come as one prebuilt LDS image (attention_image_kernel) copied with
+// float4 loads, and the tape-wide kernel prefetches the next step's inputs while it works on the current one.
 #define T2_AB_J 16
 #define T2_AB_THREADS 256
 
+// workgroup barrier that orders LDS traffic only: global loads issued before it (prefetches) stay in flight
+__device__ __forceinline__ void ab_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct AbLds {
-    float *sp, *cw, *cb, *wl, *wlT, *f, *du, *df, *dfp, *q, *v, *de;
+    float *cw, *cb, *wlT, *v;                 // parameter image: conv kernel [K][FP], conv bias [F], Wloc^T [U][FP], v_a [U]
+    float *sp, *f, *du, *df, *dfp, *q, *de;
     int FP, US;
 };
 
@@ -176,52 +238,67 @@ __host__ __device__ inline int ab_us(int F) {             // u-splits of the df 
     return us < 1 ? 1 : (us > 8 ? 8 : us);
 }
 __host__ __device__ inline int ab_r4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int ab_image_floats(int U, int F, int K) { return ab_r4(K * (F + 1)) + ab_r4(F) + ab_r4(U * (F + 1)) + ab_r4(U); }
 __host__ __device__ inline int ab_common_floats(int U, int F, int K) {
     const int FP = F + 1;
-    return ab_r4(T2_AB_J + K + 8) + ab_r4(K * FP) + ab_r4(F) + ab_r4(F * U) + ab_r4(U * FP) + 2 * ab_r4(T2_AB_J * FP) + ab_r4(T2_AB_J * U) +
-           ab_r4(ab_us(F) * T2_AB_J * FP) + 2 * ab_r4(U) + ab_r4(T2_AB_J);
+    return ab_image_floats(U, F, K) + ab_r4(T2_AB_J + K + 8) + 2 * ab_r4(T2_AB_J * FP) + ab_r4(T2_AB_J * U) + ab_r4(ab_us(F) * T2_AB_J * FP) +
+           ab_r4(U) + ab_r4(T2_AB_J);
 }
-__device__ inline float* ab_carve(float* sm, int U, int F, int K, AbLds& L) {
+__host__ __device__ inline float* ab_carve(float* sm, int U, int F, int K, AbLds& L) {
     const int FP = F + 1;
     L.FP = FP; L.US = ab_us(F);
     float* p = sm;
-    L.sp = p; p += ab_r4(T2_AB_J + K + 8);
     L.cw = p; p += ab_r4(K * FP);
     L.cb = p; p += ab_r4(F);
-    L.wl = p; p += ab_r4(F * U);
     L.wlT = p; p += ab_r4(U * FP);
+    L.v = p; p += ab_r4(U);
+    L.sp = p; p += ab_r4(T2_AB_J + K + 8);
     L.f = p; p += ab_r4(T2_AB_J * FP);
     L.df = p; p += ab_r4(T2_AB_J * FP);
     L.du = p; p += ab_r4(T2_AB_J * U);
     L.dfp = p; p += ab_r4(L.US * T2_AB_J * FP);
     L.q = p; p += ab_r4(U);
-    L.v = p; p += ab_r4(U);
     L.de = p; p += ab_r4(T2_AB_J);
     return p;
 }
 
-__device__ inline void ab_load_consts(const AbLds& L, const float* __restrict__ conv_w, const float* __restrict__ conv_b,
-                                      const float* __restrict__ wloc, const float* __restrict__ v_a, int U, int F, int K, int tid) {
-    const int FP = L.FP;
-    for (int i = tid; i < K * F; i += T2_AB_THREADS) { const int k = i / F, c = i - k * F; L.cw[k * FP + c] = conv_w[i]; }
-    for (int i = tid; i < F; i += T2_AB_THREADS) L.cb[i] = conv_b[i];
-    for (int i = tid; i < F * U; i += T2_AB_THREADS) {
-        const int c = i / U, u = i - c * U;
-        const float w = wloc[i];
-        L.wl[i] = w; L.wlT[u * FP + c] = w;
-    }
-    for (int i = tid; i < U; i += T2_AB_THREADS) L.v[i] = v_a[i];
+// the parameter image in global memory, laid out exactly as the head of the kernels' LDS (one block)
+__global__ __launch_bounds__(256) void attention_image_kernel(const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+                                                              const float* __restrict__ wloc, const float* __restrict__ v_a, float* __restrict__ img,
+                                                              int U, int F, int K) {
+    AbLds L;
+    ab_carve(img, U, F, K, L);
+    const int FP = L.FP, tid = threadIdx.x;
+    for (int i = tid; i < ab_image_floats(U, F, K); i += 256) img[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < K * F; i += 256) { const int k = i / F, c = i - k * F; L.cw[k * FP + c] = conv_w[i]; }
+    for (int i = tid; i < F; i += 256) L.cb[i] = conv_b[i];
+    for (int i = tid; i < F * U; i += 256) { const int c = i / U, u = i - c * U; L.wlT[u * FP + c] = wloc[i]; }
+    for (int i = tid; i < U; i += 256) L.v[i] = v_a[i];
 }
 
-// sp[i] <-> attention state before the step at position j0 - pad_l + i
-__device__ inline void ab_load_step(const AbLds& L, const float* __restrict__ state_prev_row, const float* __restrict__ q_row, int j0, int T,
-                                    int U, int K, int tid) {
-    const int pad_l = (K - 1) / 2;
-    for (int i = tid; i < T2_AB_J + K - 1; i += T2_AB_THREADS) {
-        const int p = j0 - pad_l + i;
-        L.sp[i] = (p >= 0 && p < T) ? state_prev_row[p] : 0.f;
+// image -> LDS, eight float4 loads in flight per thread
+__device__ inline void ab_load_image(float* sm, const float* __restrict__ img, int n4, int tid) {
+    const float4* src = reinterpret_cast<const float4*>(img);
+    float4* dst = reinterpret_cast<float4*>(sm);
+    for (int base = tid; base < n4; base += 8 * T2_AB_THREADS) {
+        float4 w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int idx = base + i * T2_AB_THREADS; w[i] = idx < n4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int idx = base + i * T2_AB_THREADS; if (idx < n4) dst[idx] = w[i]; }
     }
-    for (int i = tid; i < U; i += T2_AB_THREADS) L.q[i] = q_row[i];
+}
+
+// keys of the chunk in the register tile of ab_du (zero past the valid positions)
+__device__ inline void ab_load_keys(const float* __restrict__ keys_chunk, int jn, int U, int tid, float (*kq)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int idx = tid + m * T2_AB_THREADS;
+        const int jq = idx / U, u = idx - jq * U;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) kq[m][jj] = (idx < (T2_AB_J / 4) * U && jq * 4 + jj < jn) ? keys_chunk[(size_t)(jq * 4 + jj) * U + u] : 0.f;
+    }
 }
 
 __device__ inline void ab_features(const AbLds& L, int F, int K, int tid) {
@@ -229,6 +306,7 @@ __device__ inline void ab_features(const AbLds& L, int F, int K, int tid) {
     for (int i = tid; i < T2_AB_J * F; i += T2_AB_THREADS) {
         const int j = i / F, c = i - j * F;
         float acc = L.cb[c];
+#pragma unroll 8
         for (int k = 0; k < K; ++k) acc = fmaf(L.cw[k * FP + c], L.sp[j + k], acc);
         L.f[j * FP + c] = acc;
     }
@@ -237,7 +315,7 @@ __device__ inline void ab_features(const AbLds& L, int F, int K, int tid) {
 // du[j][u] = de[j] * v[u] * (1 - tanh(pre)^2) for the jn valid positions of the chunk (zero beyond); thread tile: one unit x
 // four positions.  ACC: also accumulate d keys (registers, dk[4][4]) and the per-(position group, unit) part of d v_a (LDS).
 template <bool ACC>
-__device__ inline void ab_du(const AbLds& L, const float* __restrict__ keys_chunk, int jn, int U, int F, int tid, float (*dk)[4], float* s_dva) {
+__device__ inline void ab_du(const AbLds& L, const float (*kq)[4], int jn, int U, int F, int tid, float (*dk)[4], float* s_dva) {
     const int FP = L.FP;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -245,10 +323,12 @@ __device__ inline void ab_du(const AbLds& L, const float* __restrict__ keys_chun
         if (idx < (T2_AB_J / 4) * U) {
             const int jq = idx / U, u = idx - jq * U, jb = jq * 4;
             float pre[4];
+            const float qu = L.q[u];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) pre[jj] = (jb + jj < jn) ? keys_chunk[(size_t)(jb + jj) * U + u] + L.q[u] : 0.f;
+            for (int jj = 0; jj < 4; ++jj) pre[jj] = kq[m][jj] + qu;
+#pragma unroll 8
             for (int c = 0; c < F; ++c) {
-                const float w = L.wl[c * U + u];
+                const float w = L.wlT[u * FP + c];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) pre[jj] = fmaf(L.f[(jb + jj) * FP + c], w, pre[jj]);
             }
@@ -277,6 +357,7 @@ __device__ inline void ab_df(const AbLds& L, int U, int F, int tid) {
         const int us = idx / items, r = idx - us * items, jq = r / F, c = r - jq * F, jb = jq * 4;
         const int u0 = us * ur, u1 = min(U, u0 + ur);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
         for (int u = u0; u < u1; ++u) {
             const float w = L.wlT[u * FP + c];
 #pragma unroll
@@ -285,7 +366,7 @@ __device__ inline void ab_df(const AbLds& L, int U, int F, int tid) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) L.dfp[(us * T2_AB_J + jb + jj) * FP + c] = acc[jj];
     }
-    __syncthreads();
+    ab_lds_barrier();
     for (int i = tid; i < T2_AB_J * F; i += T2_AB_THREADS) {
         const int j = i / F, c = i - j * F;
         float s = 0.f;
@@ -301,7 +382,7 @@ struct AttnBwdArgs {
     const float* dctx0; int ld_dctx0;         // d context: sum of two sources (LSTM-1 input part, attention-LSTM input of t + 1)
     const float* dctx1; int ld_dctx1;
     const float* g_state;                     // [B][T] d / d attention state after this step
-    const float *conv_w, *conv_b, *wloc, *v_a;
+    const float* image;                       // attention_image_kernel's output
     float* de;                                // [B][T] this step's slice of the tape-wide d energies
     float* dctx_sum; long long ld_dctx_sum;   // row b at dctx_sum + b * ld: this step's slice of the tape-wide d context
     float *part_dq, *part_ds;                 // [B][NJ][U], [B][NJ][J + K - 1]
@@ -313,67 +394,133 @@ __host__ __device__ inline int attn_bwd_lds_floats(int U, int E, int F, int K) {
 __global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = T2_AB_THREADS / 64, J = T2_AB_J;
+    constexpr int NW = T2_AB_THREADS / 64, J = T2_AB_J, JW = J / NW;
     const int T = a.T, U = a.U, E = a.E, F = a.F, K = a.K;
     const int len = a.lens[b], j0 = ch * J;
     if (ch > 0 && j0 >= len) return;          // masked chunk: its partials stay zero (workspace zeroed per call)
-    const int jn = max(0, min(J, len - j0));
+    const int jn = max(0, min(J, len - j0)), pad_l = (K - 1) / 2, NI = J + K - 1;
     AbLds L;
     float* s_dctx = ab_carve(sm, U, F, K, L);
     float* s_red = s_dctx + ab_r4(E);         // [NW] dot partials, [16..32) da
-    ab_load_consts(L, a.conv_w, a.conv_b, a.wloc, a.v_a, U, F, K, tid);
-    ab_load_step(L, a.state_prev + (size_t)b * T, a.q + (size_t)b * U, j0, T, U, K, tid);
-    float part = 0.f;
-    for (int i = tid; i < E; i += T2_AB_THREADS) {
+    // ---- every global load of the kernel is issued here
+    float r_dctx[2], r_ctx[2];                // first 512 columns; the rest (E > 512) goes through the slow loop below
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * T2_AB_THREADS;
         float v = 0.f;
-        if (a.dctx0) v += a.dctx0[(size_t)b * a.ld_dctx0 + i];
-        if (a.dctx1) v += a.dctx1[(size_t)b * a.ld_dctx1 + i];
-        s_dctx[i] = v;
-        if (ch == 0) a.dctx_sum[(size_t)b * a.ld_dctx_sum + i] = v;
-        part = fmaf(v, a.ctx[(size_t)b * E + i], part);
+        if (c < E) {
+            if (a.dctx0) v += a.dctx0[(size_t)b * a.ld_dctx0 + c];
+            if (a.dctx1) v += a.dctx1[(size_t)b * a.ld_dctx1 + c];
+        }
+        r_dctx[i] = v;
+        r_ctx[i] = c < E ? a.ctx[(size_t)b * E + c] : 0.f;
+    }
+    float r_sp = 0.f, r_q[2] = {0.f, 0.f};
+    if (tid < NI) { const int p = j0 - pad_l + tid; r_sp = (p >= 0 && p < T) ? a.state_prev[(size_t)b * T + p] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int u = tid + i * T2_AB_THREADS; if (u < U) r_q[i] = a.q[(size_t)b * U + u]; }
+    float r_al[2] = {0.f, 0.f}, r_gs[2] = {0.f, 0.f};       // first 512 positions of the row (dot); the rest: slow loop
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = tid + i * T2_AB_THREADS;
+        if (j < len && !a.first) { r_al[i] = a.align[(size_t)b * T + j]; r_gs[i] = a.g_state[(size_t)b * T + j]; }
+    }
+    const float my_al = tid < jn ? a.align[(size_t)b * T + j0 + tid] : 0.f;
+    const float my_gs = (tid < jn && !a.first) ? a.g_state[(size_t)b * T + j0 + tid] : 0.f;
+    const float* vals = a.values + ((size_t)b * T + j0) * E;
+    float vv[JW][8];                          // values rows of this wave's positions, first 512 columns
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+        const int j = wave + jj * NW;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int c = lane + 64 * i; vv[jj][i] = (j < jn && c < E) ? vals[(size_t)j * E + c] : 0.f; }
+    }
+    float kq[4][4];
+    ab_load_keys(a.keys + ((size_t)b * T + j0) * U, jn, U, tid, kq);
+    ab_load_image(sm, a.image, ab_image_floats(U, F, K) / 4, tid);
+    // ---- stage the step's inputs
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * T2_AB_THREADS;
+        if (c < E) {
+            s_dctx[c] = r_dctx[i];
+            if (ch == 0) a.dctx_sum[(size_t)b * a.ld_dctx_sum + c] = r_dctx[i];
+            part = fmaf(r_dctx[i], r_ctx[i], part);
+        }
+        part = fmaf(r_al[i], r_gs[i], part);
+    }
+    for (int c = tid + 2 * T2_AB_THREADS; c < E; c += T2_AB_THREADS) {
+        float v = 0.f;
+        if (a.dctx0) v += a.dctx0[(size_t)b * a.ld_dctx0 + c];
+        if (a.dctx1) v += a.dctx1[(size_t)b * a.ld_dctx1 + c];
+        s_dctx[c] = v;
+        if (ch == 0) a.dctx_sum[(size_t)b * a.ld_dctx_sum + c] = v;
+        part = fmaf(v, a.ctx[(size_t)b * E + c], part);
     }
     if (!a.first)
-        for (int j = tid; j < len; j += T2_AB_THREADS) part = fmaf(a.align[(size_t)b * T + j], a.g_state[(size_t)b * T + j], part);
+        for (int j = tid + 2 * T2_AB_THREADS; j < len; j += T2_AB_THREADS) part = fmaf(a.align[(size_t)b * T + j], a.g_state[(size_t)b * T + j], part);
+    if (tid < NI) L.sp[tid] = r_sp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int u = tid + i * T2_AB_THREADS; if (u < U) L.q[u] = r_q[i]; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if (lane == 0) s_red[wave] = part;
-    __syncthreads();
+    ab_lds_barrier();
     ab_features(L, F, K, tid);
     // d alignments of the chunk: da_j = dctx . values[j] + d state after this step
-    const float* vals = a.values + ((size_t)b * T + j0) * E;
-    for (int j = wave; j < jn; j += NW) {
-        float acc = 0.f;
-        for (int c = lane; c < E; c += 64) acc = fmaf(s_dctx[c], vals[(size_t)j * E + c], acc);
+    {
+        float acc[JW];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) s_red[16 + j] = acc + (a.first ? 0.f : a.g_state[(size_t)b * T + j0 + j]);
+        for (int jj = 0; jj < JW; ++jj) acc[jj] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            const float dv = c < E ? s_dctx[c] : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj) acc[jj] = fmaf(dv, vv[jj][i], acc[jj]);
+        }
+        for (int c = 512 + lane; c < E; c += 64)
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj) {
+                const int j = wave + jj * NW;
+                if (j < jn) acc[jj] = fmaf(s_dctx[c], vals[(size_t)j * E + c], acc[jj]);
+            }
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[jj] += __shfl_xor(acc[jj], off, 64);
+            if (lane == 0) s_red[16 + wave + jj * NW] = acc[jj];
+        }
     }
-    __syncthreads();
+    ab_lds_barrier();
     if (tid < J) {
         float dot = 0.f;
         for (int w = 0; w < NW; ++w) dot += s_red[w];
-        const float de = tid < jn ? a.align[(size_t)b * T + j0 + tid] * (s_red[16 + tid] - dot) : 0.f;
+        const float de = tid < jn ? my_al * (s_red[16 + tid] + my_gs - dot) : 0.f;
         L.de[tid] = de;
         if (j0 + tid < T) a.de[(size_t)b * T + j0 + tid] = de;
     }
-    __syncthreads();
-    ab_du<false>(L, a.keys + ((size_t)b * T + j0) * U, jn, U, F, tid, nullptr, nullptr);
-    __syncthreads();
+    ab_lds_barrier();
+    ab_du<false>(L, kq, jn, U, F, tid, nullptr, nullptr);
+    ab_lds_barrier();
     for (int u = tid; u < U; u += T2_AB_THREADS) {
         float s = 0.f;
+#pragma unroll
         for (int j = 0; j < J; ++j) s += L.du[j * U + u];
         a.part_dq[((size_t)b * a.NJ + ch) * U + u] = s;
     }
     ab_df(L, U, F, tid);
-    __syncthreads();
+    ab_lds_barrier();
     // partial d state_prev over the chunk + halo: ds[i] = sum_{j, c} w[i - j][c] * df[j][c], i <-> position j0 - pad_l + i
-    const int NI = J + K - 1, FP = L.FP;
+    const int FP = L.FP;
     for (int i0 = 0; i0 < NI; i0 += T2_AB_THREADS / 4) {
         const int i = i0 + (tid >> 2), cg = tid & 3;
         float acc = 0.f;
         if (i < NI) {
             const int ja = max(0, i - K + 1), jb = min(jn - 1, i);
             for (int j = ja; j <= jb; ++j)
+#pragma unroll 8
                 for (int c = cg; c < F; c += 4) acc = fmaf(L.cw[(i - j) * FP + c], L.df[j * FP + c], acc);
         }
         acc += __shfl_xor(acc, 1, 64);
@@ -411,7 +558,7 @@ __global__ __launch_bounds__(256) void attention_bwd_finish_kernel(AttnBwdFinish
 struct AttnParamArgs {
     const float* keys; const int* lens;
     const float *q, *state_prev, *de;         // tape-wide [S][B][U], [S][B][T], [S][B][T]
-    const float *conv_w, *conv_b, *wloc, *v_a;
+    const float* image;
     float* dkeys_part;                        // [NS][B][T][U]
     float *p_convw, *p_convb, *p_wloc, *p_va; // [NP][K*F], [NP][F], [NP][F*U], [NP][U]; NP = NS * B * NJ
     int B, T, U, F, K, NJ, S, NS;
@@ -428,14 +575,34 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_param_grad_kernel(Att
     const int T = a.T, U = a.U, F = a.F, K = a.K, B = a.B;
     const int len = a.lens[b], j0 = ch * J;
     if (j0 >= len) return;                    // masked chunk: outputs stay zero (workspace zeroed per call)
-    const int jn = min(J, len - j0);
+    const int jn = min(J, len - j0), pad_l = (K - 1) / 2, NI = J + K - 1;
     AbLds L;
     float* s_dwl = ab_carve(sm, U, F, K, L);
     float* s_dcw = s_dwl + ab_r4(F * U);
     float* s_dcb = s_dcw + ab_r4(K * F);
     float* s_dva = s_dcb + ab_r4(F);
     const int FP = L.FP;
-    ab_load_consts(L, a.conv_w, a.conv_b, a.wloc, a.v_a, U, F, K, tid);
+    const int per = (a.S + a.NS - 1) / a.NS, t0 = ns * per, t1 = min(a.S, t0 + per);
+    // per-step inputs: element i of [sp (NI) | q (U) | de (J)], two per thread, fetched one step ahead
+    auto fetch = [&](int t, int i) -> float {
+        const size_t row = (size_t)t * B + b;
+        if (i < NI) { const int p = j0 - pad_l + i; return (p >= 0 && p < T) ? a.state_prev[row * T + p] : 0.f; }
+        i -= NI;
+        if (i < U) return a.q[row * U + i];
+        i -= U;
+        return i < jn ? a.de[row * T + j0 + i] : 0.f;
+    };
+    auto stage = [&](int i, float v) {
+        if (i < NI) L.sp[i] = v;
+        else if (i < NI + U) L.q[i - NI] = v;
+        else if (i < NI + U + J) L.de[i - NI - U] = v;
+    };
+    const int nin = NI + U + J;               // <= 2 * T2_AB_THREADS for U <= 256, K <= 200
+    float nx0 = 0.f, nx1 = 0.f;
+    if (t0 < t1) { if (tid < nin) nx0 = fetch(t0, tid); if (tid + T2_AB_THREADS < nin) nx1 = fetch(t0, tid + T2_AB_THREADS); }
+    float kq[4][4];
+    ab_load_keys(a.keys + ((size_t)b * T + j0) * U, jn, U, tid, kq);
+    ab_load_image(sm, a.image, ab_image_floats(U, F, K) / 4, tid);
     for (int i = tid; i < F * U; i += T2_AB_THREADS) s_dwl[i] = 0.f;
     for (int i = tid; i < K * F; i += T2_AB_THREADS) s_dcw[i] = 0.f;
     for (int i = tid; i < F; i += T2_AB_THREADS) s_dcb[i] = 0.f;
@@ -445,23 +612,22 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_param_grad_kernel(Att
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) dk[m][jj] = 0.f;
-    const int per = (a.S + a.NS - 1) / a.NS, t0 = ns * per, t1 = min(a.S, t0 + per);
-    const float* keys_chunk = a.keys + ((size_t)b * T + j0) * U;
     const int FG = (F + 3) / 4;
     for (int t = t0; t < t1; ++t) {
-        __syncthreads();
-        ab_load_step(L, a.state_prev + ((size_t)t * B + b) * T, a.q + ((size_t)t * B + b) * U, j0, T, U, K, tid);
-        if (tid < J) L.de[tid] = tid < jn ? a.de[((size_t)t * B + b) * T + j0 + tid] : 0.f;
-        __syncthreads();
+        ab_lds_barrier();
+        stage(tid, nx0); stage(tid + T2_AB_THREADS, nx1);
+        if (t + 1 < t1) { if (tid < nin) nx0 = fetch(t + 1, tid); if (tid + T2_AB_THREADS < nin) nx1 = fetch(t + 1, tid + T2_AB_THREADS); }
+        ab_lds_barrier();
         ab_features(L, F, K, tid);
-        __syncthreads();
-        ab_du<true>(L, keys_chunk, jn, U, F, tid, dk, s_dva);
-        __syncthreads();
+        ab_lds_barrier();
+        ab_du<true>(L, kq, jn, U, F, tid, dk, s_dva);
+        ab_lds_barrier();
         ab_df(L, U, F, tid);
         // d Wloc[c][u] += sum_j f[j][c] * du[j][u]; thread tile: one unit x four filters
         for (int idx = tid; idx < FG * U; idx += T2_AB_THREADS) {
             const int cq = idx / U, u = idx - cq * U, c0 = cq * 4;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
             for (int j = 0; j < jn; ++j) {
                 const float d = L.du[j * U + u];
 #pragma unroll
@@ -471,10 +637,11 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_param_grad_kernel(Att
             for (int cc = 0; cc < 4; ++cc)
                 if (c0 + cc < F) s_dwl[(c0 + cc) * U + u] += acc[cc];
         }
-        __syncthreads();
+        ab_lds_barrier();
         for (int i = tid; i < K * F; i += T2_AB_THREADS) {
             const int k = i / F, c = i - k * F;
             float acc = 0.f;
+#pragma unroll 8
             for (int j = 0; j < jn; ++j) acc = fmaf(L.sp[j + k], L.df[j * FP + c], acc);
             s_dcw[i] += acc;
         }
@@ -484,7 +651,7 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_param_grad_kernel(Att
             s_dcb[c] += acc;
         }
     }
-    __syncthreads();
+    ab_lds_barrier();
     float* dkp = a.dkeys_part + (((size_t)ns * B + b) * T + j0) * U;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -541,10 +708,13 @@ struct t2_trainer {
     float *dX[3] = {}, *dy2 = nullptr, *dhq = nullptr, *dxp = nullptr;
     float *g_c[3] = {}, *g_hp[3] = {}, *g_state = nullptr;
     float *dkeys = nullptr, *dvalues = nullptr, *p_convw = nullptr, *p_convb = nullptr, *p_wloc = nullptr, *p_va = nullptr;
+    float* ab_image = nullptr;
     float *de_all = nullptr, *dctx_all = nullptr, *part_dq = nullptr, *part_ds = nullptr, *dkeys_part = nullptr;
     int NJ = 0, NS = 1;                 // attention backward: position chunks per row, step segments of the tape-wide kernel
     float *tmp = nullptr, *loss3 = nullptr;
     float* cs_part = nullptr; int cs_cols = 0;     // column-sum partials [T2_CS_CHUNKS][cs_cols]
+    double* bn_part = nullptr; int bn_cols = 0;    // batch-norm reduction partials [T2_BN_CHUNKS][2][bn_cols]
+    float* wg_part = nullptr;                      // split-K partials of the weight-gradient GEMMs [splits][rows][cols]
     std::map<std::string, long long> offsets;      // flat-gradient layout given by the caller
 };
 
@@ -574,6 +744,8 @@ extern "C" int t2_trainer_destroy(t2_trainer* tr) {
     if (tr->slab) (void)hipFree(tr->slab);
     if (tr->bslab) (void)hipFree(tr->bslab);
     if (tr->cs_part) (void)hipFree(tr->cs_part);
+    if (tr->wg_part) (void)hipFree(tr->wg_part);
+    if (tr->bn_part) (void)hipFree(tr->bn_part);
     for (void* p : tr->allocs) (void)hipFree(p);
     if (tr->state) state_free(tr->state);
     delete tr;
@@ -694,7 +866,7 @@ static int trainer_setup_backward(t2_trainer* tr) {
     const size_t SB = (size_t)S * B;
     size_t off = 0;
     auto carve = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
-    const size_t o_dY = carve(SB * N), o_dYf = carve((size_t)R * pad16(N));
+    const size_t o_dY = carve(SB * N), o_dYf = carve((size_t)S * R * pad16(N));
     size_t o_dz[3], o_dzf[3], o_dX[3], o_gc[3], o_ghp[3], o_dpre[T2_MAX_PRENET_LAYERS], o_dpref[T2_MAX_PRENET_LAYERS];
     for (int l = 0; l < 3; ++l) {
         o_dz[l] = carve(SB * 4 * H[l]); o_dzf[l] = carve((size_t)R * pad16(4 * H[l])); o_dX[l] = carve((size_t)B * KX[l]);
@@ -711,7 +883,10 @@ static int trainer_setup_backward(t2_trainer* tr) {
     const size_t o_pcw = carve(NP * d.attention_kernel * d.attention_filters), o_pcb = carve(NP * d.attention_filters),
                  o_pwl = carve(NP * d.attention_filters * U), o_pva = carve(NP * U);
     const size_t o_de = carve(SB * T), o_dctx = carve(SB * E), o_pdq = carve((size_t)B * NJ * U),
-                 o_pds = carve((size_t)B * NJ * (T2_AB_J + d.attention_kernel - 1)), o_dkp = carve((size_t)NS * B * T * U);
+                 o_pds = carve((size_t)B * NJ * (T2_AB_J + d.attention_kernel - 1)), o_dkp = carve((size_t)NS * B * T * U),
+                 o_img = carve((size_t)ab_image_floats(U, d.attention_filters, d.attention_kernel));
+    if (T2_AB_J + d.attention_kernel - 1 > T2_AB_THREADS || U > 256)
+        return fail(T2_EINVAL, "attention kernel size / attention_dim too large for the attention backward kernels");
     const size_t o_tmp = carve((size_t)std::max(D * N, 4096)), o_loss = carve(16);
     tr->bslab_bytes = off;
     HIP_TRY(hipMalloc(&tr->bslab, off));
@@ -728,7 +903,7 @@ static int trainer_setup_backward(t2_trainer* tr) {
     tr->p_convw = (float*)(p + o_pcw); tr->p_convb = (float*)(p + o_pcb); tr->p_wloc = (float*)(p + o_pwl); tr->p_va = (float*)(p + o_pva);
     tr->tmp = (float*)(p + o_tmp); tr->loss3 = (float*)(p + o_loss);
     tr->de_all = (float*)(p + o_de); tr->dctx_all = (float*)(p + o_dctx); tr->part_dq = (float*)(p + o_pdq); tr->part_ds = (float*)(p + o_pds);
-    tr->dkeys_part = (float*)(p + o_dkp);
+    tr->dkeys_part = (float*)(p + o_dkp); tr->ab_image = (float*)(p + o_img);
     const size_t lds = (size_t)std::max(attn_bwd_lds_floats(U, E, d.attention_filters, d.attention_kernel),
                                         attn_param_lds_floats(U, d.attention_filters, d.attention_kernel)) * 4;
     if (lds > 150 * 1024) return fail(T2_EINVAL, "attention dimensions too large for the attention backward kernels' LDS");
@@ -740,6 +915,14 @@ static int trainer_setup_backward(t2_trainer* tr) {
 extern "C" int t2_trainer_bind_gradient(t2_trainer* tr, const char* name, int64_t offset) {
     if (!tr || !name || offset < 0 || (offset & 3) != 0) return fail(T2_EINVAL, "bad argument (offsets are multiples of 4 floats)");
     tr->offsets[name] = offset;
+    return T2_OK;
+}
+
+static int bn_part_reserve(t2_trainer* tr, int C) {
+    if (C <= tr->bn_cols) return T2_OK;
+    if (tr->bn_part) { HIP_TRY(hipStreamSynchronize(tr->m->ctx->stream)); (void)hipFree(tr->bn_part); tr->bn_part = nullptr; }
+    tr->bn_cols = std::max(C, 512);
+    HIP_TRY(hipMalloc((void**)&tr->bn_part, (size_t)T2_BN_CHUNKS * 2 * tr->bn_cols * sizeof(double)));
     return T2_OK;
 }
 
@@ -756,16 +939,49 @@ static int col_sum(t2_trainer* tr, const float* x, long long rows, int N, float*
     return T2_OK;
 }
 
-// y[B][N] = x_frag[B][K] . W^T through the skinny dense kernel (no control block: t = 0)
-static void bwd_dense(t2_trainer* tr, const Packed& wT, float* x_frag, float* y, int N) {
+// y[B][N] = x_frag[B][K] . W^T through the skinny core (no control block: t = 0), epilogue per BwdEpi
+static void bwd_dense_epi(t2_trainer* tr, const Packed& wT, float* x_frag, BwdEpi e) {
     const int MB = mb_for(tr->B);
     SkinnyCore c{};
     c.w[0] = c.w[1] = wT.w; c.bias[0] = c.bias[1] = nullptr;
     c.kb0 = 0; c.kbtot = wT.kbtot; c.kb_w0 = 0; c.kb_full = wT.kbtot; c.ctl = nullptr; c.step_off = 0; c.t_hint = 0; c.B = tr->B;
     c.seg[0][1] = FragBuf{x_frag, 0, 1, 0, 0};
-    DenseEpi e{};
-    e.N = N; e.out_frag = FragBuf{nullptr, 0, 1, 0, 0}; e.out_plain = y; e.plain_ld = N; e.plain_t_stride = 0; e.plain_ncol = N; e.stop_col = -1;
-    launch_dense(MB, dim3(wT.n_wg), tr->m->ctx->stream, c, e);
+    hipStream_t st = tr->m->ctx->stream;
+    switch (MB) {
+        case 1: hipLaunchKernelGGL(bwd_dense_kernel<1>, dim3(wT.n_wg), dim3(T2_SKINNY_THREADS), 0, st, c, e); break;
+        case 2: hipLaunchKernelGGL(bwd_dense_kernel<2>, dim3(wT.n_wg), dim3(T2_SKINNY_THREADS), 0, st, c, e); break;
+        default: hipLaunchKernelGGL(bwd_dense_kernel<4>, dim3(wT.n_wg), dim3(T2_SKINNY_THREADS), 0, st, c, e); break;
+    }
+}
+
+static void bwd_dense(t2_trainer* tr, const Packed& wT, float* x_frag, float* y, int N) {
+    BwdEpi e{};
+    e.N = N; e.out_plain = y; e.plain_ld = N; e.mode = 0;
+    bwd_dense_epi(tr, wT, x_frag, e);
+}
+
+// Weight-gradient GEMM (trans_a mode of conv_gemm_kernel).  The reduction runs over all S*B (or B*T) tape rows while the
+// output is small, so the reduction is split over gridDim.z until about four workgroups per CU are in flight; the partial
+// products are added in split order by batch_sum_kernel.
+#define T2_WG_PART_FLOATS (16u << 20)
+static int launch_wgrad(t2_trainer* tr, ConvArgs a) {
+    hipStream_t st = tr->m->ctx->stream;
+    const int gx = ceil_div(a.N, CG_BN), gy = ceil_div(a.Mtot, CG_BM), nk = ceil_div(a.red, CG_BK);
+    long long z = std::min<long long>({(long long)ceil_div(1024, gx * gy), (long long)nk / 8, (long long)(T2_WG_PART_FLOATS / ((size_t)a.Mtot * a.N)), 64LL});
+    if (a.ldy != a.N || z < 2) z = 1;
+    a.splits = (int)z; a.part = nullptr;
+    if (z > 1) {
+        if (!tr->wg_part) HIP_TRY(hipMalloc((void**)&tr->wg_part, (size_t)T2_WG_PART_FLOATS * 4));
+        a.part = tr->wg_part;
+    }
+    hipLaunchKernelGGL(conv_gemm_kernel, dim3(gx, gy, (unsigned)z), dim3(256), 0, st, a);
+    if (z > 1) {
+        const long long n = (long long)a.Mtot * a.N;
+        hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))), dim3(256), 0, st,
+                           tr->wg_part, (int)z, n, a.y);
+    }
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
 }
 
 // dst[rows][ncols] (row stride ldd) = A^T . Bm with A [red][lda] (rows columns used), Bm [red][ldb]: weight gradients
@@ -773,13 +989,10 @@ static int bwd_wgrad(t2_trainer* tr, const float* A, int lda, int rows, const fl
     ConvArgs a{};
     a.x = A; a.ldx = lda; a.w = Bm; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.ldr = 0; a.y = dst; a.ldy = ldd;
     a.Mtot = rows; a.T = (int)red; a.Cin = rows; a.N = ncols; a.ktaps = 1; a.pad_l = 0; a.act = 0; a.trans_a = 1; a.red = (int)red;
-    a.vec_a = 0;
+    a.vec_a = (rows % 4 == 0) && (lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
     a.vec_b = (ncols % 4 == 0) && (ldb == ncols) && (((uintptr_t)Bm) % 16 == 0);
     if (ldb != ncols) return fail(T2_EINVAL, "internal: wgrad right operand must be dense");
-    dim3 grid(ceil_div(ncols, CG_BN), ceil_div(rows, CG_BM));
-    hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, tr->m->ctx->stream, a);
-    HIP_TRY(hipGetLastError());
-    return T2_OK;
+    return launch_wgrad(tr, a);
 }
 
 static int grad_dst(t2_trainer* tr, float* flat, const std::string& name, float** out) {
@@ -818,31 +1031,39 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     T2_TRY(t2_spec_loss(m->ctx, s->o_mel, s->i_targets, spec_mask, B, S * r, M, l3));
     T2_TRY(t2_binary_loss(m->ctx, s->o_stop, done, bin_mask, B, S, l3 + 4));
     hipLaunchKernelGGL(loss_grad_kernel, dim3(std::min<long long>(2048, (SB * N + 255) / 256)), dim3(256), 0, st, s->o_mel, s->i_targets,
-                       spec_mask, s->o_stop, done, bin_mask, l3 + 1, l3 + 5, tr->dY, B, S, M, r);
+                       spec_mask, s->o_stop, done, bin_mask, l3 + 1, l3 + 5, tr->dY, tr->dYf, (long long)MB * 16 * pad16(N), MB, B, S, M, r);
     auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (n + 255) / 256))); };
     const size_t lds = (size_t)attn_bwd_lds_floats(U, E, F, K) * 4;
     const int NJ = tr->NJ, NS = tr->NS;
+    hipLaunchKernelGGL(attention_image_kernel, dim3(1), dim3(256), 0, st, m->conv_w, m->conv_b, m->wloc, m->v_a, tr->ab_image, U, F, K);
     for (int t = S - 1; t >= 0; --t) {
         const int first = (t == S - 1) ? 1 : 0;
-        auto lstm_bwd = [&](int l, const float* go0, int ld0, const float* go1, int ld1, const float* gh1, int ldh1) {
+        auto lstm_args = [&](int l, const float* go0, int ld0, const float* gh1, int ldh1) {
             LstmBwdArgs a{};
             a.z = tp.z[l] + (size_t)t * B * 4 * H[l]; a.cprev = tp.cprev[l] + (size_t)t * B * H[l]; a.cnew = tp.cnew[l] + (size_t)t * B * H[l];
-            a.g_out0 = go0; a.ld_out0 = ld0; a.g_out1 = go1; a.ld_out1 = ld1;
+            a.g_out0 = go0; a.ld_out0 = ld0; a.g_out1 = nullptr; a.ld_out1 = 0;
             a.g_hs0 = tr->g_hp[l]; a.ld_hs0 = H[l]; a.g_hs1 = gh1; a.ld_hs1 = ldh1;
             a.g_c = tr->g_c[l]; a.g_hp = tr->g_hp[l];
             a.dz_plain = tr->dz[l] + (size_t)t * B * 4 * H[l]; a.dz_frag = tr->dzf[l];
             a.B = B; a.H = H[l]; a.MB = MB; a.t = t; a.stream = stream_of[l]; a.seed = tp.seed;
             a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias; a.first = first;
-            hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * H[l]), dim3(256), 0, st, a);
+            return a;
         };
-        // projections
-        hipLaunchKernelGGL(plain_to_frag_kernel, grid1((long long)B * N), dim3(256), 0, st, tr->dY + (size_t)t * B * N, N, tr->dYf, B, N, MB);
-        bwd_dense(tr, tr->projT, tr->dYf, tr->dy2, D);
-        // LSTM 2: input [y1 | h2_prev]
-        lstm_bwd(2, tr->dy2, D, nullptr, 0, tr->dX[2] + D, KX[2]);
-        bwd_dense(tr, tr->lstmT[2], tr->dzf[2], tr->dX[2], KX[2]);
-        // LSTM 1: input [h_att | ctx | h1_prev]
-        lstm_bwd(1, tr->dX[2], KX[2], nullptr, 0, tr->dX[1] + A + E, KX[1]);
+        // Every elementwise stage rides in the epilogue of the GEMM that produces its input gradient.
+        // projections -> d y2, LSTM 2 backward (input [y1 | h2_prev])
+        {
+            BwdEpi e{};
+            e.N = D; e.out_plain = nullptr; e.mode = 1;
+            e.lb = lstm_args(2, nullptr, 0, tr->dX[2] + D, KX[2]);
+            bwd_dense_epi(tr, tr->projT, tr->dYf + (size_t)t * MB * 16 * pad16(N), e);
+        }
+        // d [y1 | h2_prev], LSTM 1 backward (input [h_att | ctx | h1_prev])
+        {
+            BwdEpi e{};
+            e.N = KX[2]; e.out_plain = tr->dX[2]; e.plain_ld = KX[2]; e.mode = 1;
+            e.lb = lstm_args(1, nullptr, 0, tr->dX[1] + A + E, KX[1]);
+            bwd_dense_epi(tr, tr->lstmT[2], tr->dzf[2], e);
+        }
         bwd_dense(tr, tr->lstmT[1], tr->dzf[1], tr->dX[1], KX[1]);
         // attention
         {
@@ -852,7 +1073,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
             a.ctx = tp.ctx + (size_t)t * B * E;
             a.dctx0 = tr->dX[1] + A; a.ld_dctx0 = KX[1];
             a.dctx1 = first ? nullptr : tr->dX[0] + P_last; a.ld_dctx1 = KX[0];
-            a.g_state = tr->g_state; a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a;
+            a.g_state = tr->g_state; a.image = tr->ab_image;
             a.de = tr->de_all + (size_t)t * B * T; a.dctx_sum = tr->dctx_all + (size_t)t * E; a.ld_dctx_sum = (long long)S * E;
             a.part_dq = tr->part_dq; a.part_ds = tr->part_ds;
             a.B = B; a.T = T; a.U = U; a.E = E; a.F = F; a.K = K; a.NJ = NJ; a.first = first;
@@ -862,22 +1083,32 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
             f.B = B; f.T = T; f.U = U; f.K = K; f.NJ = NJ; f.MB = MB; f.cumulative = d.cumulative_weights; f.first = first;
             hipLaunchKernelGGL(attention_bwd_finish_kernel, dim3(B), dim3(256), 0, st, f);
         }
-        bwd_dense(tr, tr->wqT, tr->dqf, tr->dhq, A);
-        // attention LSTM: input [prenet out | ctx_prev | h_att_prev]; raw output feeds LSTM 1 and the query layer
-        lstm_bwd(0, tr->dX[1], KX[1], tr->dhq, A, tr->dX[0] + P_last + E, KX[0]);
-        bwd_dense(tr, tr->lstmT[0], tr->dzf[0], tr->dX[0], KX[0]);
-        // PreNets
+        // query layer -> d h_att (second source), attention LSTM backward (input [prenet out | ctx_prev | h_att_prev]; its raw
+        // output feeds LSTM 1 and the query layer)
+        {
+            BwdEpi e{};
+            e.N = A; e.out_plain = nullptr; e.mode = 1;
+            e.lb = lstm_args(0, tr->dX[1], KX[1], tr->dX[0] + P_last + E, KX[0]);
+            bwd_dense_epi(tr, tr->wqT, tr->dqf, e);
+        }
+        // d [prenet out | ctx_prev | h_att_prev], then the PreNets
         const float inv_keep = 1.0f / (1.0f - tp.prenet_drop_rate);
-        const float* g = tr->dX[0];
-        int ldg = KX[0];
-        for (int i = np - 1; i >= 0; --i) {
+        auto prenet_epi = [&](BwdEpi& e, int i) {
             const int P = d.prenet_units[i];
-            hipLaunchKernelGGL(prenet_bwd_kernel, grid1((long long)B * P), dim3(256), 0, st, g, ldg, tp.xp[i] + (size_t)t * B * P, inv_keep,
-                               tr->dpre[i] + (size_t)t * B * P, tr->dpref[i], B, P, MB);
-            if (i > 0) {
-                bwd_dense(tr, tr->prenetT[i], tr->dpref[i], tr->dxp, d.prenet_units[i - 1]);
-                g = tr->dxp; ldg = d.prenet_units[i - 1];
-            }
+            e.mode = 2; e.pn_y = tp.xp[i] + (size_t)t * B * P; e.pn_inv_keep = inv_keep;
+            e.pn_plain = tr->dpre[i] + (size_t)t * B * P; e.pn_frag = tr->dpref[i]; e.pn_P = P;
+        };
+        {
+            BwdEpi e{};
+            e.N = KX[0]; e.out_plain = tr->dX[0]; e.plain_ld = KX[0];
+            prenet_epi(e, np - 1);
+            bwd_dense_epi(tr, tr->lstmT[0], tr->dzf[0], e);
+        }
+        for (int i = np - 1; i >= 1; --i) {
+            BwdEpi e{};
+            e.N = d.prenet_units[i - 1]; e.out_plain = nullptr;
+            prenet_epi(e, i - 1);
+            bwd_dense_epi(tr, tr->prenetT[i], tr->dpref[i], e);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -927,7 +1158,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     {   // tape-wide attention pass: d keys and the parameter gradients from the taped d energies
         AttnParamArgs a{};
         a.keys = s->keys; a.lens = s->lens; a.q = tp.q; a.state_prev = tp.state_prev; a.de = tr->de_all;
-        a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a;
+        a.image = tr->ab_image;
         a.dkeys_part = tr->dkeys_part; a.p_convw = tr->p_convw; a.p_convb = tr->p_convb; a.p_wloc = tr->p_wloc; a.p_va = tr->p_va;
         a.B = B; a.T = T; a.U = U; a.F = F; a.K = K; a.NJ = NJ; a.S = S; a.NS = NS;
         hipLaunchKernelGGL(attention_param_grad_kernel, dim3(NJ, B, NS), dim3(T2_AB_THREADS), (size_t)attn_param_lds_floats(U, F, K) * 4, st, a);
@@ -983,21 +1214,31 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
 #define T2_STREAM_ZONE_ENC 30
 
 // per-channel batch statistics over all M rows (tf.layers.batch_normalization(training=True): padding rows included),
-// biased variance; one block per 64 channels, 4 row lanes, double accumulators, fixed summation order
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, float eps, float* __restrict__ mean,
-                                                       float* __restrict__ invstd, float* __restrict__ var_out) {
+// biased variance.  Two stages, fixed summation order: blocks of 64 channels x 4 row lanes over T2_BN_CHUNKS row ranges write
+// double partial sums part[chunk][2][C]; the final kernel adds the ranges in order.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, double* __restrict__ part) {
     __shared__ double s1[4][64], s2[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int per = (M + T2_BN_CHUNKS - 1) / T2_BN_CHUNKS, m0 = blockIdx.y * per, m1 = min(M, m0 + per);
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int m = rl; m < M; m += 4) { const double v = x[(size_t)m * C + c]; a += v; b += v * v; }
+        for (int m = m0 + rl; m < m1; m += 4) { const double v = x[(size_t)m * C + c]; a += v; b += v * v; }
     s1[rl][cl] = a; s2[rl][cl] = b;
     __syncthreads();
     if (rl == 0 && c < C) {
-        const double sum = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl], sq = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
-        const double mu = sum / M, var = fmax(sq / M - mu * mu, 0.0);
-        mean[c] = (float)mu; var_out[c] = (float)var; invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
     }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int M, int C, float eps, float* __restrict__ mean,
+                                                             float* __restrict__ invstd, float* __restrict__ var_out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double sum = 0.0, sq = 0.0;
+    for (int k = 0; k < T2_BN_CHUNKS; ++k) { sum += part[((size_t)k * 2 + 0) * C + c]; sq += part[((size_t)k * 2 + 1) * C + c]; }
+    const double mu = sum / M, var = fmax(sq / M - mu * mu, 0.0);
+    mean[c] = (float)mu; var_out[c] = (float)var; invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // Conv1d.call after the convolution (modules.py:152-156), training mode: batch norm with batch statistics -> relu -> dropout
@@ -1017,13 +1258,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // d gamma / d beta of the layer above: g = d_out * (out != 0) / keep (relu and dropout), xhat = (y - mean) * invstd
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ d_out, const float* __restrict__ out, const float* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float inv_keep,
-                                                            int M, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            int M, int C, double* __restrict__ part) {
     __shared__ double s1[4][64], s2[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int per = (M + T2_BN_CHUNKS - 1) / T2_BN_CHUNKS, m0 = blockIdx.y * per, m1 = min(M, m0 + per);
     double a = 0.0, b = 0.0;
     if (c < C) {
         const float mu = mean[c], is = invstd[c];
-        for (int m = rl; m < M; m += 4) {
+        for (int m = m0 + rl; m < m1; m += 4) {
             const size_t i = (size_t)m * C + c;
             const float g = out[i] != 0.f ? d_out[i] * inv_keep : 0.f;
             a += (double)g * (double)((y[i] - mu) * is);
@@ -1033,9 +1275,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     s1[rl][cl] = a; s2[rl][cl] = b;
     __syncthreads();
     if (rl == 0 && c < C) {
-        dgamma[c] = (float)(s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
-        dbeta[c] = (float)(s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl]);
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < T2_BN_CHUNKS; ++k) { a += part[((size_t)k * 2 + 0) * C + c]; b += part[((size_t)k * 2 + 1) * C + c]; }
+    dgamma[c] = (float)a; dbeta[c] = (float)b;
 }
 
 // dy = gamma * invstd * (g - dbeta / M - xhat * dgamma / M): gradient of the convolution output through the batch statistics
@@ -1207,7 +1457,9 @@ extern "C" int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, cons
         ConvLayer raw = m->enc_convs[i];
         raw.scale = nullptr; raw.shift = nullptr;               // the batch statistics replace the folded moving statistics
         T2_TRY(launch_conv(m, raw, et->x[i], cin, et->yraw[i], E, Mtot, T, 0, nullptr, 0));
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(E, 64)), dim3(256), 0, st, et->yraw[i], Mtot, E, d.bn_eps, et->mean[i], et->invstd[i], et->var[i]);
+        T2_TRY(bn_part_reserve(tr, E));
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(E, 64), T2_BN_CHUNKS), dim3(256), 0, st, et->yraw[i], Mtot, E, tr->bn_part);
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, st, tr->bn_part, Mtot, E, d.bn_eps, et->mean[i], et->invstd[i], et->var[i]);
         hipLaunchKernelGGL(bn_apply_kernel, grid1((long long)Mtot * E), dim3(256), 0, st, et->yraw[i], et->mean[i], et->invstd[i],
                            m->enc_bn_gamma[i], m->enc_bn_beta[i], drop_rate, seed, T2_STREAM_ENC_CONV + i, et->x[i + 1], (long long)Mtot, E);
         if (bn_stats_out) {
@@ -1344,8 +1596,10 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
     for (int i = L - 1; i >= 0; --i) {
         const int cin = i == 0 ? emb : E, k = d.enc_kernel, pad_l = (k - 1) / 2;
         const std::string pn = "encoder/conv1d_" + std::to_string(i);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(E, 64)), dim3(256), 0, st, d_out, et->x[i + 1], et->yraw[i], et->mean[i], et->invstd[i],
-                           inv_keep, Mtot, E, et->dgamma, et->dbeta);
+        T2_TRY(bn_part_reserve(tr, E));
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(E, 64), T2_BN_CHUNKS), dim3(256), 0, st, d_out, et->x[i + 1], et->yraw[i], et->mean[i], et->invstd[i],
+                           inv_keep, Mtot, E, tr->bn_part);
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, st, tr->bn_part, E, et->dgamma, et->dbeta);
         T2_TRY(grad_dst(tr, flat_grads, pn + "/batch_normalization/gamma", &g));
         HIP_TRY(hipMemcpyAsync(g, et->dgamma, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
         T2_TRY(grad_dst(tr, flat_grads, pn + "/batch_normalization/beta", &g));
@@ -1358,8 +1612,9 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
             ConvArgs a{};
             a.x = et->x[i]; a.ldx = cin; a.w = other; a.y = g; a.ldy = E;
             a.Mtot = k * cin; a.T = T; a.Cin = cin; a.N = E; a.ktaps = k; a.pad_l = pad_l; a.act = 0; a.trans_a = 1; a.red = Mtot;
-            a.vec_a = 0; a.vec_b = (E % 4 == 0) && (((uintptr_t)other) % 16 == 0);
-            hipLaunchKernelGGL(conv_gemm_kernel, dim3(ceil_div(E, CG_BN), ceil_div(k * cin, CG_BM)), dim3(256), 0, st, a);
+            a.vec_a = (cin % 4 == 0) && (((uintptr_t)et->x[i]) % 16 == 0);
+            a.vec_b = (E % 4 == 0) && (((uintptr_t)other) % 16 == 0);
+            T2_TRY(launch_wgrad(tr, a));
         }
         // data gradient: correlation of dy with the flipped, transposed kernel
         {

@@ -15,6 +15,11 @@ MID = T2Dims(num_symbols=64, num_mels=20, outputs_per_step=2, n_feed_frame=2, at
              embedding_dim=64, enc_conv_layers=3, enc_kernel=5, enc_units=64, prenet_units=(48, 32), attention_lstm_units=96,
              decoder_lstm_units=80, attention_dim=32, postnet_layers=5, postnet_kernel=5, postnet_channels=64, max_iters=40, min_iters=10)
 
+# attention_dim 128 (the benchmark profile's width) with several position chunks per row in the attention backward
+MID_U128 = T2Dims(num_symbols=64, num_mels=20, outputs_per_step=2, n_feed_frame=2, attention_kernel=31, attention_filters=32,
+                  embedding_dim=64, enc_conv_layers=3, enc_kernel=5, enc_units=64, prenet_units=(48, 32), attention_lstm_units=96,
+                  decoder_lstm_units=80, attention_dim=128, postnet_layers=5, postnet_kernel=5, postnet_channels=64, max_iters=40, min_iters=10)
+
 
 def _np(t):
     return t.detach().cpu().numpy()
@@ -63,7 +68,7 @@ def _labels(rng, B, S, r):
             "binary_loss_mask": (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)}
 
 
-@pytest.mark.parametrize("d,B,T,S", [(PROFILE_TINY, 3, 7, 5), (MID, 4, 13, 6), (MID, 18, 9, 4)])
+@pytest.mark.parametrize("d,B,T,S", [(PROFILE_TINY, 3, 7, 5), (MID, 4, 13, 6), (MID, 18, 9, 4), (MID, 3, 37, 5), (MID_U128, 2, 50, 4)])
 def test_decoder_backward_against_autograd(d, B, T, S):
     """BPTT through the training-mode decoder: every decoder/ and attention/ gradient and d loss / d memory against
     torch.autograd on the float64 restatement with the same sampled masks."""
