@@ -68,19 +68,20 @@ struct LstmBwdArgs {
 };
 
 // one (row, unit) element; g_extra: a part of the raw-output gradient the caller holds in a register
-__device__ __forceinline__ void lstm_bwd_elem(const LstmBwdArgs& a, int row, int u, float g_extra) {
+__device__ __forceinline__ void lstm_bwd_elem(const LstmBwdArgs& a, int row, int u, float g_extra, bool extra_is_state = false) {
     const int i = row * a.H + u;
     const float* z = a.z + (size_t)row * 4 * a.H;
     const float gi = sigmoidf_(z[u]), gj = tanhf(z[a.H + u]), gf = sigmoidf_(z[2 * a.H + u] + a.fb), go = sigmoidf_(z[3 * a.H + u]);
     const float cp = a.cprev[i], cn = a.cnew[i];
     const float mc = t2_u01(a.seed, a.stream, a.t, row, u) >= a.zc ? 1.f : 0.f;
     const float mh = t2_u01(a.seed, a.stream + 1, a.t, row, u) >= a.zh ? 1.f : 0.f;
-    float g_out = g_extra, g_hs = 0.f;
+    float g_out = extra_is_state ? 0.f : g_extra, g_hs = 0.f;
     if (a.g_out0) g_out += a.g_out0[(size_t)row * a.ld_out0 + u];
     if (a.g_out1) g_out += a.g_out1[(size_t)row * a.ld_out1 + u];
     if (!a.first) {
         if (a.g_hs0) g_hs += a.g_hs0[(size_t)row * a.ld_hs0 + u];
         if (a.g_hs1) g_hs += a.g_hs1[(size_t)row * a.ld_hs1 + u];
+        if (extra_is_state) g_hs += g_extra;
     }
     const float g_c = a.first ? 0.f : a.g_c[i];
     if (a.lens != nullptr && a.t >= a.lens[row]) {          // dead step: state passes through, no output, no gate gradient
@@ -117,11 +118,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 // Data-gradient GEMM of the backward recurrence, y[B][N] = x_frag[B][K] . W^T (skinny core, 16 columns per workgroup), with
 // the elementwise stage that consumes y fused into the epilogue:
 //   mode 1: ZoneoutLSTMCell backward of the layer whose raw-output gradient the columns [0, lb.H) are (g_extra = y);
+//   mode 3: ZoneoutLSTMCell backward of the SAME layer's previous step, whose state gradient the columns [col0, col0 + lb.H)
+//           are (encoder BiLSTM: d h_prev of step s is d state of step s - 1);
 //   mode 2: PreNet backward through dropout(relu(.)) on the columns [0, pn_P): d = (out != 0) ? y / keep : 0.
 struct BwdEpi {
     int N;
     float* out_plain; int plain_ld;          // y itself, may be null
-    int mode;
+    int mode, col0;
     LstmBwdArgs lb;
     const float* pn_y; float pn_inv_keep; float *pn_plain, *pn_frag; int pn_P;
 };
@@ -145,6 +148,8 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void bwd_dense_kernel(SkinnyCore
         if (e.out_plain != nullptr) e.out_plain[(size_t)row * e.plain_ld + col] = v;
         if (e.mode == 1) {
             if (col < e.lb.H) lstm_bwd_elem(e.lb, row, col, v);
+        } else if (e.mode == 3) {
+            if (col >= e.col0 && col < e.col0 + e.lb.H) lstm_bwd_elem(e.lb, row, col - e.col0, v, true);
         } else if (e.mode == 2) {
             if (col < e.pn_P) {
                 const size_t i = (size_t)row * e.pn_P + col;
@@ -169,14 +174,15 @@ __global__ __launch_bounds__(256) void prenet_bwd_kernel(const float* __restrict
     }
 }
 
-// column sums of a [rows][N] matrix (bias gradients), fixed order: stage 1 sums T2_CS_CHUNKS row ranges (64 columns x 4 row
+// column sums of a [rows][N] matrix (bias gradients), fixed order: stage 1 sums gridDim.y row ranges (64 columns x 4 row
 // lanes per block, double accumulators), stage 2 (batch_sum_kernel) adds the range partials in order
-#define T2_CS_CHUNKS 64
+#define T2_CS_CHUNKS 64        // row ranges of a wide matrix; narrow ones get more (col_sum)
+#define T2_CS_PART_FLOATS (64 * 4096)
 #define T2_BN_CHUNKS 32      // row ranges of the batch-norm reductions (bn_stats_kernel, bn_bwd_reduce_kernel)
 __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, long long rows, int N, float* __restrict__ part) {
     __shared__ double s1[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    const long long per = (rows + T2_CS_CHUNKS - 1) / T2_CS_CHUNKS, r0 = blockIdx.y * per, r1 = rows < r0 + per ? rows : r0 + per;
+    const long long per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = rows < r0 + per ? rows : r0 + per;
     double s = 0.0;
     if (c < N)
         for (long long r = r0 + rl; r < r1; r += 4) s += (double)x[r * N + c];
@@ -211,11 +217,12 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, c
 // attention_bwd_finish_kernel sums the partials in chunk order (deterministic) into dq (plain + frag16) and g_state.
 // The softmax-backward dot sum_j a_j da_j equals dctx . ctx_t + a . g_state (ctx_t = sum_j a_j values_j is on the tape),
 // which lets every chunk work without the other chunks' da.
-// After the loop attention_param_grad_kernel walks the tape per (row, chunk), recomputes du from de and accumulates
-// d keys and the parameter gradients (v_a, Wloc, conv kernel / bias).
+// The kernel also keeps du [B][T][U], f [B][T][F] and df [B][T][F] of the step tape-wide, so that after the loop
+//   d Wloc = f^T . du and d conv kernel = im2col(state_prev)^T . df are two split-K GEMMs over all S*B*T rows,
+//   d keys = sum_t du, d conv bias = column sums of df, and d v_a accumulates per step in the finish kernel.
 // Global-memory latency (about 1000 cycles a round trip) dominated the first version of these kernels: every load batch is
 // now issued before its first use, the parameters come as one prebuilt LDS image (attention_image_kernel) copied with
-// float4 loads, and the tape-wide kernel prefetches the next step's inputs while it works on the current one.
+// float4 loads.
 #define T2_AB_J 16
 #define T2_AB_THREADS 256
 
@@ -313,9 +320,8 @@ __device__ inline void ab_features(const AbLds& L, int F, int K, int tid) {
 }
 
 // du[j][u] = de[j] * v[u] * (1 - tanh(pre)^2) for the jn valid positions of the chunk (zero beyond); thread tile: one unit x
-// four positions.  ACC: also accumulate d keys (registers, dk[4][4]) and the per-(position group, unit) part of d v_a (LDS).
-template <bool ACC>
-__device__ inline void ab_du(const AbLds& L, const float (*kq)[4], int jn, int U, int F, int tid, float (*dk)[4], float* s_dva) {
+// four positions; s_dva[(position group, unit)] = this tile's part of d v_a = sum_j de[j] * tanh(pre).
+__device__ inline void ab_du(const AbLds& L, const float (*kq)[4], int jn, int U, int F, int tid, float* s_dva) {
     const int FP = L.FP;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -343,9 +349,8 @@ __device__ inline void ab_du(const AbLds& L, const float (*kq)[4], int jn, int U
                     dva = fmaf(de, th, dva);
                 }
                 L.du[(jb + jj) * U + u] = d;
-                if (ACC) dk[m][jj] += d;
             }
-            if (ACC) s_dva[idx] += dva;
+            s_dva[idx] = dva;
         }
     }
 }
@@ -385,11 +390,14 @@ struct AttnBwdArgs {
     const float* image;                       // attention_image_kernel's output
     float* de;                                // [B][T] this step's slice of the tape-wide d energies
     float* dctx_sum; long long ld_dctx_sum;   // row b at dctx_sum + b * ld: this step's slice of the tape-wide d context
-    float *part_dq, *part_ds;                 // [B][NJ][U], [B][NJ][J + K - 1]
+    float *part_dq, *part_dva, *part_ds;      // [B][NJ][U], [B][NJ][U], [B][NJ][J + K - 1]
+    float *du_out, *f_out, *df_out;           // this step's slices of the tape-wide du [B][T][U], f [B][T][F], df [B][T][F]
     int B, T, U, E, F, K, NJ, first;
 };
 
-__host__ __device__ inline int attn_bwd_lds_floats(int U, int E, int F, int K) { return ab_common_floats(U, F, K) + ab_r4(E) + 64; }
+__host__ __device__ inline int attn_bwd_lds_floats(int U, int E, int F, int K) {
+    return ab_common_floats(U, F, K) + ab_r4(E) + 64 + ab_r4((T2_AB_J / 4) * U);
+}
 
 __global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -397,11 +405,17 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArg
     constexpr int NW = T2_AB_THREADS / 64, J = T2_AB_J, JW = J / NW;
     const int T = a.T, U = a.U, E = a.E, F = a.F, K = a.K;
     const int len = a.lens[b], j0 = ch * J;
-    if (ch > 0 && j0 >= len) return;          // masked chunk: its partials stay zero (workspace zeroed per call)
+    const int jt = min(J, T - j0);            // rows of the chunk that exist
+    if (ch > 0 && j0 >= len) {                // masked chunk: its partials stay zero (workspace zeroed per call), tape rows are zero
+        for (int i = tid; i < jt * U; i += T2_AB_THREADS) a.du_out[((size_t)b * T + j0) * U + i] = 0.f;
+        for (int i = tid; i < jt * F; i += T2_AB_THREADS) { a.f_out[((size_t)b * T + j0) * F + i] = 0.f; a.df_out[((size_t)b * T + j0) * F + i] = 0.f; }
+        return;
+    }
     const int jn = max(0, min(J, len - j0)), pad_l = (K - 1) / 2, NI = J + K - 1;
     AbLds L;
     float* s_dctx = ab_carve(sm, U, F, K, L);
     float* s_red = s_dctx + ab_r4(E);         // [NW] dot partials, [16..32) da
+    float* s_dva = s_red + 64;                // [(J / 4)][U]
     // ---- every global load of the kernel is issued here
     float r_dctx[2], r_ctx[2];                // first 512 columns; the rest (E > 512) goes through the slow loop below
 #pragma unroll
@@ -502,16 +516,25 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArg
         if (j0 + tid < T) a.de[(size_t)b * T + j0 + tid] = de;
     }
     ab_lds_barrier();
-    ab_du<false>(L, kq, jn, U, F, tid, nullptr, nullptr);
+    ab_du(L, kq, jn, U, F, tid, s_dva);
     ab_lds_barrier();
     for (int u = tid; u < U; u += T2_AB_THREADS) {
-        float s = 0.f;
+        float s = 0.f, sv = 0.f;
 #pragma unroll
         for (int j = 0; j < J; ++j) s += L.du[j * U + u];
+#pragma unroll
+        for (int jq = 0; jq < J / 4; ++jq) sv += s_dva[jq * U + u];
         a.part_dq[((size_t)b * a.NJ + ch) * U + u] = s;
+        a.part_dva[((size_t)b * a.NJ + ch) * U + u] = sv;
     }
+    for (int i = tid; i < jt * U; i += T2_AB_THREADS) a.du_out[((size_t)b * T + j0) * U + i] = L.du[i];
     ab_df(L, U, F, tid);
     ab_lds_barrier();
+    for (int i = tid; i < jt * F; i += T2_AB_THREADS) {
+        const int j = i / F, c = i - j * F;
+        a.f_out[((size_t)b * T + j0) * F + i] = L.f[j * L.FP + c];
+        a.df_out[((size_t)b * T + j0) * F + i] = L.df[j * L.FP + c];
+    }
     // partial d state_prev over the chunk + halo: ds[i] = sum_{j, c} w[i - j][c] * df[j][c], i <-> position j0 - pad_l + i
     const int FP = L.FP;
     for (int i0 = 0; i0 < NI; i0 += T2_AB_THREADS / 4) {
@@ -530,8 +553,8 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArg
 }
 
 struct AttnBwdFinishArgs {
-    const float *part_dq, *part_ds;
-    float *dq_plain, *dq_frag, *g_state;
+    const float *part_dq, *part_dva, *part_ds;
+    float *dq_plain, *dq_frag, *g_state, *p_va;      // p_va [B][U]: d v_a per row, accumulated over the steps
     int B, T, U, K, NJ, MB, cumulative, first;
 };
 
@@ -539,9 +562,11 @@ __global__ __launch_bounds__(256) void attention_bwd_finish_kernel(AttnBwdFinish
     const int b = blockIdx.x, tid = threadIdx.x, NI = T2_AB_J + a.K - 1, pad_l = (a.K - 1) / 2;
     for (int u = tid; u < a.U; u += 256) {
         float s = 0.f;
-        for (int ch = 0; ch < a.NJ; ++ch) s += a.part_dq[((size_t)b * a.NJ + ch) * a.U + u];
+        float sv = a.first ? 0.f : a.p_va[(size_t)b * a.U + u];
+        for (int ch = 0; ch < a.NJ; ++ch) { s += a.part_dq[((size_t)b * a.NJ + ch) * a.U + u]; sv += a.part_dva[((size_t)b * a.NJ + ch) * a.U + u]; }
         a.dq_plain[(size_t)b * a.U + u] = s;
         a.dq_frag[frag_idx(b, u, a.MB)] = s;
+        a.p_va[(size_t)b * a.U + u] = sv;
     }
     for (int p = tid; p < a.T; p += 256) {
         float s = (a.cumulative && !a.first) ? a.g_state[(size_t)b * a.T + p] : 0.f;    // state_t = state_{t-1} + a_t
@@ -550,127 +575,6 @@ __global__ __launch_bounds__(256) void attention_bwd_finish_kernel(AttnBwdFinish
             if (i >= 0 && i < NI) s += a.part_ds[((size_t)b * a.NJ + ch) * NI + i];
         }
         a.g_state[(size_t)b * a.T + p] = s;
-    }
-}
-
-// Tape-wide part: one workgroup per (chunk, row, step segment) walks its steps, recomputes du from the taped de / q /
-// state_prev and accumulates d keys (registers) and the per-workgroup partial parameter gradients (LDS).
-struct AttnParamArgs {
-    const float* keys; const int* lens;
-    const float *q, *state_prev, *de;         // tape-wide [S][B][U], [S][B][T], [S][B][T]
-    const float* image;
-    float* dkeys_part;                        // [NS][B][T][U]
-    float *p_convw, *p_convb, *p_wloc, *p_va; // [NP][K*F], [NP][F], [NP][F*U], [NP][U]; NP = NS * B * NJ
-    int B, T, U, F, K, NJ, S, NS;
-};
-
-__host__ __device__ inline int attn_param_lds_floats(int U, int F, int K) {
-    return ab_common_floats(U, F, K) + ab_r4(F * U) + ab_r4(K * F) + ab_r4(F) + ab_r4((T2_AB_J / 4) * U);
-}
-
-__global__ __launch_bounds__(T2_AB_THREADS) void attention_param_grad_kernel(AttnParamArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int ch = blockIdx.x, b = blockIdx.y, ns = blockIdx.z, tid = threadIdx.x;
-    constexpr int J = T2_AB_J;
-    const int T = a.T, U = a.U, F = a.F, K = a.K, B = a.B;
-    const int len = a.lens[b], j0 = ch * J;
-    if (j0 >= len) return;                    // masked chunk: outputs stay zero (workspace zeroed per call)
-    const int jn = min(J, len - j0), pad_l = (K - 1) / 2, NI = J + K - 1;
-    AbLds L;
-    float* s_dwl = ab_carve(sm, U, F, K, L);
-    float* s_dcw = s_dwl + ab_r4(F * U);
-    float* s_dcb = s_dcw + ab_r4(K * F);
-    float* s_dva = s_dcb + ab_r4(F);
-    const int FP = L.FP;
-    const int per = (a.S + a.NS - 1) / a.NS, t0 = ns * per, t1 = min(a.S, t0 + per);
-    // per-step inputs: element i of [sp (NI) | q (U) | de (J)], two per thread, fetched one step ahead
-    auto fetch = [&](int t, int i) -> float {
-        const size_t row = (size_t)t * B + b;
-        if (i < NI) { const int p = j0 - pad_l + i; return (p >= 0 && p < T) ? a.state_prev[row * T + p] : 0.f; }
-        i -= NI;
-        if (i < U) return a.q[row * U + i];
-        i -= U;
-        return i < jn ? a.de[row * T + j0 + i] : 0.f;
-    };
-    auto stage = [&](int i, float v) {
-        if (i < NI) L.sp[i] = v;
-        else if (i < NI + U) L.q[i - NI] = v;
-        else if (i < NI + U + J) L.de[i - NI - U] = v;
-    };
-    const int nin = NI + U + J;               // <= 2 * T2_AB_THREADS for U <= 256, K <= 200
-    float nx0 = 0.f, nx1 = 0.f;
-    if (t0 < t1) { if (tid < nin) nx0 = fetch(t0, tid); if (tid + T2_AB_THREADS < nin) nx1 = fetch(t0, tid + T2_AB_THREADS); }
-    float kq[4][4];
-    ab_load_keys(a.keys + ((size_t)b * T + j0) * U, jn, U, tid, kq);
-    ab_load_image(sm, a.image, ab_image_floats(U, F, K) / 4, tid);
-    for (int i = tid; i < F * U; i += T2_AB_THREADS) s_dwl[i] = 0.f;
-    for (int i = tid; i < K * F; i += T2_AB_THREADS) s_dcw[i] = 0.f;
-    for (int i = tid; i < F; i += T2_AB_THREADS) s_dcb[i] = 0.f;
-    for (int i = tid; i < (J / 4) * U; i += T2_AB_THREADS) s_dva[i] = 0.f;
-    float dk[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) dk[m][jj] = 0.f;
-    const int FG = (F + 3) / 4;
-    for (int t = t0; t < t1; ++t) {
-        ab_lds_barrier();
-        stage(tid, nx0); stage(tid + T2_AB_THREADS, nx1);
-        if (t + 1 < t1) { if (tid < nin) nx0 = fetch(t + 1, tid); if (tid + T2_AB_THREADS < nin) nx1 = fetch(t + 1, tid + T2_AB_THREADS); }
-        ab_lds_barrier();
-        ab_features(L, F, K, tid);
-        ab_lds_barrier();
-        ab_du<true>(L, kq, jn, U, F, tid, dk, s_dva);
-        ab_lds_barrier();
-        ab_df(L, U, F, tid);
-        // d Wloc[c][u] += sum_j f[j][c] * du[j][u]; thread tile: one unit x four filters
-        for (int idx = tid; idx < FG * U; idx += T2_AB_THREADS) {
-            const int cq = idx / U, u = idx - cq * U, c0 = cq * 4;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int j = 0; j < jn; ++j) {
-                const float d = L.du[j * U + u];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) acc[cc] = fmaf(L.f[j * FP + min(c0 + cc, F - 1)], d, acc[cc]);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-                if (c0 + cc < F) s_dwl[(c0 + cc) * U + u] += acc[cc];
-        }
-        ab_lds_barrier();
-        for (int i = tid; i < K * F; i += T2_AB_THREADS) {
-            const int k = i / F, c = i - k * F;
-            float acc = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < jn; ++j) acc = fmaf(L.sp[j + k], L.df[j * FP + c], acc);
-            s_dcw[i] += acc;
-        }
-        for (int c = tid; c < F; c += T2_AB_THREADS) {
-            float acc = 0.f;
-            for (int j = 0; j < jn; ++j) acc += L.df[j * FP + c];
-            s_dcb[c] += acc;
-        }
-    }
-    ab_lds_barrier();
-    float* dkp = a.dkeys_part + (((size_t)ns * B + b) * T + j0) * U;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int idx = tid + m * T2_AB_THREADS;
-        if (idx < (J / 4) * U) {
-            const int jq = idx / U, u = idx - jq * U;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jq * 4 + jj < jn) dkp[(size_t)(jq * 4 + jj) * U + u] = dk[m][jj];
-        }
-    }
-    const size_t wg = ((size_t)ns * B + b) * a.NJ + ch;
-    for (int i = tid; i < F * U; i += T2_AB_THREADS) a.p_wloc[wg * F * U + i] = s_dwl[i];
-    for (int i = tid; i < K * F; i += T2_AB_THREADS) a.p_convw[wg * K * F + i] = s_dcw[i];
-    for (int i = tid; i < F; i += T2_AB_THREADS) a.p_convb[wg * F + i] = s_dcb[i];
-    for (int u = tid; u < U; u += T2_AB_THREADS) {
-        float s = 0.f;
-        for (int jq = 0; jq < J / 4; ++jq) s += s_dva[jq * U + u];
-        a.p_va[wg * U + u] = s;
     }
 }
 
@@ -707,12 +611,13 @@ struct t2_trainer {
     float *dpre[T2_MAX_PRENET_LAYERS] = {}, *dpref[T2_MAX_PRENET_LAYERS] = {}, *xin = nullptr;
     float *dX[3] = {}, *dy2 = nullptr, *dhq = nullptr, *dxp = nullptr;
     float *g_c[3] = {}, *g_hp[3] = {}, *g_state = nullptr;
-    float *dkeys = nullptr, *dvalues = nullptr, *p_convw = nullptr, *p_convb = nullptr, *p_wloc = nullptr, *p_va = nullptr;
+    float *dkeys = nullptr, *dvalues = nullptr, *p_va = nullptr;
     float* ab_image = nullptr;
-    float *de_all = nullptr, *dctx_all = nullptr, *part_dq = nullptr, *part_ds = nullptr, *dkeys_part = nullptr;
-    int NJ = 0, NS = 1;                 // attention backward: position chunks per row, step segments of the tape-wide kernel
+    float *de_all = nullptr, *dctx_all = nullptr, *part_dq = nullptr, *part_dva = nullptr, *part_ds = nullptr;
+    float *du_all = nullptr, *f_all = nullptr, *df_all = nullptr;      // own allocation: every row is written each call, never zero-filled
+    int NJ = 0;                         // attention backward: position chunks per row
     float *tmp = nullptr, *loss3 = nullptr;
-    float* cs_part = nullptr; int cs_cols = 0;     // column-sum partials [T2_CS_CHUNKS][cs_cols]
+    float* cs_part = nullptr;                      // column-sum partials [chunks][N], T2_CS_PART_FLOATS
     double* bn_part = nullptr; int bn_cols = 0;    // batch-norm reduction partials [T2_BN_CHUNKS][2][bn_cols]
     float* wg_part = nullptr;                      // split-K partials of the weight-gradient GEMMs [splits][rows][cols]
     std::map<std::string, long long> offsets;      // flat-gradient layout given by the caller
@@ -746,6 +651,7 @@ extern "C" int t2_trainer_destroy(t2_trainer* tr) {
     if (tr->cs_part) (void)hipFree(tr->cs_part);
     if (tr->wg_part) (void)hipFree(tr->wg_part);
     if (tr->bn_part) (void)hipFree(tr->bn_part);
+    if (tr->du_all) (void)hipFree(tr->du_all);
     for (void* p : tr->allocs) (void)hipFree(p);
     if (tr->state) state_free(tr->state);
     delete tr;
@@ -877,13 +783,11 @@ static int trainer_setup_backward(t2_trainer* tr) {
     for (int i = 0; i < np; ++i) { o_dpre[i] = carve(SB * d.prenet_units[i]); o_dpref[i] = carve((size_t)R * pad16(d.prenet_units[i])); pmax = std::max(pmax, d.prenet_units[i]); }
     const size_t o_xin = carve(SB * M * nf), o_dy2 = carve((size_t)B * D), o_dhq = carve((size_t)B * A), o_dxp = carve((size_t)B * pmax);
     const size_t o_gs = carve((size_t)B * T), o_dk = carve((size_t)B * T * U), o_dv = carve((size_t)B * T * E);
-    const int NJ = ceil_div(T, T2_AB_J), NS = std::max(1, std::min({8, S, ceil_div(512, NJ * B)}));
-    const size_t NP = (size_t)NS * B * NJ;
-    tr->NJ = NJ; tr->NS = NS;
-    const size_t o_pcw = carve(NP * d.attention_kernel * d.attention_filters), o_pcb = carve(NP * d.attention_filters),
-                 o_pwl = carve(NP * d.attention_filters * U), o_pva = carve(NP * U);
-    const size_t o_de = carve(SB * T), o_dctx = carve(SB * E), o_pdq = carve((size_t)B * NJ * U),
-                 o_pds = carve((size_t)B * NJ * (T2_AB_J + d.attention_kernel - 1)), o_dkp = carve((size_t)NS * B * T * U),
+    const int NJ = ceil_div(T, T2_AB_J);
+    tr->NJ = NJ;
+    const size_t o_pva = carve((size_t)B * U);
+    const size_t o_de = carve(SB * T), o_dctx = carve(SB * E), o_pdq = carve((size_t)B * NJ * U), o_pdva = carve((size_t)B * NJ * U),
+                 o_pds = carve((size_t)B * NJ * (T2_AB_J + d.attention_kernel - 1)),
                  o_img = carve((size_t)ab_image_floats(U, d.attention_filters, d.attention_kernel));
     if (T2_AB_J + d.attention_kernel - 1 > T2_AB_THREADS || U > 256)
         return fail(T2_EINVAL, "attention kernel size / attention_dim too large for the attention backward kernels");
@@ -900,15 +804,21 @@ static int trainer_setup_backward(t2_trainer* tr) {
     for (int i = 0; i < np; ++i) { tr->dpre[i] = (float*)(p + o_dpre[i]); tr->dpref[i] = (float*)(p + o_dpref[i]); }
     tr->xin = (float*)(p + o_xin); tr->dy2 = (float*)(p + o_dy2); tr->dhq = (float*)(p + o_dhq); tr->dxp = (float*)(p + o_dxp);
     tr->g_state = (float*)(p + o_gs); tr->dkeys = (float*)(p + o_dk); tr->dvalues = (float*)(p + o_dv);
-    tr->p_convw = (float*)(p + o_pcw); tr->p_convb = (float*)(p + o_pcb); tr->p_wloc = (float*)(p + o_pwl); tr->p_va = (float*)(p + o_pva);
+    tr->p_va = (float*)(p + o_pva); tr->part_dva = (float*)(p + o_pdva);
     tr->tmp = (float*)(p + o_tmp); tr->loss3 = (float*)(p + o_loss);
     tr->de_all = (float*)(p + o_de); tr->dctx_all = (float*)(p + o_dctx); tr->part_dq = (float*)(p + o_pdq); tr->part_ds = (float*)(p + o_pds);
-    tr->dkeys_part = (float*)(p + o_dkp); tr->ab_image = (float*)(p + o_img);
-    const size_t lds = (size_t)std::max(attn_bwd_lds_floats(U, E, d.attention_filters, d.attention_kernel),
-                                        attn_param_lds_floats(U, d.attention_filters, d.attention_kernel)) * 4;
+    tr->ab_image = (float*)(p + o_img);
+    {   // tape-wide du / f / df of the attention backward: written row by row every call, so outside the zero-filled slab
+        const size_t rows = SB * T, nU = align_up(rows * U * 4, 256), nF = align_up(rows * d.attention_filters * 4, 256);
+        char* q = nullptr;
+        hipError_t e = hipMalloc((void**)&q, nU + 2 * nF);
+        if (e != hipSuccess) return fail(T2_ENOMEM, "hipMalloc(attention backward tape, %zu bytes) failed: %s", nU + 2 * nF, hipGetErrorString(e));
+        tr->du_all = (float*)q; tr->f_all = (float*)(q + nU); tr->df_all = (float*)(q + nU + nF);
+        if (rows > (size_t)INT_MAX) return fail(T2_EINVAL, "S * B * T_in too large");
+    }
+    const size_t lds = (size_t)attn_bwd_lds_floats(U, E, d.attention_filters, d.attention_kernel) * 4;
     if (lds > 150 * 1024) return fail(T2_EINVAL, "attention dimensions too large for the attention backward kernels' LDS");
     HIP_TRY(hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)attention_param_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return T2_OK;
 }
 
@@ -928,14 +838,13 @@ static int bn_part_reserve(t2_trainer* tr, int C) {
 
 // out[N] = column sums of x [rows][N]
 static int col_sum(t2_trainer* tr, const float* x, long long rows, int N, float* out) {
-    if (N > tr->cs_cols) {
-        if (tr->cs_part) { HIP_TRY(hipStreamSynchronize(tr->m->ctx->stream)); (void)hipFree(tr->cs_part); tr->cs_part = nullptr; }
-        tr->cs_cols = std::max(N, 4096);
-        HIP_TRY(hipMalloc((void**)&tr->cs_part, (size_t)T2_CS_CHUNKS * tr->cs_cols * 4));
-    }
+    if (N > T2_CS_PART_FLOATS / T2_CS_CHUNKS) return fail(T2_EINVAL, "internal: col_sum of %d columns", N);
+    if (!tr->cs_part) HIP_TRY(hipMalloc((void**)&tr->cs_part, (size_t)T2_CS_PART_FLOATS * 4));
+    const int cb = ceil_div(N, 64);
+    const int chunks = (int)std::max<long long>(1, std::min<long long>({(long long)std::max(T2_CS_CHUNKS, 2048 / cb), (long long)T2_CS_PART_FLOATS / N, (rows + 63) / 64}));
     hipStream_t st = tr->m->ctx->stream;
-    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(ceil_div(N, 64), T2_CS_CHUNKS), dim3(256), 0, st, x, rows, N, tr->cs_part);
-    hipLaunchKernelGGL(batch_sum_kernel, dim3(std::max(1, std::min(1024, ceil_div(N, 256)))), dim3(256), 0, st, tr->cs_part, T2_CS_CHUNKS, (long long)N, out);
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cb, chunks), dim3(256), 0, st, x, rows, N, tr->cs_part);
+    hipLaunchKernelGGL(batch_sum_kernel, dim3(std::max(1, std::min(1024, ceil_div(N, 256)))), dim3(256), 0, st, tr->cs_part, chunks, (long long)N, out);
     return T2_OK;
 }
 
@@ -967,7 +876,7 @@ static void bwd_dense(t2_trainer* tr, const Packed& wT, float* x_frag, float* y,
 static int launch_wgrad(t2_trainer* tr, ConvArgs a) {
     hipStream_t st = tr->m->ctx->stream;
     const int gx = ceil_div(a.N, CG_BN), gy = ceil_div(a.Mtot, CG_BM), nk = ceil_div(a.red, CG_BK);
-    long long z = std::min<long long>({(long long)ceil_div(1024, gx * gy), (long long)nk / 8, (long long)(T2_WG_PART_FLOATS / ((size_t)a.Mtot * a.N)), 64LL});
+    long long z = std::min<long long>({(long long)ceil_div(1024, gx * gy), (long long)nk / 8, (long long)(T2_WG_PART_FLOATS / ((size_t)a.Mtot * a.N)), 1024LL});
     if (a.ldy != a.N || z < 2) z = 1;
     a.splits = (int)z; a.part = nullptr;
     if (z > 1) {
@@ -1034,7 +943,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
                        spec_mask, s->o_stop, done, bin_mask, l3 + 1, l3 + 5, tr->dY, tr->dYf, (long long)MB * 16 * pad16(N), MB, B, S, M, r);
     auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (n + 255) / 256))); };
     const size_t lds = (size_t)attn_bwd_lds_floats(U, E, F, K) * 4;
-    const int NJ = tr->NJ, NS = tr->NS;
+    const int NJ = tr->NJ;
     hipLaunchKernelGGL(attention_image_kernel, dim3(1), dim3(256), 0, st, m->conv_w, m->conv_b, m->wloc, m->v_a, tr->ab_image, U, F, K);
     for (int t = S - 1; t >= 0; --t) {
         const int first = (t == S - 1) ? 1 : 0;
@@ -1075,11 +984,12 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
             a.dctx1 = first ? nullptr : tr->dX[0] + P_last; a.ld_dctx1 = KX[0];
             a.g_state = tr->g_state; a.image = tr->ab_image;
             a.de = tr->de_all + (size_t)t * B * T; a.dctx_sum = tr->dctx_all + (size_t)t * E; a.ld_dctx_sum = (long long)S * E;
-            a.part_dq = tr->part_dq; a.part_ds = tr->part_ds;
+            a.part_dq = tr->part_dq; a.part_dva = tr->part_dva; a.part_ds = tr->part_ds;
+            a.du_out = tr->du_all + (size_t)t * B * T * U; a.f_out = tr->f_all + (size_t)t * B * T * F; a.df_out = tr->df_all + (size_t)t * B * T * F;
             a.B = B; a.T = T; a.U = U; a.E = E; a.F = F; a.K = K; a.NJ = NJ; a.first = first;
             hipLaunchKernelGGL(attention_bwd_kernel, dim3(NJ, B), dim3(T2_AB_THREADS), lds, st, a);
             AttnBwdFinishArgs f{};
-            f.part_dq = tr->part_dq; f.part_ds = tr->part_ds; f.dq_plain = tr->dq + (size_t)t * B * U; f.dq_frag = tr->dqf; f.g_state = tr->g_state;
+            f.part_dq = tr->part_dq; f.part_dva = tr->part_dva; f.part_ds = tr->part_ds; f.p_va = tr->p_va; f.dq_plain = tr->dq + (size_t)t * B * U; f.dq_frag = tr->dqf; f.g_state = tr->g_state;
             f.B = B; f.T = T; f.U = U; f.K = K; f.NJ = NJ; f.MB = MB; f.cumulative = d.cumulative_weights; f.first = first;
             hipLaunchKernelGGL(attention_bwd_finish_kernel, dim3(B), dim3(256), 0, st, f);
         }
@@ -1155,23 +1065,23 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     T2_TRY(bwd_wgrad(tr, tp.hraw[0], A, A, tr->dq, U, U, SB, g, U));
     T2_TRY(grad_dst(tr, flat_grads, "attention/attention_bias", &g));
     T2_TRY(col_sum(tr, tr->dq, (long long)SB, U, g));
-    {   // tape-wide attention pass: d keys and the parameter gradients from the taped d energies
-        AttnParamArgs a{};
-        a.keys = s->keys; a.lens = s->lens; a.q = tp.q; a.state_prev = tp.state_prev; a.de = tr->de_all;
-        a.image = tr->ab_image;
-        a.dkeys_part = tr->dkeys_part; a.p_convw = tr->p_convw; a.p_convb = tr->p_convb; a.p_wloc = tr->p_wloc; a.p_va = tr->p_va;
-        a.B = B; a.T = T; a.U = U; a.F = F; a.K = K; a.NJ = NJ; a.S = S; a.NS = NS;
-        hipLaunchKernelGGL(attention_param_grad_kernel, dim3(NJ, B, NS), dim3(T2_AB_THREADS), (size_t)attn_param_lds_floats(U, F, K) * 4, st, a);
-        const int NP = NS * B * NJ;
-        hipLaunchKernelGGL(batch_sum_kernel, grid1((long long)B * T * U), dim3(256), 0, st, tr->dkeys_part, NS, (long long)B * T * U, tr->dkeys);
+    {   // tape-wide attention gradients from the taped du / f / df (rows (t, b, j))
+        const long long rows = (long long)SB * T;
+        hipLaunchKernelGGL(batch_sum_kernel, grid1((long long)B * T * U), dim3(256), 0, st, tr->du_all, S, (long long)B * T * U, tr->dkeys);
         T2_TRY(grad_dst(tr, flat_grads, "attention/attention_variable", &g));
-        hipLaunchKernelGGL(batch_sum_kernel, grid1(U), dim3(256), 0, st, tr->p_va, NP, (long long)U, g);
-        T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/kernel", &g));
-        hipLaunchKernelGGL(batch_sum_kernel, grid1(K * F), dim3(256), 0, st, tr->p_convw, NP, (long long)K * F, g);
-        T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/bias", &g));
-        hipLaunchKernelGGL(batch_sum_kernel, grid1(F), dim3(256), 0, st, tr->p_convb, NP, (long long)F, g);
+        hipLaunchKernelGGL(batch_sum_kernel, grid1(U), dim3(256), 0, st, tr->p_va, B, (long long)U, g);
         T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_layer/kernel", &g));
-        hipLaunchKernelGGL(batch_sum_kernel, grid1(F * U), dim3(256), 0, st, tr->p_wloc, NP, (long long)F * U, g);
+        T2_TRY(bwd_wgrad(tr, tr->f_all, F, F, tr->du_all, U, U, rows, g, U));
+        T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/kernel", &g));
+        {   // [K][1][F] = im2col(state_prev)^T . df, taps reaching outside a row's [0, T) read zero
+            ConvArgs a{};
+            a.x = tp.state_prev; a.ldx = 1; a.w = tr->df_all; a.y = g; a.ldy = F;
+            a.Mtot = K; a.T = T; a.Cin = 1; a.N = F; a.ktaps = K; a.pad_l = (K - 1) / 2; a.act = 0; a.trans_a = 1; a.red = (int)rows;
+            a.vec_a = 0; a.vec_b = (F % 4 == 0) && (((uintptr_t)tr->df_all) % 16 == 0);
+            T2_TRY(launch_wgrad(tr, a));
+        }
+        T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/bias", &g));
+        T2_TRY(col_sum(tr, tr->df_all, rows, F, g));
         // d values[b][j][:] = sum_t a_t[b][j] * dctx_t[b][:]: one [T x S] . [S x E] product per row
         for (int b = 0; b < B; ++b)
             T2_TRY(bwd_wgrad(tr, s->o_hist + (size_t)b * T, B * T, T, tr->dctx_all + (size_t)b * S * E, E, E, S, tr->dvalues + (size_t)b * T * E, E));
@@ -1313,26 +1223,26 @@ __global__ __launch_bounds__(256) void seq_gather_kernel(const float* __restrict
     }
 }
 
-// gradient of the raw output of step s of one direction: dmemory[b][pos][off + u] for live rows
+// gradient of the raw output of every step of one direction: g[s][b][u] = dmemory[b][pos][off + u] for live rows
 __global__ __launch_bounds__(256) void enc_gout_kernel(const float* __restrict__ dmem, const int* __restrict__ lens, float* __restrict__ g,
-                                                       int B, int T, int E, int H, int off, int s, int reverse) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * H; i += gridDim.x * blockDim.x) {
-        const int b = i / H, u = i - b * H;
+                                                       int B, int T, int E, int H, int off, int reverse) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)T * B * H; i += (long long)gridDim.x * blockDim.x) {
+        const int u = (int)(i % H), b = (int)((i / H) % B), s = (int)(i / ((long long)H * B));
         const int len = lens[b];
         const int pos = reverse ? len - 1 - s : s;
         g[i] = (s < len) ? dmem[((size_t)b * T + pos) * E + off + u] : 0.f;
     }
 }
 
-// d(conv stack output)[b][pos][:] += dX[b][:C] of step s (live rows)
+// d(conv stack output)[b][pos][:] += dX[s][b][:C] over all steps s (live rows; every (b, pos) has one step per direction)
 __global__ __launch_bounds__(256) void enc_dx_scatter_kernel(const float* __restrict__ dX, int ld, const int* __restrict__ lens, float* __restrict__ dxc,
-                                                             int B, int T, int C, int s, int reverse) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * C; i += gridDim.x * blockDim.x) {
-        const int b = i / C, c = i - b * C;
+                                                             int B, int T, int C, int reverse) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)T * B * C; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), b = (int)((i / C) % B), s = (int)(i / ((long long)C * B));
         const int len = lens[b];
         if (s >= len) continue;
         const int pos = reverse ? len - 1 - s : s;
-        dxc[((size_t)b * T + pos) * C + c] += dX[(size_t)b * ld + c];
+        dxc[((size_t)b * T + pos) * C + c] += dX[((size_t)s * B + b) * ld + c];
     }
 }
 
@@ -1531,8 +1441,9 @@ static int enc_setup_backward(t2_trainer* tr, EncTape* et) {
     const int cmax = std::max(E, emb);
     size_t off = 0;
     auto carve = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
-    const size_t o_xs = carve((size_t)T * B * Cx), o_go = carve((size_t)B * He), o_dzp = carve((size_t)T * B * 4 * He), o_dzf = carve((size_t)R * pad16(4 * He));
-    const size_t o_dX = carve((size_t)B * (Cx + He)), o_gc = carve((size_t)B * He), o_ghp = carve((size_t)B * He);
+    const size_t o_xs = carve((size_t)T * B * Cx), o_go = carve((size_t)T * B * He), o_dzp = carve((size_t)T * B * 4 * He),
+                 o_dzf = carve((size_t)2 * R * pad16(4 * He));          // ping-pong: a step's GEMM reads one while its epilogue fills the other
+    const size_t o_dX = carve((size_t)T * B * (Cx + He)), o_gc = carve((size_t)B * He), o_ghp = carve((size_t)B * He);
     const size_t o_a = carve(Mtot * cmax), o_b = carve(Mtot * cmax), o_dg = carve(E), o_db = carve(E);
     void* p0 = nullptr;
     HIP_TRY(hipMalloc(&p0, off));
@@ -1566,20 +1477,27 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
     const char* dirs[2] = {"fw", "bw"};
     for (int dir = 0; dir < 2; ++dir) {
         hipLaunchKernelGGL(seq_gather_kernel, grid1((long long)T * B * Cx), dim3(256), 0, st, et->x[L], et->lens, et->xs, B, T, Cx, dir);
-        HIP_TRY(hipMemsetAsync(et->dzf, 0, (size_t)R * pad16(4 * He) * 4, st));
-        for (int s = T - 1; s >= 0; --s) {
-            hipLaunchKernelGGL(enc_gout_kernel, grid1((long long)B * He), dim3(256), 0, st, dmemory, et->lens, et->gout, B, T, E, He, dir * He, s, dir);
+        const size_t fsz = (size_t)R * pad16(4 * He);
+        HIP_TRY(hipMemsetAsync(et->dzf, 0, 2 * fsz * 4, st));
+        hipLaunchKernelGGL(enc_gout_kernel, grid1((long long)T * B * He), dim3(256), 0, st, dmemory, et->lens, et->gout, B, T, E, He, dir * He, dir);
+        auto lstm_args = [&](int s) {
             LstmBwdArgs a{};
             a.z = et->z[dir] + (size_t)s * B * 4 * He; a.cprev = et->cprev[dir] + (size_t)s * B * He; a.cnew = et->cnew[dir] + (size_t)s * B * He;
-            a.g_out0 = et->gout; a.ld_out0 = He; a.g_out1 = nullptr;
-            a.g_hs0 = et->g_hp; a.ld_hs0 = He; a.g_hs1 = et->dX + Cx; a.ld_hs1 = Cx + He;
-            a.g_c = et->g_c; a.g_hp = et->g_hp; a.dz_plain = et->dzp + (size_t)s * B * 4 * He; a.dz_frag = et->dzf;
+            a.g_out0 = et->gout + (size_t)s * B * He; a.ld_out0 = He; a.g_out1 = nullptr;
+            a.g_hs0 = et->g_hp; a.ld_hs0 = He; a.g_hs1 = nullptr; a.ld_hs1 = 0;      // d h_prev of step s + 1 arrives as the epilogue's own value
+            a.g_c = et->g_c; a.g_hp = et->g_hp; a.dz_plain = et->dzp + (size_t)s * B * 4 * He; a.dz_frag = et->dzf + (size_t)(s & 1) * fsz;
             a.B = B; a.H = He; a.MB = MB; a.t = s; a.stream = T2_STREAM_ZONE_ENC + 2 * dir; a.seed = et->seed;
             a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias; a.first = (s == T - 1) ? 1 : 0; a.lens = et->lens;
-            hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * He), dim3(256), 0, st, a);
-            bwd_dense(tr, et->lstmT[dir], et->dzf, et->dX, Cx + He);
-            hipLaunchKernelGGL(enc_dx_scatter_kernel, grid1((long long)B * Cx), dim3(256), 0, st, et->dX, Cx + He, et->lens, et->dxa, B, T, Cx, s, dir);
+            return a;
+        };
+        hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * He), dim3(256), 0, st, lstm_args(T - 1));
+        for (int s = T - 1; s >= 0; --s) {            // one launch per step: d [x | h_prev] of step s, cell backward of step s - 1 in the epilogue
+            BwdEpi e{};
+            e.N = Cx + He; e.out_plain = et->dX + (size_t)s * B * (Cx + He); e.plain_ld = Cx + He;
+            if (s > 0) { e.mode = 3; e.col0 = Cx; e.lb = lstm_args(s - 1); }
+            bwd_dense_epi(tr, et->lstmT[dir], et->dzf + (size_t)(s & 1) * fsz, e);
         }
+        hipLaunchKernelGGL(enc_dx_scatter_kernel, grid1((long long)T * B * Cx), dim3(256), 0, st, et->dX, Cx + He, et->lens, et->dxa, B, T, Cx, dir);
         const std::string pn = std::string("encoder/bidirectional_rnn/") + dirs[dir] + "/lstm_cell";
         const int n4 = 4 * He;
         T2_TRY(grad_dst(tr, flat_grads, pn + "/kernel", &g));

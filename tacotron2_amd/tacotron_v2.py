@@ -276,8 +276,20 @@ class TacotronV2Model:
 
     PREDICT returns the reference's prediction dict (models.py:122-129: id, mel, alignment
     [B, T_in, S], source, text) plus ``mel_postnet`` and ``stop_token``; EVAL returns the losses of
-    the free-feeding and the teacher-forced pass (models.py:94-107); TRAIN (gradients, Adam, RCCL
-    all-reduce) is not built yet."""
+    the free-feeding and the teacher-forced pass (models.py:94-107); TRAIN runs one optimizer step
+    (models.py:63-76: training-mode forward, loss, gradients, clip_by_global_norm(1.0), Adam with the
+    optional Noam decay, batch-norm UPDATE_OPS) on the device and returns ``{"loss", "mel_loss",
+    "done_loss", "global_step", "learning_rate"}`` -- the EstimatorSpec's loss plus what add_training_stats
+    records (models.py:72).  With torch.distributed initialised the gradients are averaged over the
+    data-parallel group (RCCL) before the clip; every rank then applies the same update.
+
+    Training hyper-parameters come from ``params`` (dict or object) with the reference's defaults
+    (hparams.py:44,34,64-68): decoder_prenet_drop_rate 0.5, encoder drop rate 0.5, adam_beta1 0.9,
+    adam_beta2 0.999, adam_eps 1e-8, initial_learning_rate 0.002, decay_learning_rate True.  The dropout /
+    zoneout masks of step n are drawn from the counter-based generator with seed ``seed + n``."""
+
+    TRAIN_DEFAULTS = dict(decoder_prenet_drop_rate=0.5, encoder_drop_rate=0.5, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
+                          initial_learning_rate=0.002, decay_learning_rate=True)
 
     def __init__(self, params: T2Dims, weights: Optional[Dict[str, np.ndarray]] = None, device: int = 0, seed: int = 1234):
         self.params = params
@@ -293,13 +305,65 @@ class TacotronV2Model:
                                  min_iters=p.min_iters, engine=self.engine)
         self.postnet = PostNetV2(p.num_mels, p.postnet_layers, p.postnet_kernel, p.postnet_channels, is_training=False,
                                  engine=self.engine)
+        self.global_step = 0            # tf.train.get_global_step()
+        self.seed = seed
+        self._train = None              # flat parameters / gradients / optimizer, built by the first TRAIN call
+        self._trainers = {}             # (B, T_in, S) -> training.Trainer
+
+    def _train_state(self, hp):
+        if self._train is None:
+            spec = training.flatten_spec(self.weights)
+            flat = torch.tensor(training.flatten(self.weights, spec), device=self.engine.device)
+            lr0 = float(hp["initial_learning_rate"])
+            lr = (lambda step: training.learning_rate_decay(lr0, step)) if hp["decay_learning_rate"] else lr0
+            opt = training.AdamOptimizer(self.engine, flat.numel(), learning_rate=lr, beta1=hp["adam_beta1"], beta2=hp["adam_beta2"],
+                                         epsilon=hp["adam_eps"])
+            self._train = SimpleNamespace(spec=spec, flat=flat, grads=torch.zeros_like(flat), opt=opt)
+        return self._train
+
+    def _trainer(self, B, T_in, S):
+        key = (int(B), int(T_in), int(S))
+        if key not in self._trainers:
+            if len(self._trainers) >= 4:                 # tapes are large: keep the most recent shapes only
+                self._trainers.pop(next(iter(self._trainers))).close()
+            tr = training.Trainer(self.engine, *key)
+            tr.bind_gradients(self._train.spec)
+            self._trainers[key] = tr
+        return self._trainers[key]
+
+    def parameters(self) -> Dict[str, np.ndarray]:
+        """The current variables (TF names and layouts), read back from the flat device buffer after training."""
+        if self._train is None:
+            return self.weights
+        return training.unflatten(self._train.flat.cpu().numpy(), self._train.spec)
+
+    def _train_step(self, f, lab, params):
+        hp = dict(self.TRAIN_DEFAULTS)
+        if params is not None:
+            src = params if isinstance(params, dict) else params.__dict__
+            hp.update({k: src[k] for k in hp if k in src})
+        st = self._train_state(hp)
+        source = np.asarray(f["source"].cpu() if isinstance(f["source"], torch.Tensor) else f["source"])
+        lens = np.asarray(f["source_length"].cpu() if isinstance(f["source_length"], torch.Tensor) else f["source_length"])
+        mel = self.engine._f32(lab["mel"])
+        r = self.params.outputs_per_step
+        if mel.shape[1] % r != 0:
+            raise ValueError("target length must be a multiple of outputs_per_step (the reference's padded batches are)")
+        tr = self._trainer(source.shape[0], source.shape[1], mel.shape[1] // r)
+        labels = {"mel": mel, "done": lab["done"], "spec_loss_mask": lab["spec_loss_mask"], "binary_loss_mask": lab["binary_loss_mask"]}
+        step0 = self.global_step
+        lr = st.opt.learning_rate(step0) if callable(st.opt.learning_rate) else st.opt.learning_rate
+        self.global_step, losses = tr.train_step(st.opt, st.flat, st.grads, {"source": source, "source_length": lens}, labels,
+                                                 global_step=step0, seed=self.seed + step0,
+                                                 prenet_drop_rate=hp["decoder_prenet_drop_rate"], encoder_drop_rate=hp["encoder_drop_rate"])
+        return {"loss": losses[2], "mel_loss": losses[0], "done_loss": losses[1], "global_step": self.global_step, "learning_rate": lr}
 
     def model_fn(self, features, labels=None, mode=ModeKeys.PREDICT, params=None):
         is_training = mode == ModeKeys.TRAIN
         is_validation = mode == ModeKeys.EVAL
-        if is_training:
-            raise NotImplementedError("the training step (BASELINE.json configs[3]) is not built yet")
         f = features if isinstance(features, dict) else features.__dict__
+        if is_training:
+            return self._train_step(f, labels if isinstance(labels, dict) else labels.__dict__, params)
         source, source_length = f["source"], f["source_length"]
         target = None
         if is_validation:
@@ -330,4 +394,7 @@ class TacotronV2Model:
         return self.model_fn(features, None, ModeKeys.PREDICT)["predictions"]
 
     def close(self):
+        for tr in self._trainers.values():
+            tr.close()
+        self._trainers = {}
         self.engine.close()

@@ -247,3 +247,56 @@ def test_load_params_and_training_loop_against_oracle():
     for o in (tr, eng2, eng):
         o.close()
     opt.close()
+
+
+def test_model_fn_train_mode():
+    """TacotronV2Model.model_fn(mode=TRAIN) (models.py:63-76): the same step as Trainer.train_step with the reference's
+    hyper-parameters, global_step bookkeeping, the Noam learning rate, and a model whose PREDICT / EVAL passes use the
+    updated weights."""
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    from tacotron2_amd.tacotron_v2 import ModeKeys, TacotronV2Model
+    d, B, T, S = MID, 4, 12, 5
+    w = init_weights(d, 21, perturb=True)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    lens = rng.integers(T // 2, T + 1, size=B).astype(np.int64)
+    lens[0] = T
+    labels = _labels(rng, B, S, d.outputs_per_step)
+    labels["mel"] = rng.uniform(0, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+    feats = {"source": ids, "source_length": lens}
+    model = TacotronV2Model(d, {k: v.copy() for k, v in w.items()}, seed=77)
+    mel_before = _np(model.predict(feats)["mel"])
+    # the reference loop by hand: Trainer.train_step with the same seeds and the Noam schedule of models.py:150-154
+    eng = Engine(d, w)
+    spec = TR.flatten_spec(w)
+    tr = TR.Trainer(eng, B, T, S)
+    tr.bind_gradients(spec)
+    flat = torch.tensor(TR.flatten(w, spec), device="cuda")
+    grads = torch.zeros_like(flat)
+    opt = TR.AdamOptimizer(eng, flat.numel(), learning_rate=lambda s: TR.learning_rate_decay(0.002, s))
+    step = 0
+    losses_model = []
+    for it in range(3):
+        out = model.model_fn(feats, labels, ModeKeys.TRAIN)
+        step, ref_losses = tr.train_step(opt, flat, grads, feats, labels, global_step=step, seed=77 + it)
+        assert out["global_step"] == step == it + 1
+        assert abs(out["learning_rate"] - TR.learning_rate_decay(0.002, it)) < 1e-12
+        for key, idx in (("mel_loss", 0), ("done_loss", 1), ("loss", 2)):
+            assert float(out[key]) == float(ref_losses[idx]), (it, key)
+        losses_model.append(float(out["loss"]))
+    got, want = model.parameters(), TR.unflatten(flat, spec)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k])
+    assert float(np.abs(got["decoder/lstm_1/kernel"] - w["decoder/lstm_1/kernel"]).max()) > 0
+    # PREDICT after training runs on the updated weights
+    mel_after = _np(model.predict(feats)["mel"])
+    assert mel_after.shape[0] == B and not np.array_equal(mel_before[:, :2], mel_after[:, :2])
+    eng2 = Engine(d, got)
+    np.testing.assert_allclose(_np(model.engine.encode(ids, lens)), _np(eng2.encode(ids, lens)), atol=1e-6)
+    # hyper-parameters through `params`: a constant learning rate
+    model2 = TacotronV2Model(d, {k: v.copy() for k, v in w.items()}, seed=77)
+    out2 = model2.model_fn(feats, labels, ModeKeys.TRAIN, params={"decay_learning_rate": False, "initial_learning_rate": 0.01})
+    assert out2["learning_rate"] == 0.01 and float(out2["loss"]) == losses_model[0]
+    model.close(); model2.close()
