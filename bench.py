@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--max-iters", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (tuning runs)")
     args = ap.parse_args()
 
@@ -212,6 +213,48 @@ def main():
         dt1 = (time.perf_counter() - t1) / reps
         out["batch1"] = {"frames": n1 * r, "ms": dt1 * 1e3, "frames_per_s": n1 * r / dt1,
                          "rtf": dt1 / (n1 * r * FRAME_SHIFT_S), "us_per_decoder_step_incl_enc_post": dt1 * 1e6 / n1}
+
+    # ---- training step (BASELINE.json configs[3]; N=1 only: tools/train_bench.py is the multi-rank version) ----
+    if rank == 0 and world == 1 and not args.no_train:
+        try:
+            from tacotron2_amd import training as TR
+            Bt, Tt, St = 32, 140, 400
+            rng = np.random.default_rng(1234 + 4)
+            lens_t = rng.integers(60, Tt + 1, Bt).astype(np.int64); lens_t[0] = Tt
+            ids_t = np.zeros((Bt, Tt), np.int64)
+            for b, n in enumerate(lens_t):
+                ids_t[b, :n] = rng.integers(32, 91, n)
+            tl = rng.integers(400, 801, Bt); tl[0] = 800
+            sl = (tl + 1) // 2
+            labels = {"mel": rng.uniform(0, 1, (Bt, St * r, M)).astype(np.float32),
+                      "done": (np.arange(St)[None, :] >= (sl[:, None] - 1)).astype(np.float32),
+                      "spec_loss_mask": (np.arange(St * r)[None, :] < tl[:, None]).astype(np.float32),
+                      "binary_loss_mask": (np.arange(St)[None, :] < sl[:, None]).astype(np.float32)}
+            labels = {k: torch.tensor(v, device="cuda") for k, v in labels.items()}
+            feats = {"source": ids_t, "source_length": lens_t}
+            spec = TR.flatten_spec(w)
+            trn = TR.Trainer(eng, Bt, Tt, St)
+            trn.bind_gradients(spec)
+            flat = torch.tensor(TR.flatten(w, spec), device="cuda")
+            grads = torch.zeros_like(flat)
+            opt = TR.AdamOptimizer(eng, flat.numel(), learning_rate=lambda s_: TR.learning_rate_decay(0.002, s_))
+            gstep, _ = trn.train_step(opt, flat, grads, feats, labels, global_step=0, seed=1)        # warm-up
+            torch.cuda.synchronize()
+            t_tr = time.perf_counter()
+            n_tr = 3
+            for i in range(n_tr):
+                gstep, losses = trn.train_step(opt, flat, grads, feats, labels, global_step=gstep, seed=2 + i)
+            torch.cuda.synchronize()
+            dt_tr = (time.perf_counter() - t_tr) / n_tr
+            out["train_step"] = {"workload": "BASELINE.json configs[3]: teacher-forced training step (forward, backward, clip + Adam, "
+                                             "weight refresh), B=32, T_in<=140, 800 frames, profile P, fp32",
+                                 "ms_per_step": dt_tr * 1e3, "mel_frames_per_s": Bt * St * r / dt_tr, "steps": n_tr,
+                                 "loss": float(losses[2])}
+            trn.load_params(torch.tensor(TR.flatten(w, spec), device="cuda"))      # back to the bench weights
+            trn.close()
+            del flat, grads
+        except Exception as ex:                                      # never lose the headline line over the extra leg
+            out["train_step"] = {"error": repr(ex)}
 
     # ---- CPU baseline: the NumPy oracle on this box's host cores, bounded sample (N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
