@@ -976,7 +976,9 @@ extern "C" int t2_state_get(t2_state* s, const char* name, float* out) {
 // one decoder step = the launch sequence below
 // ------------------------------------------------------------------------------------------------
 struct StepIO {
-    int feed_mode;              // 0: teacher (targets), 1: own output (proj writes xin), 2: caller frames (API)
+    int feed_mode;              // 0: teacher (targets), 1: own output (proj writes xin), 2: caller frames (API),
+                                // 3: teacher, PreNets of every step already computed (xp_all: frag16 operand per step)
+    float* xp_all; int xp_all_stride; int xp_all_slots;
     const float* feed_src;      // mode 0: targets + M*(r-nf) ; mode 2: prev_frames
     long long feed_row_stride;  // floats
     long long feed_t_stride;
@@ -1016,6 +1018,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     const int KBe = s->KBe, KBa = s->KBa;
     const int np = d.num_prenet_layers;
     const bool all = !m->opt_lstm_only;
+    const FragBuf xp_last = io.feed_mode == 3 ? FragBuf{io.xp_all, io.xp_all_stride, io.xp_all_slots, 0, 0} : single(s->xp[np - 1], 0);
     // 1. decoder input frames (helpers.py:86 / :182 / go frame :187-188)
     if (all && (io.feed_mode == 0 || io.feed_mode == 2)) {
         FeedArgs f{};
@@ -1024,7 +1027,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         hipLaunchKernelGGL(feed_frames_kernel, dim3(ceil_div(MB * 16 * pad16(M * nf), 256)), dim3(256), 0, st, f);
     }
     // 2. prenets (rnn_wrappers.py:51-53)
-    for (int i = 0; all && i < np; ++i) {
+    for (int i = 0; all && io.feed_mode != 3 && i < np; ++i) {
         SkinnyCore c = core(m->prenet[i]);
         c.seg[0][1] = single(i == 0 ? s->xf : s->xp[i - 1], 0);
         DenseEpi e{};
@@ -1064,16 +1067,16 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         if (att3) {
             c.kb0 = m->att_lstm.seg_kb[0];
             c.kbtot = m->att_lstm.seg_kb[0] + KBe;
-            c.seg[0][0] = single(s->xp[np - 1], 0);
+            c.seg[0][0] = xp_last;
             c.seg[0][1] = pp(s->XA, s->XA_sz, 0, 0);
             e.zpart = s->ZA;
         } else if (hoist) {
             c.kbtot = m->att_lstm.seg_kb[0];
-            c.seg[0][1] = single(s->xp[np - 1], 0);
+            c.seg[0][1] = xp_last;
             e.zpart = s->ZA;
         } else {
             c.kb0 = m->att_lstm.seg_kb[0];
-            c.seg[0][0] = single(s->xp[np - 1], 0);
+            c.seg[0][0] = xp_last;
             c.seg[0][1] = pp(s->XA, s->XA_sz, 0, 0);
         }
         e.H = A; e.c[0] = s->c_att; e.Hld = A;
