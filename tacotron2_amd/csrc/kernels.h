@@ -1429,6 +1429,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Teacher-forced PreNets of ALL steps at once (TrainingHelper / ValidationHelper with teacher forcing feed known
+// frames, helpers.py:86,182): inputs gathered for every step, the Dense layers as conv_gemm_kernel GEMMs over S*B rows,
+// then the pass below (dropout in training mode, frag16 operands of the attention LSTM per step).
+// ------------------------------------------------------------------------------------------------
+// xin[t][b][:] = targets[b][t - 1][-M*nf:] (t >= 1), zeros at t = 0: inputs of PreNet layer 0 over the whole tape
+__global__ __launch_bounds__(256) void feed_gather_kernel(const float* __restrict__ targets, float* __restrict__ xin, int B, int S, int M, int r, int nf) {
+    const int W = M * nf;
+    const long long n = (long long)S * B * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % W);
+        const long long tb = i / W;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        xin[i] = t == 0 ? 0.f : targets[((size_t)b * S + (t - 1)) * r * M + (size_t)M * (r - nf) + c];
+    }
+}
+
+// PreNet dropout over all teacher-forced steps at once: x [S][B][P] in place (x = relu(dense) already), optionally also as the
+// per-step frag16 operands of the attention LSTM (slot t at frag + t * frag_stride)
+__global__ __launch_bounds__(256) void prenet_dropout_all_kernel(float* __restrict__ x, float* __restrict__ frag, long long frag_stride, int S, int B, int P,
+                                                                 int MB, float rate, uint32_t seed, int stream) {
+    const long long n = (long long)S * B * P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % P);
+        const long long tb = i / P;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        float v = x[i];
+        if (rate > 0.f) v = dropout_train(v, rate, t2_u01(seed, stream, t, b, c));
+        x[i] = v;
+        if (frag != nullptr) frag[(size_t)t * frag_stride + frag_idx(b, c, MB)] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tacotron v1 cells
 // ------------------------------------------------------------------------------------------------
 // TF GRUCell step in two launches (reference tacotron/rnn_impl.py:38): the reset gate

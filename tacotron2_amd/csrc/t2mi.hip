@@ -89,6 +89,7 @@ struct t2_model {
     ConvLayer post_proj, memory_layer;
     Packed enc_lstm[2];
     Packed prenet[T2_MAX_PRENET_LAYERS];
+    ConvLayer prenet_plain[T2_MAX_PRENET_LAYERS];     // the same layers in plain layout (batched teacher-forced PreNets)
     Packed att_lstm, lstm1, lstm2, proj;
     float *wq = nullptr;                // query layer kernel [A][U], plain
     float *conv_w = nullptr, *conv_b = nullptr, *wloc = nullptr, *v_a = nullptr, *b_a = nullptr;
@@ -134,6 +135,8 @@ struct t2_state {
     int* ctl = nullptr;
     // output staging (graph-stable addresses)
     float *o_mel = nullptr, *o_stop = nullptr, *o_hist = nullptr, *i_targets = nullptr;
+    float *tf_buf = nullptr, *tf_xin = nullptr, *tf_x[2] = {nullptr, nullptr}, *tf_frag = nullptr;   // batched teacher-forced PreNets (lazy)
+    long long tf_stride = 0;
     void* outbuf = nullptr;
     // cached graphs: [mode] 0 = teacher forcing, 1 = feed own output (free / validation)
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
@@ -441,6 +444,10 @@ extern "C" int t2_model_finalize(t2_model* m) {
         T2_TRY(get_w(m, p + "kernel", &w, {pin, d.prenet_units[i]}));
         T2_TRY(get_w(m, p + "bias", &b, {d.prenet_units[i]}));
         T2_TRY(pack_skinny(m, &m->prenet[i], w->data.data(), d.prenet_units[i], {{0, pin}}, 0, d.prenet_units[i], b->data.data()));
+        ConvLayer& Lp = m->prenet_plain[i];
+        Lp.k = 1; Lp.cin = pin; Lp.cout = d.prenet_units[i];
+        T2_TRY(upload(m, &Lp.w, w->data));
+        T2_TRY(upload(m, &Lp.shift, b->data));
         pin = d.prenet_units[i];
     }
     T2_TRY(get_w(m, "decoder/attention_lstm/kernel", &w, {pin + E + A, 4 * A}));
@@ -804,6 +811,7 @@ static void state_free(t2_state* s) {
     if (s->slab) hipFree(s->slab);
     if (s->fixed) hipFree(s->fixed);
     if (s->outbuf) hipFree(s->outbuf);
+    if (s->tf_buf) hipFree(s->tf_buf);
     delete s;
 }
 
@@ -1204,6 +1212,7 @@ static StepIO loop_io(t2_state* s, int mode) {
     const int M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame;
     StepIO io{};
     io.feed_mode = mode;
+    if (mode == 0 && s->tf_frag != nullptr) { io.feed_mode = 3; io.xp_all = s->tf_frag; io.xp_all_stride = (int)s->tf_stride; io.xp_all_slots = s->cap; }
     io.feed_src = s->i_targets ? s->i_targets + (size_t)M * (r - nf) : nullptr;
     io.feed_row_stride = (long long)s->cap * r * M;
     io.feed_t_stride = (long long)r * M;
@@ -1212,6 +1221,40 @@ static StepIO loop_io(t2_state* s, int mode) {
     io.hist = s->o_hist;
     io.slot_hint = (s->m->opt_chunk % 2 == 0) ? 1 : 0;
     return io;
+}
+
+// PreNets of all cap steps of a teacher-forced decode from s->i_targets (batched GEMMs); the per-step frag16 operands land
+// in s->tf_frag, which loop_io hands to launch_step as feed mode 3.  tape_xp (training): where layer i's outputs are kept.
+static int teacher_prenets(t2_state* s, float drop_rate, uint32_t seed, float* const* tape_xp = nullptr) {
+    t2_model* m = s->m;
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int B = s->B, S = s->cap, MB = s->MB, M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame, np = d.num_prenet_layers;
+    const long long SB = (long long)S * B;
+    if (!s->tf_buf) {
+        int pmax = 0;
+        for (int i = 0; i < np; ++i) pmax = std::max(pmax, d.prenet_units[i]);
+        s->tf_stride = (long long)MB * 16 * pad16(d.prenet_units[np - 1]);
+        const size_t n_xin = align_up((size_t)SB * M * nf, 64), n_x = align_up((size_t)SB * pmax, 64), n_frag = (size_t)S * s->tf_stride;
+        hipError_t e = hipMalloc((void**)&s->tf_buf, (n_xin + 2 * n_x + n_frag) * 4);
+        if (e != hipSuccess) { s->tf_buf = nullptr; return fail(T2_ENOMEM, "hipMalloc(teacher-forced PreNet buffers) failed: %s", hipGetErrorString(e)); }
+        HIP_TRY(hipMemsetAsync(s->tf_buf, 0, (n_xin + 2 * n_x + n_frag) * 4, st));
+        s->tf_xin = s->tf_buf; s->tf_x[0] = s->tf_xin + n_xin; s->tf_x[1] = s->tf_x[0] + n_x; s->tf_frag = s->tf_x[1] + n_x;
+    }
+    auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
+    hipLaunchKernelGGL(feed_gather_kernel, grid1(SB * M * nf), dim3(256), 0, st, s->i_targets, s->tf_xin, B, S, M, r, nf);
+    const float* x = s->tf_xin;
+    for (int i = 0; i < np; ++i) {
+        const int P = d.prenet_units[i];
+        const ConvLayer& L = m->prenet_plain[i];
+        float* y = tape_xp ? tape_xp[i] : s->tf_x[i & 1];
+        T2_TRY(launch_conv(m, L, x, L.cin, y, P, (int)SB, (int)SB, 1, nullptr, 0));
+        hipLaunchKernelGGL(prenet_dropout_all_kernel, grid1(SB * P), dim3(256), 0, st, y, i == np - 1 ? s->tf_frag : nullptr, s->tf_stride, S, B, P, MB,
+                           drop_rate, seed, T2_STREAM_PRENET + i);
+        x = y;
+    }
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
 }
 
 // Enqueue one chunk of `chunk` steps followed by the base-step advance.
@@ -1264,6 +1307,7 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     T2_TRY(state_zero(s, S, 0, 0));
     HIP_TRY(hipMemcpyAsync(s->i_targets, targets, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     const int mode = teacher_forcing ? 0 : 1;
+    if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
     for (int done = 0; done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));

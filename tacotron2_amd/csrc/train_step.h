@@ -578,34 +578,6 @@ __global__ __launch_bounds__(256) void attention_bwd_finish_kernel(AttnBwdFinish
     }
 }
 
-// PreNet dropout over all teacher-forced steps at once: x [S][B][P] in place (x = relu(dense) already), optionally also as the
-// per-step frag16 operands of the attention LSTM (slot t at frag + t * frag_stride)
-__global__ __launch_bounds__(256) void prenet_dropout_all_kernel(float* __restrict__ x, float* __restrict__ frag, long long frag_stride, int S, int B, int P,
-                                                                 int MB, float rate, uint32_t seed, int stream) {
-    const long long n = (long long)S * B * P;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % P);
-        const long long tb = i / P;
-        const int b = (int)(tb % B), t = (int)(tb / B);
-        float v = x[i];
-        if (rate > 0.f) v = dropout_train(v, rate, t2_u01(seed, stream, t, b, c));
-        x[i] = v;
-        if (frag != nullptr) frag[(size_t)t * frag_stride + frag_idx(b, c, MB)] = v;
-    }
-}
-
-// xin[t][b][:] = targets[b][t - 1][-M*nf:] (t >= 1), zeros at t = 0: inputs of PreNet layer 0 over the whole tape
-__global__ __launch_bounds__(256) void feed_gather_kernel(const float* __restrict__ targets, float* __restrict__ xin, int B, int S, int M, int r, int nf) {
-    const int W = M * nf;
-    const long long n = (long long)S * B * W;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % W);
-        const long long tb = i / W;
-        const int b = (int)(tb % B), t = (int)(tb / B);
-        xin[i] = t == 0 ? 0.f : targets[((size_t)b * S + (t - 1)) * r * M + (size_t)M * (r - nf) + c];
-    }
-}
-
 struct BwdOperand {             // skinny dense operand holding W^T of a TF-layout [rows][cols] variable: K = cols, N = rows
     Packed p;
 };
@@ -629,10 +601,6 @@ struct t2_trainer {
     float *g_c[3] = {}, *g_hp[3] = {}, *g_state = nullptr;
     float *dkeys = nullptr, *dvalues = nullptr, *p_va = nullptr;
     float* ab_image = nullptr;
-    // teacher-forced PreNets of all steps in one pass (training forward): plain weights, inputs, frag16 operands per step
-    ConvLayer prenet_plain[T2_MAX_PRENET_LAYERS];
-    float *fw_xin = nullptr, *xp_frag_all = nullptr;
-    long long xp_frag_stride = 0;
     float *de_all = nullptr, *dctx_all = nullptr, *part_dq = nullptr, *part_dva = nullptr, *part_ds = nullptr;
     float *du_all = nullptr, *f_all = nullptr, *df_all = nullptr;      // own allocation: every row is written each call, never zero-filled
     int NJ = 0;                         // attention backward: position chunks per row
@@ -711,31 +679,6 @@ extern "C" int t2_trainer_create(t2_model* m, int B, int T_in, int S, t2_trainer
     if (attn_lds_bytes(m->d, T_in) > 120 * 1024) { t2_trainer_destroy(tr); return fail(T2_EINVAL, "T_in %d too long for the attention kernel's LDS", T_in); }
     int rc = state_alloc(m, B, T_in, S, true, &tr->state);
     if (rc != T2_OK) { t2_trainer_destroy(tr); return rc; }
-    {
-        const int np = d.num_prenet_layers, MB = mb_for(B);
-        tr->xp_frag_stride = (long long)MB * 16 * pad16(d.prenet_units[np - 1]);
-        const size_t n_xin = SB * d.num_mels * d.n_feed_frame, n_frag = (size_t)S * tr->xp_frag_stride;
-        float* q = nullptr;
-        if (hipMalloc((void**)&q, (n_xin + n_frag) * 4) != hipSuccess) { t2_trainer_destroy(tr); return fail(T2_ENOMEM, "hipMalloc(trainer PreNet operands) failed"); }
-        tr->allocs.push_back(q);
-        (void)hipMemset(q, 0, (n_xin + n_frag) * 4);
-        tr->fw_xin = q; tr->xp_frag_all = q + n_xin;
-        for (int i = 0; i < np; ++i) {
-            const int kin = i == 0 ? d.num_mels * d.n_feed_frame : d.prenet_units[i - 1], P = d.prenet_units[i];
-            const HostWeight *w, *bb;
-            const std::string pn = "decoder/prenet_" + std::to_string(i) + "/dense";
-            rc = get_w(m, pn + "/kernel", &w, {kin, P});
-            if (rc == T2_OK) rc = get_w(m, pn + "/bias", &bb, {P});
-            if (rc != T2_OK) { t2_trainer_destroy(tr); return rc; }
-            float* wb = nullptr;
-            if (hipMalloc((void**)&wb, ((size_t)kin * P + P) * 4) != hipSuccess) { t2_trainer_destroy(tr); return fail(T2_ENOMEM, "hipMalloc(trainer PreNet weights) failed"); }
-            tr->allocs.push_back(wb);
-            (void)hipMemcpy(wb, w->data.data(), (size_t)kin * P * 4, hipMemcpyHostToDevice);
-            (void)hipMemcpy(wb + (size_t)kin * P, bb->data.data(), (size_t)P * 4, hipMemcpyHostToDevice);
-            ConvLayer& L = tr->prenet_plain[i];
-            L.k = 1; L.cin = kin; L.cout = P; L.w = wb; L.scale = nullptr; L.shift = wb + (size_t)kin * P;
-        }
-    }
     *out = tr;
     return T2_OK;
 }
@@ -759,22 +702,9 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     tr->tape.seed = seed; tr->tape.prenet_drop_rate = prenet_drop_rate;
     // TrainingHelper feeds known frames, so the PreNets of all S steps run as batched GEMMs over S*B rows (tape rows
     // xp[i][t][b][:]), followed by the sampled dropout; the last layer also lands as the per-step frag16 operands.
-    {
-        const int np = d.num_prenet_layers, nf = d.n_feed_frame, MB = mb_for(B);
-        const long long SBr = (long long)S * B;
-        auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
-        hipLaunchKernelGGL(feed_gather_kernel, grid1(SBr * M * nf), dim3(256), 0, st, s->i_targets, tr->fw_xin, B, S, M, r, nf);
-        for (int i = 0; i < np; ++i) {
-            const int P = d.prenet_units[i];
-            const ConvLayer& L = tr->prenet_plain[i];
-            T2_TRY(launch_conv(m, L, i == 0 ? tr->fw_xin : tr->tape.xp[i - 1], L.cin, tr->tape.xp[i], P, (int)SBr, (int)SBr, 1, nullptr, 0));
-            hipLaunchKernelGGL(prenet_dropout_all_kernel, grid1(SBr * P), dim3(256), 0, st, tr->tape.xp[i], i == np - 1 ? tr->xp_frag_all : nullptr,
-                               tr->xp_frag_stride, S, B, P, MB, prenet_drop_rate, seed, T2_STREAM_PRENET + i);
-        }
-    }
+    T2_TRY(teacher_prenets(s, prenet_drop_rate, seed, tr->tape.xp));
     StepIO io = loop_io(s, 0);
     io.train = &tr->tape;
-    io.feed_mode = 3; io.xp_all = tr->xp_frag_all; io.xp_all_stride = (int)tr->xp_frag_stride; io.xp_all_slots = S;
     io.slot_hint = 1;                              // the control block's base stays 0: step t runs as step_off = t
     for (int t = 0; t < S; ++t) T2_TRY(launch_step(s, t, io));       // eager launches: seed and rates are per-call kernel arguments
     HIP_TRY(hipGetLastError());
@@ -1306,11 +1236,21 @@ __global__ __launch_bounds__(256) void enc_dx_scatter_kernel(const float* __rest
 
 // d embedding[sym][:] = sum over the rows m with ids[m] == sym of dx[m][:]: one block per symbol, rows in order (deterministic)
 __global__ __launch_bounds__(256) void embedding_grad_kernel(const int* __restrict__ ids, const float* __restrict__ dx, int M, int C, float* __restrict__ demb) {
+    __shared__ int s_ids[1024];
     const int sym = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int c0 = 0; c0 < C; c0 += blockDim.x) {
+        const int c = c0 + threadIdx.x;
         float acc = 0.f;
-        for (int m = 0; m < M; ++m) if (ids[m] == sym) acc += dx[(size_t)m * C + c];
-        demb[(size_t)sym * C + c] = acc;
+        for (int m0 = 0; m0 < M; m0 += 1024) {          // the row ids go through LDS: every thread scans them
+            __syncthreads();
+            for (int i = threadIdx.x; i < 1024 && m0 + i < M; i += blockDim.x) s_ids[i] = ids[m0 + i];
+            __syncthreads();
+            const int n = min(1024, M - m0);
+            if (c < C)
+                for (int i = 0; i < n; ++i)
+                    if (s_ids[i] == sym) acc += dx[(size_t)(m0 + i) * C + c];
+        }
+        if (c < C) demb[(size_t)sym * C + c] = acc;
     }
 }
 
@@ -1765,8 +1705,8 @@ extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
         T2_TRY(flat_src(tr, flat, pn + "/bias", &b));
         repack(st, m->prenet[i], w, d.prenet_units[i], 1, d.prenet_units[i]);
         T2_TRY(copy(m->prenet[i].bias, b, d.prenet_units[i]));
-        T2_TRY(copy(tr->prenet_plain[i].w, w, (size_t)tr->prenet_plain[i].cin * d.prenet_units[i]));
-        T2_TRY(copy(tr->prenet_plain[i].shift, b, d.prenet_units[i]));
+        T2_TRY(copy(m->prenet_plain[i].w, w, (size_t)m->prenet_plain[i].cin * d.prenet_units[i]));
+        T2_TRY(copy(m->prenet_plain[i].shift, b, d.prenet_units[i]));
         if (i > 0) repack(st, tr->prenetT[i], w, 1, d.prenet_units[i], d.prenet_units[i - 1]);
         pin = d.prenet_units[i];
     }
