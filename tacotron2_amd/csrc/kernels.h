@@ -118,6 +118,7 @@ struct LstmEpi {
     int plain_off[2];         // column offset per direction
     int reverse[2];           // direction writes to position len-1-t
     const float* zpart;       // optional partial pre-activations of the recurrent K range (partial_step_kernel), D-fragment layout
+    const float* zpart2;      // optional second partial (a second hoisted K range), same layout
     // fused partial query (attention LSTM only): qpart[wg][row][u] = sum_uu h[row][4wg+uu] * wq[4wg+uu][u]
     const float* wq;          // [A][U] or null
     float* qpart;             // [n_wg][MB*16][U]
@@ -366,6 +367,11 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
                 const float* zp = e.zpart + ((size_t)(blockIdx.x * MB + (row >> 4)) * 64 + ((row & 15) >> 2) * 16) * 4 + (row & 3);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) zp4[g4] = zp[(g4 * 4 + uu) * 4];
+                if (e.zpart2 != nullptr) {
+                    const float* zq = e.zpart2 + (zp - e.zpart);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) zp4[g4] += zq[(g4 * 4 + uu) * 4];
+                }
             }
             if (e.lens != nullptr) len = e.lens[row];
         }
@@ -477,6 +483,8 @@ struct PartialJobs {
     SkinnyCore core[3];
     float* z[3];
     int n[3];
+    int off[3];      // first column tile of the job served by this launch (a job may be spread over several launches)
+    int skip;        // dense_step_kernel: workgroups below skip take no riding tile (the dense role's own workgroups)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -707,10 +715,12 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void dense_step_kernel(SkinnyCor
     __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
     __shared__ int s_notstop;
     if ((int)blockIdx.x < e.n_wg) dense_body<MB>(a, e, blockIdx.x, red, &s_notstop);
-    if ((int)blockIdx.x < pj.n[0]) {
-        __syncthreads();
-        partial_body<MB, NPW>(pj.core[0], pj.z[0], blockIdx.x, red);
-    }
+    const int j = (int)blockIdx.x - pj.skip;
+    if (j < 0 || j >= pj.n[0] + pj.n[1] + pj.n[2]) return;
+    if ((int)blockIdx.x < e.n_wg) __syncthreads();
+    if (j >= pj.n[0] + pj.n[1]) partial_body<MB, NPW>(pj.core[2], pj.z[2], pj.off[2] + j - pj.n[0] - pj.n[1], red);
+    else if (j >= pj.n[0]) partial_body<MB, NPW>(pj.core[1], pj.z[1], pj.off[1] + j - pj.n[0], red);
+    else partial_body<MB, NPW>(pj.core[0], pj.z[0], pj.off[0] + j, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -789,9 +799,9 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
     {
         __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
         const int j = (int)blockIdx.x - a.B;           // the attention rows come first: they are the critical path
-        if (j >= pj.n[0] + pj.n[1]) { partial_body<MB, NPW>(pj.core[2], pj.z[2], j - pj.n[0] - pj.n[1], red); return; }
-        if (j >= pj.n[0]) { partial_body<MB, NPW>(pj.core[1], pj.z[1], j - pj.n[0], red); return; }
-        if (j >= 0) { partial_body<MB, NPW>(pj.core[0], pj.z[0], j, red); return; }
+        if (j >= pj.n[0] + pj.n[1]) { partial_body<MB, NPW>(pj.core[2], pj.z[2], pj.off[2] + j - pj.n[0] - pj.n[1], red); return; }
+        if (j >= pj.n[0]) { partial_body<MB, NPW>(pj.core[1], pj.z[1], pj.off[1] + j - pj.n[0], red); return; }
+        if (j >= 0) { partial_body<MB, NPW>(pj.core[0], pj.z[0], pj.off[0] + j, red); return; }
     }
     T2_STAMP(0);
     const int t_step = step_index(a.ctl, a.step_off);

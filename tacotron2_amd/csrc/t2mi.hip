@@ -105,6 +105,8 @@ struct t2_model {
     int opt_splitk = 0;                 // batches > 16 rows: split-K LSTM step with in-launch reduction
     int opt_hoist = 1;                  // recurrent halves of the LSTM GEMMs ride in the attention / projection launches
     int opt_att3 = 1;                   // B <= 16: all three riders in the attention launch
+    int opt_spread = 1;                 // B > 16: riders spread as tile ranges over the PreNet / attention / projection launches
+    int n_cu = 256;                     // compute units of the device (rider capacity of a launch)
     int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
 };
@@ -129,6 +131,7 @@ struct t2_state {
     int XA_sz = 0, X1_sz = 0, X2_sz = 0;         // floats per slot
     int KBe = 0, KBa = 0, KBd = 0;
     float *ZA = nullptr, *Z1 = nullptr, *Z2 = nullptr;   // recurrent-half pre-activations (partial_step_kernel)
+    float* Z1x = nullptr;                        // LSTM 1: product of the attention cell's raw output (spread schedule)
     unsigned* tickets = nullptr;                 // split-K arrival counters, 3 layers x tiles (zeroed with the slab)
     unsigned long long* sk_slabs = nullptr;      // split-K partial slabs [tiles][2][512][2]
     int sk_tiles = 0;
@@ -332,6 +335,8 @@ extern "C" int t2_model_create(t2_ctx* ctx, const t2_dims* d, t2_model** out) {
     t2_model* m = new t2_model();
     m->ctx = ctx;
     m->d = *d;
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n_cu > 0) m->n_cu = n_cu;
     *out = m;
     return T2_OK;
 }
@@ -365,6 +370,10 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     }
     else if (!strcmp(name, "att3")) {
         m->opt_att3 = value;
+        for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+    }
+    else if (!strcmp(name, "spread")) {
+        m->opt_spread = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
     else if (!strcmp(name, "lstm_only")) {
@@ -609,10 +618,17 @@ static void timed_lstm(bool timing, int MB, int n_wg4, hipStream_t st, const Ski
 template <int MB>
 static inline void launch_dense_mb(dim3 grid, hipStream_t st, const SkinnyCore& c, const DenseEpi& e, const PartialJobs& pj) {
     constexpr int G = (MB >= 4) ? T2_G4 : 4;
-    const int base = pj.n[0] > 0 ? (pj.core[0].kbtot / G) / T2_SKINNY_WAVES : 0;
+    int base = -1;      // groups per wave common to every riding job present (else the runtime loop)
+    for (int i = 0; i < 3; ++i) {
+        if (pj.n[i] <= 0) continue;
+        const int bi = (pj.core[i].kbtot / G) / T2_SKINNY_WAVES;
+        base = (base < 0 || base == bi) ? bi : 0;
+    }
     const dim3 blk(T2_SKINNY_THREADS);
     switch (base) {
+        case 2: hipLaunchKernelGGL((dense_step_kernel<MB, 2>), grid, blk, 0, st, c, e, pj); break;
         case 3: hipLaunchKernelGGL((dense_step_kernel<MB, 3>), grid, blk, 0, st, c, e, pj); break;
+        case 4: hipLaunchKernelGGL((dense_step_kernel<MB, 4>), grid, blk, 0, st, c, e, pj); break;
         case 6: hipLaunchKernelGGL((dense_step_kernel<MB, 6>), grid, blk, 0, st, c, e, pj); break;
         default: hipLaunchKernelGGL((dense_step_kernel<MB, 0>), grid, blk, 0, st, c, e, pj); break;
     }
@@ -623,7 +639,7 @@ static inline void launch_dense(int MB, dim3 grid, hipStream_t st, const SkinnyC
     if (jobs) pj = *jobs;
     DenseEpi e2 = e;
     e2.n_wg = grid.x;
-    grid.x = std::max<unsigned>(grid.x, pj.n[0]);
+    grid.x = std::max<unsigned>(grid.x, pj.skip + pj.n[0] + pj.n[1] + pj.n[2]);
     if (MB == 1) launch_dense_mb<1>(grid, st, c, e2, pj);
     else if (MB == 2) launch_dense_mb<2>(grid, st, c, e2, pj);
     else launch_dense_mb<4>(grid, st, c, e2, pj);
@@ -847,7 +863,7 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     const size_t o_sk = carve((size_t)s->sk_tiles * 2 * T2_SKINNY_THREADS * 2 * 8);
     const size_t o_xf = carve((size_t)R * pad16(M * nf) * 4);
     const size_t o_ZA = carve((size_t)m->att_lstm.n_wg * MB * 256 * 4), o_Z1 = carve((size_t)m->lstm1.n_wg * MB * 256 * 4),
-                 o_Z2 = carve((size_t)m->lstm2.n_wg * MB * 256 * 4);
+                 o_Z2 = carve((size_t)m->lstm2.n_wg * MB * 256 * 4), o_Z1x = carve((size_t)m->lstm1.n_wg * MB * 256 * 4);
     size_t o_xp[T2_MAX_PRENET_LAYERS];
     for (int i = 0; i < d.num_prenet_layers; ++i) o_xp[i] = carve((size_t)R * pad16(d.prenet_units[i]) * 4);
     s->slab_bytes = off;
@@ -860,7 +876,7 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     s->c_att = (float*)(p + o_ca); s->c1 = (float*)(p + o_c1); s->c2 = (float*)(p + o_c2);
     s->XA = (float*)(p + o_XA); s->X1 = (float*)(p + o_X1); s->X2 = (float*)(p + o_X2); s->XY = (float*)(p + o_XY);
     s->xf = (float*)(p + o_xf);
-    s->ZA = (float*)(p + o_ZA); s->Z1 = (float*)(p + o_Z1); s->Z2 = (float*)(p + o_Z2);
+    s->ZA = (float*)(p + o_ZA); s->Z1 = (float*)(p + o_Z1); s->Z2 = (float*)(p + o_Z2); s->Z1x = (float*)(p + o_Z1x);
     s->tickets = (unsigned*)(p + o_tk); s->sk_slabs = (unsigned long long*)(p + o_sk);
     for (int i = 0; i < d.num_prenet_layers; ++i) s->xp[i] = (float*)(p + o_xp[i]);
     // output staging
@@ -1034,6 +1050,35 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         f.B = B; f.K = M * nf; f.MB = MB; f.go_zero = io.feed_mode == 0; f.ctl = s->ctl; f.step_off = step_off;
         hipLaunchKernelGGL(feed_frames_kernel, dim3(ceil_div(MB * 16 * pad16(M * nf), 256)), dim3(256), 0, st, f);
     }
+    const bool hoist = m->opt_hoist != 0;
+    // recurrent half of an LSTM layer: [state operands] . kernel[their K range] -> z (partial_body)
+    auto job = [&](const Packed& p, int kb_w0, int kb_n, FragBuf src, int off) {
+        SkinnyCore c = core(p);
+        c.step_off = step_off + off;
+        c.t_hint = io.slot_hint ? step_off + off : -1;
+        c.kb_w0 = kb_w0; c.kbtot = kb_n; c.kb0 = 0; c.seg[0][1] = src;
+        return c;
+    };
+    // Spread schedule (more than one row block, PreNet launches present).  Four hoisted products of K = one state width
+    // each -- Z1 = h1.W, Z2 = h2.W (state of the previous step), Z1x = h_att_raw.W (this step's attention cell output),
+    // ZA = h_att.W for the NEXT step -- are cut into column-tile ranges and placed on the CUs that the small launches of
+    // the step leave idle: PreNet 0 <- Z1, PreNet 1 <- rest of Z1, Z2, rest of ZA; attention <- Z1x + what fills its last
+    // rider round from Z2; projection <- ZA.  The riding workgroups are separate from the dense role's own, so a small
+    // launch lasts max(own, one rider round) instead of own + rider.  The attention LSTM then multiplies [prenet | ctx],
+    // LSTM 1 only the new context.
+    const bool spread = hoist && m->opt_spread && (MB >= 2 || m->opt_spread >= 2) && all && io.feed_mode != 3 && np >= 2 && !io.train;
+    const int nA = m->att_lstm.n_wg, n1 = m->lstm1.n_wg, n2 = m->lstm2.n_wg;
+    int sp_a = 0, sp_b = 0, sp_c = 0;       // Z2 tiles [0, a) ride in the attention launch, Z1 tiles [0, b) in PreNet 0, ZA tiles [0, c) in the projection
+    if (spread) {
+        const int cap_att = std::max(1, m->n_cu - B);
+        const int free_last = (cap_att - n1 % cap_att) % cap_att;
+        sp_a = std::min(n2, free_last);
+        sp_b = std::min(n1, std::max(0, m->n_cu - m->prenet[0].n_wg));
+        sp_c = std::min(nA, std::max(0, m->n_cu - m->proj.n_wg));
+    }
+    auto job_Z1 = [&]() { return job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0); };
+    auto job_Z2 = [&]() { return job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0); };
+    auto job_ZAh = [&](int off) { return job(m->att_lstm, m->att_lstm.seg_kb[0] + KBe, KBa, pp(s->XA, s->XA_sz, 0, KBe * 16), off); };
     // 2. prenets (rnn_wrappers.py:51-53)
     for (int i = 0; all && io.feed_mode != 3 && i < np; ++i) {
         SkinnyCore c = core(m->prenet[i]);
@@ -1045,22 +1090,23 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
             e.out_plain = io.train->xp[i]; e.plain_ld = d.prenet_units[i]; e.plain_t_stride = (long long)B * d.prenet_units[i];
             e.plain_ncol = d.prenet_units[i];
         }
-        launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e);
+        PartialJobs pj{};
+        if (spread && i == 0) {
+            pj.skip = m->prenet[0].n_wg;
+            pj.core[0] = job_Z1(); pj.z[0] = s->Z1; pj.off[0] = 0; pj.n[0] = sp_b;
+        } else if (spread && i == 1) {
+            pj.skip = m->prenet[1].n_wg;
+            pj.core[0] = job_Z1(); pj.z[0] = s->Z1; pj.off[0] = sp_b; pj.n[0] = n1 - sp_b;
+            pj.core[1] = job_Z2(); pj.z[1] = s->Z2; pj.off[1] = sp_a; pj.n[1] = n2 - sp_a;
+            pj.core[2] = job_ZAh(0); pj.z[2] = s->ZA; pj.off[2] = sp_c; pj.n[2] = nA - sp_c;
+        }
+        launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e, (spread && i < 2) ? &pj : nullptr);
     }
-    const bool hoist = m->opt_hoist != 0;
     // One row block (B <= 16): the attention launch leaves > 240 CUs idle for ~19 us, so it takes all three state halves
     // (h1, h2 of this step and h_att for the NEXT step); the context part of the attention LSTM's K range stays in the
     // LSTM launch and the projection launch carries no rider.  At B = 64 the same placement costs a fourth rider round.
-    const bool att3 = hoist && m->opt_att3 && MB == 1 && !m->opt_lstm_only;
+    const bool att3 = hoist && m->opt_att3 && MB == 1 && !m->opt_lstm_only && !spread;
     const bool timing = m->opt_time_lstm && !m->opt_graph;
-    // recurrent half of an LSTM layer: [state operands] . kernel[their K range] -> z (partial_body)
-    auto job = [&](const Packed& p, int kb_w0, int kb_n, FragBuf src, int off) {
-        SkinnyCore c = core(p);
-        c.step_off = step_off + off;
-        c.t_hint = io.slot_hint ? step_off + off : -1;
-        c.kb_w0 = kb_w0; c.kbtot = kb_n; c.kb0 = 0; c.seg[0][1] = src;
-        return c;
-    };
     auto taped = [&](LstmEpi& e, int layer, int stream) {
         if (!io.train) return;
         e.train = 1; e.seed = io.train->seed; e.stream = stream;
@@ -1072,7 +1118,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     {
         SkinnyCore c = core(m->att_lstm);
         LstmEpi e{};
-        if (att3) {
+        if (att3 || spread) {
             c.kb0 = m->att_lstm.seg_kb[0];
             c.kbtot = m->att_lstm.seg_kb[0] + KBe;
             c.seg[0][0] = xp_last;
@@ -1109,7 +1155,10 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         const size_t lds = attn_lds_bytes(d, s->T);
         // the recurrent halves of the two decoder LSTMs of THIS step ride behind the attention grid
         PartialJobs pj{};
-        if (hoist) {
+        if (spread) {
+            pj.core[0] = job(m->lstm1, 0, KBa, pp(s->X1, s->X1_sz, 0, 0), 0); pj.z[0] = s->Z1x; pj.n[0] = n1;
+            pj.core[1] = job_Z2(); pj.z[1] = s->Z2; pj.n[1] = sp_a;
+        } else if (hoist) {
             pj.core[0] = job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0); pj.z[0] = s->Z1; pj.n[0] = m->lstm1.n_wg;
             pj.core[1] = job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0); pj.z[1] = s->Z2; pj.n[1] = m->lstm2.n_wg;
             if (att3) {
@@ -1127,7 +1176,8 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         SkinnyCore c = core(m->lstm1);
         LstmEpi e{};
         c.seg[0][1] = pp(s->X1, s->X1_sz, 0, 0);
-        if (hoist) { c.kbtot = KBa + KBe; e.zpart = s->Z1; }
+        if (spread) { c.kb_w0 = KBa; c.kbtot = KBe; c.seg[0][1] = pp(s->X1, s->X1_sz, 0, KBa * 16); e.zpart = s->Z1; e.zpart2 = s->Z1x; }
+        else if (hoist) { c.kbtot = KBa + KBe; e.zpart = s->Z1; }
         e.H = D; e.c[0] = s->c1; e.Hld = D;
         e.hprev[0] = pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16); e.hstate[0] = pp(s->X1, s->X1_sz, 1, (KBa + KBe) * 16);
         e.hraw[0] = pp(s->X2, s->X2_sz, 0, 0);
@@ -1158,7 +1208,8 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.stop_col = M * r; e.out_stop = io.stop; e.stop_ld = io.stop_ld; e.stop_t_mul = io.stop_t_mul; e.ctl_w = s->ctl;
         // the recurrent half of the attention LSTM of the NEXT step rides behind the projection grid
         PartialJobs pj{};
-        if (hoist && !att3) { pj.core[0] = job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1); pj.z[0] = s->ZA; pj.n[0] = m->att_lstm.n_wg; }
+        if (spread) { pj.skip = m->proj.n_wg; pj.core[0] = job_ZAh(1); pj.z[0] = s->ZA; pj.n[0] = sp_c; }
+        else if (hoist && !att3) { pj.core[0] = job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1); pj.z[0] = s->ZA; pj.n[0] = m->att_lstm.n_wg; }
         launch_dense(MB, dim3(m->proj.n_wg), st, c, e, (hoist && !att3) ? &pj : nullptr);
     } else if (hoist) {
         launch_partial(MB, dim3(m->att_lstm.n_wg), st, job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1), s->ZA);
