@@ -77,9 +77,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    # T2MI_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices; timing reductions on the CPU).  The driver's runs use the default: one rank per GPU, RCCL.
+    backend = os.environ.get("T2MI_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from tacotron2_amd.engine import Engine
     from tacotron2_amd.hparams import PROFILE_P
@@ -120,7 +128,7 @@ def main():
         frames += B * n * r
     barrier()
     dt = time.perf_counter() - t0
-    tot = torch.tensor([dt, float(frames)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([dt, float(frames)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -106,6 +106,7 @@ struct t2_model {
     int opt_hoist = 1;                  // recurrent halves of the LSTM GEMMs ride in the attention / projection launches
     int opt_att3 = 1;                   // B <= 16: all three riders in the attention launch
     int opt_spread = 1;                 // B > 16: riders spread as tile ranges over the PreNet / attention / projection launches
+    int opt_sp_att = -1;                // tuning: rider rounds the attention launch holds (-1: 3)
     int n_cu = 256;                     // compute units of the device (rider capacity of a launch)
     int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
@@ -370,6 +371,10 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     }
     else if (!strcmp(name, "att3")) {
         m->opt_att3 = value;
+        for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+    }
+    else if (!strcmp(name, "sp_att")) {
+        m->opt_sp_att = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
     else if (!strcmp(name, "spread")) {
@@ -1062,19 +1067,34 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     // Spread schedule (more than one row block, PreNet launches present).  Four hoisted products of K = one state width
     // each -- Z1 = h1.W, Z2 = h2.W (state of the previous step), Z1x = h_att_raw.W (this step's attention cell output),
     // ZA = h_att.W for the NEXT step -- are cut into column-tile ranges and placed on the CUs that the small launches of
-    // the step leave idle: PreNet 0 <- Z1, PreNet 1 <- rest of Z1, Z2, rest of ZA; attention <- Z1x + what fills its last
-    // rider round from Z2; projection <- ZA.  The riding workgroups are separate from the dense role's own, so a small
-    // launch lasts max(own, one rider round) instead of own + rider.  The attention LSTM then multiplies [prenet | ctx],
-    // LSTM 1 only the new context.
+    // the step leave idle.  The attention launch lasts ~25 us whenever anything rides in it and holds three rider rounds
+    // on its n_cu - B free CUs in that time, so it takes Z1x, Z2 and the tail of Z1; the projection takes ZA of the next
+    // step (as many tiles as it has free CUs); what is left (head of Z1, the last tiles of ZA) rides in the LAST PreNet
+    // launch and, only if that is full, in the one before.  The riding workgroups are separate from the dense role's own,
+    // so a small launch lasts max(own, one rider round) instead of own + rider.  The attention LSTM then multiplies
+    // [prenet | ctx], LSTM 1 only the new context.
     const bool spread = hoist && m->opt_spread && (MB >= 2 || m->opt_spread >= 2) && all && io.feed_mode != 3 && np >= 2 && !io.train;
     const int nA = m->att_lstm.n_wg, n1 = m->lstm1.n_wg, n2 = m->lstm2.n_wg;
-    int sp_a = 0, sp_b = 0, sp_c = 0;       // Z2 tiles [0, a) ride in the attention launch, Z1 tiles [0, b) in PreNet 0, ZA tiles [0, c) in the projection
+    struct Piece { int job, off, n; };       // job: 0 = Z1, 1 = Z2, 2 = ZA (this step's)
+    int za_proj = 0, z2_att = 0, z1_att = 0;
+    Piece pre_pieces[2][3] = {};             // [0]: last PreNet launch, [1]: the one before
+    int pre_np[2] = {0, 0};
     if (spread) {
-        const int cap_att = std::max(1, m->n_cu - B);
-        const int free_last = (cap_att - n1 % cap_att) % cap_att;
-        sp_a = std::min(n2, free_last);
-        sp_b = std::min(n1, std::max(0, m->n_cu - m->prenet[0].n_wg));
-        sp_c = std::min(nA, std::max(0, m->n_cu - m->proj.n_wg));
+        const int att_cap = (m->opt_sp_att >= 0 ? m->opt_sp_att : 3) * std::max(1, m->n_cu - B);
+        za_proj = std::min(nA, std::max(0, m->n_cu - m->proj.n_wg));
+        z2_att = std::min(n2, std::max(0, att_cap - n1));
+        z1_att = std::min(n1, std::max(0, att_cap - n1 - z2_att));
+        const Piece todo[3] = {{2, za_proj, nA - za_proj}, {1, z2_att, n2 - z2_att}, {0, 0, n1 - z1_att}};
+        int slot = 0, room = std::max(0, m->n_cu - m->prenet[np - 1].n_wg);
+        for (const Piece& q : todo) {
+            int off = q.off, n = q.n;
+            while (n > 0) {
+                if (slot == 0 && (room == 0 || pre_np[0] == 3)) { slot = 1; room = 1 << 30; }     // the rest: a second round there
+                const int k = std::min(n, room);
+                if (pre_np[slot] < 3) pre_pieces[slot][pre_np[slot]++] = Piece{q.job, off, k};
+                off += k; n -= k; room -= k;
+            }
+        }
     }
     auto job_Z1 = [&]() { return job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0); };
     auto job_Z2 = [&]() { return job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0); };
@@ -1091,16 +1111,17 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
             e.plain_ncol = d.prenet_units[i];
         }
         PartialJobs pj{};
-        if (spread && i == 0) {
-            pj.skip = m->prenet[0].n_wg;
-            pj.core[0] = job_Z1(); pj.z[0] = s->Z1; pj.off[0] = 0; pj.n[0] = sp_b;
-        } else if (spread && i == 1) {
-            pj.skip = m->prenet[1].n_wg;
-            pj.core[0] = job_Z1(); pj.z[0] = s->Z1; pj.off[0] = sp_b; pj.n[0] = n1 - sp_b;
-            pj.core[1] = job_Z2(); pj.z[1] = s->Z2; pj.off[1] = sp_a; pj.n[1] = n2 - sp_a;
-            pj.core[2] = job_ZAh(0); pj.z[2] = s->ZA; pj.off[2] = sp_c; pj.n[2] = nA - sp_c;
+        const int slot = np - 1 - i;        // 0: last PreNet launch
+        if (spread && slot < 2) {
+            pj.skip = m->prenet[i].n_wg;
+            for (int k = 0; k < pre_np[slot]; ++k) {
+                const Piece& q = pre_pieces[slot][k];
+                pj.core[k] = q.job == 0 ? job_Z1() : q.job == 1 ? job_Z2() : job_ZAh(0);
+                pj.z[k] = q.job == 0 ? s->Z1 : q.job == 1 ? s->Z2 : s->ZA;
+                pj.off[k] = q.off; pj.n[k] = q.n;
+            }
         }
-        launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e, (spread && i < 2) ? &pj : nullptr);
+        launch_dense(MB, dim3(m->prenet[i].n_wg), st, c, e, (spread && slot < 2 && pre_np[slot] > 0) ? &pj : nullptr);
     }
     // One row block (B <= 16): the attention launch leaves > 240 CUs idle for ~19 us, so it takes all three state halves
     // (h1, h2 of this step and h_att for the NEXT step); the context part of the attention LSTM's K range stays in the
@@ -1157,7 +1178,8 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         PartialJobs pj{};
         if (spread) {
             pj.core[0] = job(m->lstm1, 0, KBa, pp(s->X1, s->X1_sz, 0, 0), 0); pj.z[0] = s->Z1x; pj.n[0] = n1;
-            pj.core[1] = job_Z2(); pj.z[1] = s->Z2; pj.n[1] = sp_a;
+            pj.core[1] = job_Z2(); pj.z[1] = s->Z2; pj.n[1] = z2_att;
+            pj.core[2] = job_Z1(); pj.z[2] = s->Z1; pj.off[2] = n1 - z1_att; pj.n[2] = z1_att;
         } else if (hoist) {
             pj.core[0] = job(m->lstm1, KBa + KBe, s->KBd, pp(s->X1, s->X1_sz, 0, (KBa + KBe) * 16), 0); pj.z[0] = s->Z1; pj.n[0] = m->lstm1.n_wg;
             pj.core[1] = job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0); pj.z[1] = s->Z2; pj.n[1] = m->lstm2.n_wg;
@@ -1208,7 +1230,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.stop_col = M * r; e.out_stop = io.stop; e.stop_ld = io.stop_ld; e.stop_t_mul = io.stop_t_mul; e.ctl_w = s->ctl;
         // the recurrent half of the attention LSTM of the NEXT step rides behind the projection grid
         PartialJobs pj{};
-        if (spread) { pj.skip = m->proj.n_wg; pj.core[0] = job_ZAh(1); pj.z[0] = s->ZA; pj.n[0] = sp_c; }
+        if (spread) { pj.skip = m->proj.n_wg; pj.core[0] = job_ZAh(1); pj.z[0] = s->ZA; pj.n[0] = za_proj; }
         else if (hoist && !att3) { pj.core[0] = job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1); pj.z[0] = s->ZA; pj.n[0] = m->att_lstm.n_wg; }
         launch_dense(MB, dim3(m->proj.n_wg), st, c, e, (hoist && !att3) ? &pj : nullptr);
     } else if (hoist) {
