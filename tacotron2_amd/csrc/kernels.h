@@ -153,6 +153,10 @@ struct DenseEpi {
     float drop_rate;          // > 0: tf.layers.dropout after the activation (PreNet, modules.py:90), training mode
     uint32_t seed;
     int stream;
+    // fused first PreNet layer of the NEXT step (free-running decode): columns [fuse_col0, fuse_col0 + fuse_n) hold
+    // y . (W_mel[:, fed frames] . W_prenet0) + (b_mel[fed frames] . W_prenet0 + b_prenet0); relu, frag16 destination
+    int fuse_col0, fuse_n;
+    FragBuf fuse_frag;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -683,9 +687,15 @@ __device__ __forceinline__ void dense_body(const SkinnyCore& a, const DenseEpi& 
     for (int idx = threadIdx.x; idx < MB * 16 * 16; idx += T2_SKINNY_THREADS) {
         const int row = idx >> 4, c = idx & 15;
         const int col = wg * 16 + c;
-        if (row >= a.B || col >= e.N) continue;
+        if (row >= a.B) continue;
+        const bool fused_col = e.fuse_n > 0 && col >= e.fuse_col0 && col < e.fuse_col0 + e.fuse_n;
+        if (col >= e.N && !fused_col) continue;
         float v = red_sum<MB>(red, row, c);
         if (a.bias[0] != nullptr) v += a.bias[0][col];
+        if (fused_col) {
+            frag_slot(e.fuse_frag, t)[frag_idx(row, e.fuse_frag.koff + col - e.fuse_col0, MB)] = fmaxf(v, 0.f);
+            continue;
+        }
         if (e.relu) v = fmaxf(v, 0.f);
         if (e.drop_rate > 0.f) v = dropout_train(v, e.drop_rate, t2_u01(e.seed, e.stream, t, row, col));
         if (col == e.stop_col) {

@@ -91,6 +91,9 @@ struct t2_model {
     Packed prenet[T2_MAX_PRENET_LAYERS];
     ConvLayer prenet_plain[T2_MAX_PRENET_LAYERS];     // the same layers in plain layout (batched teacher-forced PreNets)
     Packed att_lstm, lstm1, lstm2, proj;
+    Packed proj_fused;                  // proj + the first PreNet layer of the next step composed into it (free-running decode)
+    bool proj_fused_ok = false;         // false after a device-side parameter refresh (the composition is made on the host)
+    int opt_projfuse = 1;
     float *wq = nullptr;                // query layer kernel [A][U], plain
     float *conv_w = nullptr, *conv_b = nullptr, *wloc = nullptr, *v_a = nullptr, *b_a = nullptr;
     // cached workspaces
@@ -373,6 +376,10 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
         m->opt_att3 = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
+    else if (!strcmp(name, "projfuse")) {
+        m->opt_projfuse = value;
+        for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+    }
     else if (!strcmp(name, "sp_att")) {
         m->opt_sp_att = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
@@ -488,6 +495,36 @@ extern "C" int t2_model_finalize(t2_model* m) {
         for (int c = 0; c < M * r; ++c) bc[c] = bm->data[c];
         bc[M * r] = bs->data[0];
         T2_TRY(pack_skinny(m, &m->proj, wc.data(), N, {{0, D}}, 0, N, bc.data()));
+        // Free-running decode: the first PreNet layer of step t+1 reads only the fed-back frames of step t's mel output
+        // (helpers.py:86), so relu((y.Wm + bm)[fed] . Wp + bp) = relu(y . (Wm[:, fed] . Wp) + (bm[fed] . Wp + bp)): the
+        // composed columns are appended to the projection (16-column tile aligned) and the PreNet-0 launch disappears.
+        // Composition in double, rounded once.
+        {
+            const HostWeight *wp, *bp;
+            const int nfm = M * d.n_feed_frame, c0 = M * (r - d.n_feed_frame), P0 = d.prenet_units[0], N0 = pad16(N), N2 = N0 + P0;
+            T2_TRY(get_w(m, "decoder/prenet_0/dense/kernel", &wp, {nfm, P0}));
+            T2_TRY(get_w(m, "decoder/prenet_0/dense/bias", &bp, {P0}));
+            std::vector<float> w2((size_t)D * N2, 0.f), b2(N2, 0.f);
+            std::vector<double> acc(P0);
+            for (int k = 0; k < D; ++k) {
+                for (int c = 0; c < N; ++c) w2[(size_t)k * N2 + c] = wc[(size_t)k * N + c];
+                std::fill(acc.begin(), acc.end(), 0.0);
+                for (int j = 0; j < nfm; ++j) {
+                    const double a = wm->data[(size_t)k * M * r + c0 + j];
+                    const float* wr = wp->data.data() + (size_t)j * P0;
+                    for (int q = 0; q < P0; ++q) acc[q] += a * (double)wr[q];
+                }
+                for (int q = 0; q < P0; ++q) w2[(size_t)k * N2 + N0 + q] = (float)acc[q];
+            }
+            for (int c = 0; c < N; ++c) b2[c] = bc[c];
+            for (int q = 0; q < P0; ++q) {
+                double a = bp->data[q];
+                for (int j = 0; j < nfm; ++j) a += (double)bm->data[c0 + j] * (double)wp->data[(size_t)j * P0 + q];
+                b2[N0 + q] = (float)a;
+            }
+            T2_TRY(pack_skinny(m, &m->proj_fused, w2.data(), N2, {{0, D}}, 0, N2, b2.data()));
+            m->proj_fused_ok = true;
+        }
     }
     cin = M;
     m->post_convs.resize(d.postnet_layers);
@@ -1027,6 +1064,15 @@ struct TrainTape {
     float *q, *state_prev, *ctx;              // attention: q + b_a, state before the step, context
 };
 
+// which launch schedule a decoder step uses (see launch_step)
+static inline bool spread_mode(const t2_model* m, int MB, int feed_mode, bool train) {
+    return m->opt_hoist && m->opt_spread && (MB >= 2 || m->opt_spread >= 2) && !m->opt_lstm_only && feed_mode != 3 &&
+           m->d.num_prenet_layers >= 2 && !train;
+}
+static inline bool fused_mode(const t2_model* m, int MB, int feed_mode, bool train) {
+    return m->opt_hoist && !m->opt_lstm_only && !train && feed_mode == 1 && m->opt_projfuse && m->proj_fused_ok;
+}
+
 static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     t2_model* m = s->m;
     const t2_dims& d = m->d;
@@ -1073,19 +1119,23 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     // launch and, only if that is full, in the one before.  The riding workgroups are separate from the dense role's own,
     // so a small launch lasts max(own, one rider round) instead of own + rider.  The attention LSTM then multiplies
     // [prenet | ctx], LSTM 1 only the new context.
-    const bool spread = hoist && m->opt_spread && (MB >= 2 || m->opt_spread >= 2) && all && io.feed_mode != 3 && np >= 2 && !io.train;
+    const bool spread = spread_mode(m, MB, io.feed_mode, io.train != nullptr);
     const int nA = m->att_lstm.n_wg, n1 = m->lstm1.n_wg, n2 = m->lstm2.n_wg;
+    // fused: the projection launch also computes the first PreNet layer of the next step (composed weights), so the
+    // PreNet-0 launch is skipped (step 0 gets it from decode_prologue)
+    const bool fused = fused_mode(m, MB, io.feed_mode, io.train != nullptr);
+    const Packed& projP = fused ? m->proj_fused : m->proj;
     struct Piece { int job, off, n; };       // job: 0 = Z1, 1 = Z2, 2 = ZA (this step's)
     int za_proj = 0, z2_att = 0, z1_att = 0;
     Piece pre_pieces[2][3] = {};             // [0]: last PreNet launch, [1]: the one before
     int pre_np[2] = {0, 0};
     if (spread) {
         const int att_cap = (m->opt_sp_att >= 0 ? m->opt_sp_att : 3) * std::max(1, m->n_cu - B);
-        za_proj = std::min(nA, std::max(0, m->n_cu - m->proj.n_wg));
+        za_proj = std::min(nA, std::max(0, m->n_cu - projP.n_wg));
         z2_att = std::min(n2, std::max(0, att_cap - n1));
         z1_att = std::min(n1, std::max(0, att_cap - n1 - z2_att));
         const Piece todo[3] = {{2, za_proj, nA - za_proj}, {1, z2_att, n2 - z2_att}, {0, 0, n1 - z1_att}};
-        int slot = 0, room = std::max(0, m->n_cu - m->prenet[np - 1].n_wg);
+        int slot = 0, room = fused ? (1 << 30) : std::max(0, m->n_cu - m->prenet[np - 1].n_wg);     // fused: no launch before the last PreNet
         for (const Piece& q : todo) {
             int off = q.off, n = q.n;
             while (n > 0) {
@@ -1100,7 +1150,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     auto job_Z2 = [&]() { return job(m->lstm2, s->KBd, s->KBd, pp(s->X2, s->X2_sz, 0, s->KBd * 16), 0); };
     auto job_ZAh = [&](int off) { return job(m->att_lstm, m->att_lstm.seg_kb[0] + KBe, KBa, pp(s->XA, s->XA_sz, 0, KBe * 16), off); };
     // 2. prenets (rnn_wrappers.py:51-53)
-    for (int i = 0; all && io.feed_mode != 3 && i < np; ++i) {
+    for (int i = fused ? 1 : 0; all && io.feed_mode != 3 && i < np; ++i) {
         SkinnyCore c = core(m->prenet[i]);
         c.seg[0][1] = single(i == 0 ? s->xf : s->xp[i - 1], 0);
         DenseEpi e{};
@@ -1221,18 +1271,19 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     }
     // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
     if (all) {
-        SkinnyCore c = core(m->proj);
+        SkinnyCore c = core(projP);
         c.seg[0][1] = single(s->XY, 0);
         DenseEpi e{};
         e.N = M * r + 1; e.relu = 0;
+        if (fused) { e.fuse_col0 = pad16(M * r + 1); e.fuse_n = d.prenet_units[0]; e.fuse_frag = single(s->xp[0], 0); }
         e.out_plain = io.mel; e.plain_ld = io.mel_ld; e.plain_t_stride = io.mel_t_stride; e.plain_ncol = M * r;
         e.out_frag = io.feed_mode == 1 ? single(s->xf, 0) : none; e.frag_col0 = M * (r - nf);
         e.stop_col = M * r; e.out_stop = io.stop; e.stop_ld = io.stop_ld; e.stop_t_mul = io.stop_t_mul; e.ctl_w = s->ctl;
         // the recurrent half of the attention LSTM of the NEXT step rides behind the projection grid
         PartialJobs pj{};
-        if (spread) { pj.skip = m->proj.n_wg; pj.core[0] = job_ZAh(1); pj.z[0] = s->ZA; pj.n[0] = za_proj; }
+        if (spread) { pj.skip = projP.n_wg; pj.core[0] = job_ZAh(1); pj.z[0] = s->ZA; pj.n[0] = za_proj; }
         else if (hoist && !att3) { pj.core[0] = job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1); pj.z[0] = s->ZA; pj.n[0] = m->att_lstm.n_wg; }
-        launch_dense(MB, dim3(m->proj.n_wg), st, c, e, (hoist && !att3) ? &pj : nullptr);
+        launch_dense(MB, dim3(projP.n_wg), st, c, e, (hoist && !att3) ? &pj : nullptr);
     } else if (hoist) {
         launch_partial(MB, dim3(m->att_lstm.n_wg), st, job(m->att_lstm, m->att_lstm.seg_kb[0], KBe + KBa, pp(s->XA, s->XA_sz, 0, 0), 1), s->ZA);
     }
@@ -1340,6 +1391,24 @@ static int enqueue_chunk(t2_state* s, int mode, int chunk) {
     return T2_OK;
 }
 
+// Fused schedule: step t's projection launch produces the first PreNet layer of step t + 1; step 0 takes it from here
+// (go frame = zeros in xf after state_zero: helpers.py:187-188).
+static int decode_prologue(t2_state* s, int mode) {
+    t2_model* m = s->m;
+    const StepIO io = loop_io(s, mode);
+    if (!fused_mode(m, s->MB, io.feed_mode, false)) return T2_OK;
+    SkinnyCore c{};
+    const Packed& p = m->prenet[0];
+    c.w[0] = c.w[1] = p.w; c.bias[0] = c.bias[1] = p.bias;
+    c.kb0 = 0; c.kbtot = p.kbtot; c.kb_w0 = 0; c.kb_full = p.kbtot; c.ctl = s->ctl; c.step_off = 0; c.B = s->B; c.t_hint = -1;
+    c.seg[0][1] = FragBuf{s->xf, 0, 1, 0, 0};
+    DenseEpi e{};
+    e.N = m->d.prenet_units[0]; e.relu = 1; e.out_frag = FragBuf{s->xp[0], 0, 1, 0, 0}; e.frag_col0 = 0; e.stop_col = -1;
+    launch_dense(s->MB, dim3(p.n_wg), m->ctx->stream, c, e);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
 static int run_chunk(t2_state* s, int mode) {
     t2_model* m = s->m;
     hipStream_t st = m->ctx->stream;
@@ -1381,6 +1450,7 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     HIP_TRY(hipMemcpyAsync(s->i_targets, targets, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     const int mode = teacher_forcing ? 0 : 1;
     if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
+    T2_TRY(decode_prologue(s, mode));
     for (int done = 0; done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
@@ -1427,6 +1497,7 @@ extern "C" int t2_decode_free_launch(t2_model* m, const float* memory, const int
                                      int max_iters, int min_iters, float* mel, float* stop, float* align) {
     t2_state* s = nullptr;
     T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
+    T2_TRY(decode_prologue(s, 1));
     for (int done = 0; done < max_iters; done += m->opt_chunk) T2_TRY(run_chunk(s, 1));
     T2_TRY(free_copy_out(s, mel, stop, align));
     m->pending = s;
@@ -1453,9 +1524,9 @@ extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* l
     int* h_flag = nullptr;
     HIP_TRY(hipHostMalloc((void**)&h_flag, 2 * 8 * sizeof(int), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-    int rc = T2_OK, n = 0;
+    int rc = decode_prologue(s, 1), n = 0;
     bool finished = false;
-    for (int done = 0; done < max_iters && !finished; done += m->opt_chunk, ++n) {
+    for (int done = 0; rc == T2_OK && done < max_iters && !finished; done += m->opt_chunk, ++n) {
         if (n >= 2) {
             hipEventSynchronize(ev[n & 1]);
             if (h_flag[(n & 1) * 8 + CTL_FINAL] != 0) { finished = true; break; }

@@ -1732,6 +1732,10 @@ extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
         HIP_TRY(hipMemcpy2DAsync(wc, (size_t)N * 4, wm, (size_t)M * r * 4, (size_t)M * r * 4, D, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpy2DAsync(wc + M * r, (size_t)N * 4, ws, 4, 4, D, hipMemcpyDeviceToDevice, st));
         repack(st, m->proj, wc, N, 1, N);
+        if (m->proj_fused_ok) {        // the composed projection + PreNet-0 operand is built on the host (t2_model_finalize):
+            m->proj_fused_ok = false;  // decode falls back to the separate PreNet-0 launch; cached step graphs are stale
+            for (t2_state* s2 : m->states) for (int i = 0; i < 2; ++i) if (s2->gexec[i]) { (void)hipGraphExecDestroy(s2->gexec[i]); s2->gexec[i] = nullptr; }
+        }
         repack(st, tr->projT, wc, 1, N, D);
         T2_TRY(copy(m->proj.bias, bm, (size_t)M * r));
         T2_TRY(copy(m->proj.bias + M * r, bs, 1));
