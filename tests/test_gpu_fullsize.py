@@ -54,6 +54,26 @@ def test_full_size_batch64_against_oracle(paper, hoist):
     eng.set_option("hoist", 1)
 
 
+@pytest.mark.parametrize("spread,projfuse", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("B", [64, 24, 3])
+def test_full_size_free_run_schedules_against_oracle(paper, spread, projfuse, B):
+    """Free-running decode under every launch schedule (riders spread over the small launches or not; first PreNet layer
+    composed into the projection launch or not) against the oracle's free run, for 1, 2 and 4 row blocks."""
+    d, w, eng, ids, lens = paper
+    eng.set_option("spread", spread)
+    eng.set_option("projfuse", projfuse)
+    S = 6
+    memory_o = O.encoder_v2(d, w, O.embedding_lookup(ids[:B], w["embedding"]), lens[:B])
+    mel_o, stop_o, st = O.decoder_v2(d.replace(min_iters=100), w, memory_o, memory_sequence_length=lens[:B], max_iters=S)
+    mel, stop, align, n = eng.decode_free(memory_o, lens[:B], max_iters=S, min_iters=100)
+    assert n == S
+    np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
+    np.testing.assert_allclose(_np(stop), stop_o, atol=2e-4)
+    np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
+    eng.set_option("spread", 1)
+    eng.set_option("projfuse", 1)
+
+
 def test_full_size_rows_are_independent(paper):
     """No tensor is shared across batch rows: rows decoded alone equal the same rows of the B = 64 batch."""
     d, w, eng, ids, lens = paper
