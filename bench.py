@@ -180,6 +180,15 @@ def main():
         for kv in args.opt:
             k, v = kv.split("=")
             eng.set_option(k, int(v))
+        # the whole production decoder step (all launches, riders included), same HIP-event timing
+        eng.decode_free_launch(memory, lens, n_steps, d.min_iters, lb, events=(e0, e1))
+        eng.decode_free_finish()
+        torch.cuda.synchronize()
+        ms_step = e0.elapsed_time(e1) / n_steps
+        P2_, E_, A_, D_, U_ = d.prenet_units[-1], d.enc_units, d.attention_lstm_units, d.decoder_lstm_units, d.attention_dim
+        wd = (M * d.n_feed_frame * d.prenet_units[0] + d.prenet_units[0] * P2_ + (P2_ + E_ + A_) * 4 * A_ + A_ * U_ +
+              (A_ + E_ + D_) * 4 * D_ + 2 * D_ * 4 * D_ + D_ * (M * r + 1))
+        step_flops = B * (2.0 * wd + T_in * (2 * d.attention_kernel * d.attention_filters + 2 * d.attention_filters * U_ + 6 * U_ + 2 * E_ + 8))
         flops, byts = lstm_algorithmic(d, B)
         avg_s = ms * 1e-3 / max(n_l, 1)
         achieved = flops / avg_s / 1e12
@@ -197,6 +206,11 @@ def main():
                            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
                            "lstm_gemm_us_per_decoder_step": {"whole_k_3_launches": ms * 1e3 / n_steps,
                                                              "split_6_launches_standalone": ms_split * 1e3 / n_steps},
+                           "whole_decoder_step": {"us_per_step": ms_step * 1e3, "algorithmic_flops_per_step": step_flops,
+                                                  "achieved_TFLOPs": step_flops / (ms_step * 1e-3) / 1e12,
+                                                  "frac_of_fp32_mfma_peak": step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                                  "note": "all launches of the production schedule (hoisted products riding in the "
+                                                          "PreNet / attention / projection launches), SURVEY.md 8d formula Fd"},
                            "hbm_side": {"achieved_GBs": byts / avg_s / 1e9, "peak_GBs": HBM_PEAK_GBS,
                                         "frac": byts / avg_s / 1e9 / HBM_PEAK_GBS}}
 
