@@ -108,7 +108,7 @@ struct t2_model {
     int opt_splitk = 0;                 // batches > 16 rows: split-K LSTM step with in-launch reduction
     int opt_hoist = 1;                  // recurrent halves of the LSTM GEMMs ride in the attention / projection launches
     int opt_att3 = 1;                   // B <= 16: all three riders in the attention launch
-    int opt_spread = 1;                 // B > 16: riders spread as tile ranges over the PreNet / attention / projection launches
+    int opt_spread = 2;                 // riders spread as tile ranges over the PreNet / attention / projection launches (1: only B > 16)
     int opt_sp_att = -1;                // tuning: rider rounds the attention launch holds (-1: 3)
     int n_cu = 256;                     // compute units of the device (rider capacity of a launch)
     int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels

@@ -54,7 +54,7 @@ def test_full_size_batch64_against_oracle(paper, hoist):
     eng.set_option("hoist", 1)
 
 
-@pytest.mark.parametrize("spread,projfuse", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("spread,projfuse", [(2, 1), (2, 0), (1, 1), (0, 1), (0, 0)])
 @pytest.mark.parametrize("B", [64, 24, 3])
 def test_full_size_free_run_schedules_against_oracle(paper, spread, projfuse, B):
     """Free-running decode under every launch schedule (riders spread over the small launches or not; first PreNet layer
@@ -70,7 +70,7 @@ def test_full_size_free_run_schedules_against_oracle(paper, spread, projfuse, B)
     np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
     np.testing.assert_allclose(_np(stop), stop_o, atol=2e-4)
     np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
-    eng.set_option("spread", 1)
+    eng.set_option("spread", 2)
     eng.set_option("projfuse", 1)
 
 
