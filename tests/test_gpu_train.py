@@ -300,3 +300,40 @@ def test_model_fn_train_mode():
     out2 = model2.model_fn(feats, labels, ModeKeys.TRAIN, params={"decay_learning_rate": False, "initial_learning_rate": 0.01})
     assert out2["learning_rate"] == 0.01 and float(out2["loss"]) == losses_model[0]
     model.close(); model2.close()
+
+
+def test_training_step_on_a_pipeline_batch():
+    """Ragged utterances through the reference's batching rules (tacotron2_amd/datasets.py: tail padding to a multiple of r,
+    done padded with 1, masks padded with 0) into one training step: losses against the oracle on the same batch."""
+    import torch
+    from oracle import torch_train as TT
+    from tacotron2_amd import datasets as DS
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    d = MID
+    rng = np.random.default_rng(17)
+    ex = []
+    for i, (n_in, n_out) in enumerate(((9, 7), (12, 10), (6, 5), (11, 9))):
+        ex.append((DS.prepare_source(rng.integers(1, d.num_symbols, n_in), example_id=i),
+                   rng.uniform(0, 1, (n_out, d.num_mels)).astype(np.float32)))
+    batches = list(DS.group_by_batch(ex, batch_size=4, r=d.outputs_per_step, approx_min_target_length=0))
+    assert len(batches) == 1
+    feats, labels = batches[0]
+    B, T = feats["source"].shape
+    S = labels["done"].shape[1]
+    assert (B, T, S) == (4, 12, 5) and labels["target_length"].tolist() == [8, 10, 6, 10]
+    w = init_weights(d, 23, perturb=True)
+    eng = Engine(d, w)
+    spec = TR.flatten_spec(w)
+    tr = TR.Trainer(eng, B, T, S)
+    tr.bind_gradients(spec)
+    flat = torch.tensor(TR.flatten(w, spec), device="cuda")
+    grads = torch.zeros_like(flat)
+    opt = TR.AdamOptimizer(eng, flat.numel(), learning_rate=1e-3)
+    ref = TT.train_forward_backward(d, w, feats["source"], feats["source_length"], labels, seed=9, prenet_drop_rate=0.5,
+                                    encoder_drop_rate=0.5)
+    _, losses = tr.train_step(opt, flat, grads, feats, labels, global_step=0, seed=9)
+    assert abs(float(losses[2]) - ref["loss"]) < 2e-4 * max(1.0, abs(ref["loss"])), (float(losses[2]), ref["loss"])
+    for o in (tr, eng):
+        o.close()
+    opt.close()
