@@ -269,6 +269,17 @@ int t2v1_decode_teacher(t2v1_model* m, const float* memory, const int64_t* lens,
 int t2v1_decode_free(t2v1_model* m, const float* memory, const int64_t* lens, int B, int T_in, int max_iters, int min_iters,
                      float* mel, float* stop, float* align, int* steps_out);
 
+/* ---- spectrogram -> waveform ------------------------------------------------------------
+ * Audio.inv_spectrogram_tf (util/audio.py:55-59): inv_amp_tf (:51-53: clip to [0,1], de-normalise with min_level_db,
+ * + ref_level_db, dB -> amplitude), ** power, then _griffin_lim_tf (:66-82): y = inverse_stft(S); `iters` times
+ * { est = stft(y); y = inverse_stft(S * est / max(1e-8, |est|)) } with tf.contrib.signal.stft / inverse_stft at
+ * (frame_length = win_length, frame_step = hop_length, fft_length = 2 (num_freq - 1)), periodic Hann windows
+ * (_stft_tf / _istft_tf / _stft_parameters :88-100).  spectrogram dev [B,T,num_freq] (normalised, as the V1 PostNet
+ * emits it), wav dev [B, (T - 1) * hop_length + win_length].  The reference runs B = 1 (synthesize.py:39); rows are
+ * independent.  n_fft must be a power of two <= 4096 (the reference: 2048). */
+int t2_griffin_lim(t2_ctx* ctx, const float* spectrogram, int B, int T, int num_freq, int win_length, int hop_length,
+                   float min_level_db, float ref_level_db, float power, int iters, float* wav);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,7 @@ _SIGS = {
     "t2_optim_step": (C.c_int, [_p, _p, _p, C.c_float, C.c_float, C.c_float]),
     "t2_optim_get_state": (C.c_int, [_p, _p, _p, _i64p]),
     "t2_optim_set_state": (C.c_int, [_p, _p, _p, C.c_int64]),
+    "t2_griffin_lim": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _p]),
 }
 
 _lib = None

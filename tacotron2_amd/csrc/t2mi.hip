@@ -52,6 +52,8 @@ struct t2_ctx {
     hipStream_t stream;
     bool own_stream;
     float* red_ws = nullptr;   // partial sums of the loss reductions (train.h)
+    void* voc_ws = nullptr;    // Griffin-Lim workspace (vocoder.h), grown on demand
+    size_t voc_ws_bytes = 0;
 };
 
 struct HostWeight {
@@ -311,6 +313,7 @@ extern "C" int t2_ctx_create(int device, void* hip_stream, t2_ctx** out) {
 extern "C" int t2_ctx_destroy(t2_ctx* c) {
     if (!c) return T2_OK;
     if (c->red_ws) (void)hipFree(c->red_ws);
+    if (c->voc_ws) (void)hipFree(c->voc_ws);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return T2_OK;
@@ -1575,3 +1578,8 @@ extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
 // training step: training-mode forward with a tape, backward pass (BASELINE.json configs[3])
 // ------------------------------------------------------------------------------------------------
 #include "train_step.h"
+
+// ------------------------------------------------------------------------------------------------
+// spectrogram -> waveform (Griffin-Lim)
+// ------------------------------------------------------------------------------------------------
+#include "vocoder.h"

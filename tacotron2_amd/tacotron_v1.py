@@ -298,10 +298,11 @@ class SingleSpeakerTacotronV1Model:
 
 
 class TacotronV1PostNetModel:
-    """models.py:185-263 without the Griffin-Lim audio entry (:256, util/audio.py: out of scope)."""
+    """models.py:185-263.  ``audio``: a ``tacotron2_amd.audio.Audio`` (the reference's constructor argument, :185-187);
+    when given, PREDICT adds the Griffin-Lim waveform of the predicted spectrogram (:256)."""
 
-    def __init__(self, params: V1Dims, engine: EngineV1):
-        self.params, self.engine = params, engine
+    def __init__(self, params: V1Dims, engine: EngineV1, audio=None):
+        self.params, self.engine, self.audio = params, engine, audio
         self.post_net = PostNet(False, params.num_freq, params.post_net_cbhg_out_units, params.post_net_conv_channels,
                                 params.post_net_max_filter_width, params.post_net_projection1_out_channels,
                                 params.post_net_projection2_out_channels, params.post_net_num_highway, engine=engine)
@@ -315,6 +316,9 @@ class TacotronV1PostNetModel:
             lab = labels if isinstance(labels, dict) else labels.__dict__
             loss = training.spec_loss(self.engine, linear_output, lab["spec"], lab["spec_loss_mask"])     # models.py:208-211
             return {"loss": loss, "eval_metric_ops": {"linear_loss": loss}, "spec": linear_output}
-        return {"predictions": {"id": f.get("id"), "spec": linear_output, "mel": f["mel"], "ground_truth_spec": f.get("spec"),
-                                "ground_truth_mel": f.get("ground_truth_mel"), "alignment": f.get("alignment"),
-                                "source": f.get("source"), "text": f.get("text")}}
+        pred = {"id": f.get("id"), "spec": linear_output, "mel": f["mel"], "ground_truth_spec": f.get("spec"),
+                "ground_truth_mel": f.get("ground_truth_mel"), "alignment": f.get("alignment"),
+                "source": f.get("source"), "text": f.get("text")}
+        if self.audio is not None:
+            pred["audio"] = self.audio.inv_spectrogram_tf(linear_output)                                  # models.py:256
+        return {"predictions": pred}
