@@ -96,6 +96,7 @@ struct t2_model {
     Packed proj_fused;                  // proj + the first PreNet layer of the next step composed into it (free-running decode)
     bool proj_fused_ok = false;         // false after a device-side parameter refresh (the composition is made on the host)
     int opt_projfuse = 1;
+    int opt_conv_generic = 0;           // tuning / tests: 1 forces the generic conv_gemm_kernel
     float *wq = nullptr;                // query layer kernel [A][U], plain
     float *conv_w = nullptr, *conv_b = nullptr, *wloc = nullptr, *v_a = nullptr, *b_a = nullptr;
     // cached workspaces
@@ -379,6 +380,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
         m->opt_att3 = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
+    else if (!strcmp(name, "conv_generic")) m->opt_conv_generic = value;
     else if (!strcmp(name, "projfuse")) {
         m->opt_projfuse = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
@@ -574,7 +576,10 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
     a.vec_a = (L.cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0);
     a.vec_b = (L.cout % 4 == 0) && (((uintptr_t)L.w) % 16 == 0);
     dim3 grid(ceil_div(L.cout, CG_BN), ceil_div(Mtot, CG_BM));
-    hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, m->ctx->stream, a);
+    if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic)
+        hipLaunchKernelGGL(conv_gemm_fast_kernel, grid, dim3(256), 0, m->ctx->stream, a);
+    else
+        hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, m->ctx->stream, a);
     HIP_TRY(hipGetLastError());
     return T2_OK;
 }
