@@ -1454,17 +1454,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // division or divergent control flow in the main loop), no split-K, no transposed operand.  Same
 // tiles, same MFMA loop, same summation order and epilogue as the generic kernel (bit-identical results).
 // ------------------------------------------------------------------------------------------------
+template <int MI>      // M sub-tiles of 32 rows per wave: workgroup tile 64 * MI rows x 128 columns (MI = 1 for small M: more workgroups)
 __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
-    __shared__ float As[2][CG_BK][CG_LD];
+    constexpr int BM = 64 * MI;
+    __shared__ float As[2][CG_BK][BM + 4];
     __shared__ float Bs[2][CG_BK][CG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * CG_BM, n0 = blockIdx.x * CG_BN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * CG_BN;
     const int nk = (a.ktaps * a.Cin) / CG_BK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1473,10 +1475,10 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
     const int a_kq = tid & 3, a_r0 = tid >> 2;
     const int b_nq = tid & 31, b_k0 = tid >> 5;
     // per-thread row state of the A loader: position inside the utterance (or far outside for rows >= Mtot)
-    int tt[2];
-    const float* xrow[2];
+    int tt[MI];
+    const float* xrow[MI];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < MI; ++p) {
         const int m = m0 + a_r0 + p * 64;
         tt[p] = m < a.Mtot ? m % a.T : -(1 << 28);
         xrow[p] = a.x + (size_t)min(m, a.Mtot - 1) * a.ldx + a_kq * 4;
@@ -1485,12 +1487,12 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
     const bool b_ok = n_b < a.N;
     const float* wcol = a.w + (size_t)b_k0 * a.N + (b_ok ? n_b : 0);
 
-    float4 ra[2], rbv[2];
+    float4 ra[MI], rbv[2];
     int tap = 0, ci = 0;                          // k-tile kt covers channels [ci, ci + 16) of tap `tap`
     auto load_tiles = [&](int kt) {
         const int dt = tap - a.pad_l;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < MI; ++p) {
             const int ts = tt[p] + dt;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ts >= 0 && ts < a.T) v = *reinterpret_cast<const float4*>(xrow[p] + (long long)dt * a.ldx + ci);
@@ -1507,7 +1509,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < MI; ++p) {
             const int r = a_r0 + p * 64;
             As[buf][a_kq * 4 + 0][r] = ra[p].x;
             As[buf][a_kq * 4 + 1][r] = ra[p].y;
@@ -1527,20 +1529,20 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
         if (kt + 1 < nk) load_tiles(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < CG_BK; ks += 2) {
-            const float a0 = As[buf][ks + lh][wm * 64 + l31];
-            const float a1 = As[buf][ks + lh][wm * 64 + 32 + l31];
             const float b0 = Bs[buf][ks + lh][wn * 64 + l31];
             const float b1 = Bs[buf][ks + lh][wn * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const float av = As[buf][ks + lh][wm * 32 * MI + i * 32 + l31];
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+            }
         }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + l31;
@@ -1549,7 +1551,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
             const float sh = a.shift ? a.shift[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= a.Mtot) continue;
                 float v = acc[i][j][r] * sc + sh;
                 if (a.act == 1) v = fmaxf(v, 0.f);

@@ -576,9 +576,15 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
     a.vec_a = (L.cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0);
     a.vec_b = (L.cout % 4 == 0) && (((uintptr_t)L.w) % 16 == 0);
     dim3 grid(ceil_div(L.cout, CG_BN), ceil_div(Mtot, CG_BM));
-    if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic)
-        hipLaunchKernelGGL(conv_gemm_fast_kernel, grid, dim3(256), 0, m->ctx->stream, a);
-    else
+    if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic) {
+        // fewer than ~3 workgroups of 128 rows per CU: 64-row tiles (twice the workgroups) keep more waves per SIMD
+        if ((long long)grid.x * grid.y < 3LL * m->n_cu) {
+            grid.y = ceil_div(Mtot, 64);
+            hipLaunchKernelGGL(conv_gemm_fast_kernel<1>, grid, dim3(256), 0, m->ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL(conv_gemm_fast_kernel<2>, grid, dim3(256), 0, m->ctx->stream, a);
+        }
+    } else
         hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, m->ctx->stream, a);
     HIP_TRY(hipGetLastError());
     return T2_OK;
