@@ -1563,6 +1563,105 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight-gradient fast path (trans_a mode of conv_gemm_kernel with float4 operands): the output rows of a thread
+// (tap j, channels i .. i + 3) never change, and the position of a reduction row inside its utterance advances by the
+// k-tile, so the main loop holds no integer division.  Same tiles, MFMA loop, split-K scheme and summation order as
+// the generic kernel (bit-identical results).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_gemm_wgrad_fast_kernel(ConvArgs a) {
+    __shared__ float As[2][CG_BK][CG_LD];
+    __shared__ float Bs[2][CG_BK][CG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * CG_BM, n0 = blockIdx.x * CG_BN;
+    const int Ktot = a.red;
+    const int nk = (Ktot + CG_BK - 1) / CG_BK;
+    const int nz = a.splits > 1 ? a.splits : 1, z = a.splits > 1 ? (int)blockIdx.z : 0;
+    const int kt0 = (int)((long long)nk * z / nz), kt1 = (int)((long long)nk * (z + 1) / nz);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int b_nq = tid & 31, b_k0 = tid >> 5;
+    const int mo = m0 + b_nq * 4;                       // output rows mo .. mo + 3 = (tap, channels): fixed per thread
+    const bool mo_ok = mo < a.Mtot;
+    const int tap = mo_ok ? mo / a.Cin : 0, ch = mo_ok ? mo - tap * a.Cin : 0;
+    const int dt = tap - a.pad_l;
+    const bool taps = a.ktaps > 1;                      // plain GEMM (one tap): no utterance boundary to respect
+    int tt[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) tt[p] = taps ? (kt0 * CG_BK + b_k0 + p * 8) % a.T : 0;
+    const int n_b = n0 + b_nq * 4;
+    const bool b_ok = n_b < a.N;
+
+    float4 ra[2], rbv[2];
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int rr = kt * CG_BK + b_k0 + p * 8;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (rr < Ktot) {
+                const int ts = tt[p] + dt;
+                if (mo_ok && (!taps || (ts >= 0 && ts < a.T)))
+                    va = *reinterpret_cast<const float4*>(a.x + (long long)(rr + dt) * a.ldx + ch);
+                if (b_ok) vb = *reinterpret_cast<const float4*>(a.w + (size_t)rr * a.N + n_b);
+            }
+            ra[p] = va; rbv[p] = vb;
+            if (taps) { tt[p] += CG_BK; while (tt[p] >= a.T) tt[p] -= a.T; }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<float4*>(&As[buf][b_k0 + p * 8][b_nq * 4]) = ra[p];
+            *reinterpret_cast<float4*>(&Bs[buf][b_k0 + p * 8][b_nq * 4]) = rbv[p];
+        }
+    };
+    if (kt0 < kt1) {
+        load_tiles(kt0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tiles(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < CG_BK; ks += 2) {
+            const float a0 = As[buf][ks + lh][wm * 64 + l31];
+            const float a1 = As[buf][ks + lh][wm * 64 + 32 + l31];
+            const float b0 = Bs[buf][ks + lh][wn * 64 + l31];
+            const float b1 = Bs[buf][ks + lh][wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < kt1) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    float* dst = a.splits > 1 ? a.part + (size_t)z * a.Mtot * a.N : a.y;
+    const int ld = a.splits > 1 ? a.N : a.ldy;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < a.Mtot) dst[(size_t)m * ld + n] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Teacher-forced PreNets of ALL steps at once (TrainingHelper / ValidationHelper with teacher forcing feed known
 // frames, helpers.py:86,182): inputs gathered for every step, the Dense layers as conv_gemm_kernel GEMMs over S*B rows,
 // then the pass below (dropout in training mode, frag16 operands of the attention LSTM per step).

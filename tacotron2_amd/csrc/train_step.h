@@ -871,7 +871,10 @@ static int launch_wgrad(t2_trainer* tr, ConvArgs a) {
         if (!tr->wg_part) HIP_TRY(hipMalloc((void**)&tr->wg_part, (size_t)T2_WG_PART_FLOATS * 4));
         a.part = tr->wg_part;
     }
-    hipLaunchKernelGGL(conv_gemm_kernel, dim3(gx, gy, (unsigned)z), dim3(256), 0, st, a);
+    if (a.trans_a && a.vec_a && a.vec_b && !a.scale && !a.shift && !a.res && a.act == 0 && !tr->m->opt_conv_generic)
+        hipLaunchKernelGGL(conv_gemm_wgrad_fast_kernel, dim3(gx, gy, (unsigned)z), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(conv_gemm_kernel, dim3(gx, gy, (unsigned)z), dim3(256), 0, st, a);
     if (z > 1) {
         const long long n = (long long)a.Mtot * a.N;
         hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))), dim3(256), 0, st,
