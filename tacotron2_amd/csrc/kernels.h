@@ -119,6 +119,7 @@ struct LstmEpi {
     int reverse[2];           // direction writes to position len-1-t
     const float* zpart;       // optional partial pre-activations of the recurrent K range (partial_step_kernel), D-fragment layout
     const float* zpart2;      // optional second partial (a second hoisted K range), same layout
+    float* y_all;             // optional plain [S][B][H] store of the raw output of every step (deferred projection)
     // fused partial query (attention LSTM only): qpart[wg][row][u] = sum_uu h[row][4wg+uu] * wq[4wg+uu][u]
     const float* wq;          // [A][U] or null
     float* qpart;             // [n_wg][MB*16][U]
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void lstm_step_kernel(SkinnyCore
             e.c[dir][(size_t)row * e.Hld + unit] = cs;
             frag_slot(e.hstate[dir], t)[frag_idx(row, e.hstate[dir].koff + unit, MB)] = hs;
             if (e.hraw[dir].base != nullptr) frag_slot(e.hraw[dir], t)[frag_idx(row, e.hraw[dir].koff + unit, MB)] = hn;
+            if (e.y_all != nullptr) e.y_all[((size_t)t * a.B + row) * e.H + unit] = hn;
             if (e.plain_out != nullptr && live) {
                 const int tpos = e.reverse[dir] ? (len - 1 - t) : t;
                 e.plain_out[(size_t)row * e.plain_bs + (size_t)tpos * e.plain_ts + e.plain_off[dir] + unit] = hn;
@@ -1659,6 +1661,21 @@ __global__ __launch_bounds__(256) void conv_gemm_wgrad_fast_kernel(ConvArgs a) {
                 if (m < a.Mtot) dst[(size_t)m * ld + n] = acc[i][j][r];
             }
         }
+}
+
+// Deferred projection of a teacher-forced decode: rows (t, b) of the batched GEMM output [S*B][ld] -> mel [b][t][M*r]
+// (row stride mel_ld, step stride M*r) and the stop logit [b][t] (row stride stop_ld).
+__global__ __launch_bounds__(256) void proj_scatter_kernel(const float* __restrict__ y, int ld, int S, int B, int ncol, float* __restrict__ mel,
+                                                           long long mel_ld, float* __restrict__ stop, int stop_ld) {
+    const long long n = (long long)S * B * (ncol + 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (ncol + 1));
+        const long long tb = i / (ncol + 1);
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        const float v = y[tb * ld + c];
+        if (c < ncol) mel[(long long)b * mel_ld + (long long)t * ncol + c] = v;
+        else stop[(long long)b * stop_ld + t] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -97,6 +97,8 @@ struct t2_model {
     bool proj_fused_ok = false;         // false after a device-side parameter refresh (the composition is made on the host)
     int opt_projfuse = 1;
     int opt_conv_generic = 0;           // tuning / tests: 1 forces the generic conv_gemm_kernel
+    ConvLayer proj_plain;               // mel | stop projection in plain layout [D][pad4(M*r + 1)] (deferred, batched projection)
+    int opt_tfproj = 1;                 // teacher-forced decode: projections of all steps as one GEMM after the loop
     float *wq = nullptr;                // query layer kernel [A][U], plain
     float *conv_w = nullptr, *conv_b = nullptr, *wloc = nullptr, *v_a = nullptr, *b_a = nullptr;
     // cached workspaces
@@ -139,6 +141,7 @@ struct t2_state {
     int KBe = 0, KBa = 0, KBd = 0;
     float *ZA = nullptr, *Z1 = nullptr, *Z2 = nullptr;   // recurrent-half pre-activations (partial_step_kernel)
     float* Z1x = nullptr;                        // LSTM 1: product of the attention cell's raw output (spread schedule)
+    float *y_all = nullptr, *proj_tmp = nullptr; // deferred projection of a teacher-forced decode: y2 of every step, GEMM output (lazy)
     unsigned* tickets = nullptr;                 // split-K arrival counters, 3 layers x tiles (zeroed with the slab)
     unsigned long long* sk_slabs = nullptr;      // split-K partial slabs [tiles][2][512][2]
     int sk_tiles = 0;
@@ -381,6 +384,10 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
     else if (!strcmp(name, "conv_generic")) m->opt_conv_generic = value;
+    else if (!strcmp(name, "tfproj")) {
+        m->opt_tfproj = value;
+        for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+    }
     else if (!strcmp(name, "projfuse")) {
         m->opt_projfuse = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
@@ -500,6 +507,15 @@ extern "C" int t2_model_finalize(t2_model* m) {
         for (int c = 0; c < M * r; ++c) bc[c] = bm->data[c];
         bc[M * r] = bs->data[0];
         T2_TRY(pack_skinny(m, &m->proj, wc.data(), N, {{0, D}}, 0, N, bc.data()));
+        {   // the same operand in plain layout, columns padded to a multiple of 4 (batched projection of teacher-forced decodes)
+            const int Np = (N + 3) & ~3;
+            std::vector<float> wp((size_t)D * Np, 0.f), bp(Np, 0.f);
+            for (int k = 0; k < D; ++k) for (int c = 0; c < N; ++c) wp[(size_t)k * Np + c] = wc[(size_t)k * N + c];
+            for (int c = 0; c < N; ++c) bp[c] = bc[c];
+            m->proj_plain.k = 1; m->proj_plain.cin = D; m->proj_plain.cout = Np;
+            T2_TRY(upload(m, &m->proj_plain.w, wp));
+            T2_TRY(upload(m, &m->proj_plain.shift, bp));
+        }
         // Free-running decode: the first PreNet layer of step t+1 reads only the fed-back frames of step t's mel output
         // (helpers.py:86), so relu((y.Wm + bm)[fed] . Wp + bp) = relu(y . (Wm[:, fed] . Wp) + (bm[fed] . Wp + bp)): the
         // composed columns are appended to the projection (16-column tile aligned) and the PreNet-0 launch disappears.
@@ -884,6 +900,7 @@ static void state_free(t2_state* s) {
     if (s->fixed) hipFree(s->fixed);
     if (s->outbuf) hipFree(s->outbuf);
     if (s->tf_buf) hipFree(s->tf_buf);
+    if (s->y_all) hipFree(s->y_all);
     delete s;
 }
 
@@ -1067,6 +1084,8 @@ struct StepIO {
     float* hist;
     int slot_hint;              // 1: ctl base is even (chunked loops with an even chunk), so t and step_off select the same slots
     const struct TrainTape* train;   // non-null: training-mode arithmetic (sampled dropout / zoneout) + tape writes
+    int defer_proj;             // 1: teacher-forced decode, no projection launch per step (teacher_projection after the loop)
+    float* y_all;               // where LSTM 2 keeps its raw output of every step [S][B][D] (null: the training tape has it)
 };
 
 // Tape of one teacher-forced training forward (csrc/train_step.h): plain [S][B][.] arrays read by the backward pass.
@@ -1190,7 +1209,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     // One row block (B <= 16): the attention launch leaves > 240 CUs idle for ~19 us, so it takes all three state halves
     // (h1, h2 of this step and h_att for the NEXT step); the context part of the attention LSTM's K range stays in the
     // LSTM launch and the projection launch carries no rider.  At B = 64 the same placement costs a fourth rider round.
-    const bool att3 = hoist && m->opt_att3 && MB == 1 && !m->opt_lstm_only && !spread;
+    const bool att3 = hoist && m->opt_att3 && (MB == 1 || io.defer_proj) && !m->opt_lstm_only && !spread;   // deferred projection: its rider moves here
     const bool timing = m->opt_time_lstm && !m->opt_graph;
     auto taped = [&](LstmEpi& e, int layer, int stream) {
         if (!io.train) return;
@@ -1281,10 +1300,14 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.hraw[0] = single(s->XY, 0);
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         taped(e, 2, T2_STREAM_ZONE_L2);
+        e.y_all = io.defer_proj ? io.y_all : nullptr;
         timed_lstm(timing, MB, m->lstm2.n_wg, st, c, e, (m->opt_splitk && !hoist) ? s->tickets + 2 * s->sk_tiles : nullptr, s->sk_slabs);
     }
     // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
-    if (all) {
+    if (all && io.defer_proj) {
+        // teacher forcing: nothing of this step's output is fed back (helpers.py:134-136,182), so the projections of all steps
+        // run as one GEMM after the loop (teacher_projection)
+    } else if (all) {
         SkinnyCore c = core(projP);
         c.seg[0][1] = single(s->XY, 0);
         DenseEpi e{};
@@ -1351,6 +1374,7 @@ static StepIO loop_io(t2_state* s, int mode) {
     StepIO io{};
     io.feed_mode = mode;
     if (mode == 0 && s->tf_frag != nullptr) { io.feed_mode = 3; io.xp_all = s->tf_frag; io.xp_all_stride = (int)s->tf_stride; io.xp_all_slots = s->cap; }
+    if (io.feed_mode == 3 && s->m->opt_tfproj && s->m->opt_hoist && s->m->opt_att3 && s->y_all != nullptr) { io.defer_proj = 1; io.y_all = s->y_all; }
     io.feed_src = s->i_targets ? s->i_targets + (size_t)M * (r - nf) : nullptr;
     io.feed_row_stride = (long long)s->cap * r * M;
     io.feed_t_stride = (long long)r * M;
@@ -1396,6 +1420,29 @@ static int teacher_prenets(t2_state* s, float drop_rate, uint32_t seed, float* c
 }
 
 // Enqueue one chunk of `chunk` steps followed by the base-step advance.
+// Deferred projection of a teacher-forced decode (rnn_wrappers.py:105-109 for all S steps at once): y_all [S*B][D] .
+// [D][M*r + 1] + bias as one GEMM, then rows (t, b) scattered to mel [B][S*r][M] / stop [B][S].
+static int teacher_projection_buffers(t2_state* s) {
+    if (s->y_all) return T2_OK;
+    const t2_dims& d = s->m->d;
+    const size_t SB = (size_t)s->cap * s->B, n_y = align_up(SB * d.decoder_lstm_units, 64), n_t = SB * s->m->proj_plain.cout;
+    hipError_t e = hipMalloc((void**)&s->y_all, (n_y + n_t) * 4);
+    if (e != hipSuccess) { s->y_all = nullptr; return fail(T2_ENOMEM, "hipMalloc(deferred projection buffers) failed: %s", hipGetErrorString(e)); }
+    s->proj_tmp = s->y_all + n_y;
+    return T2_OK;
+}
+static int teacher_projection(t2_state* s, const float* y_all, float* mel, long long mel_ld, float* stop, int stop_ld) {
+    t2_model* m = s->m;
+    const t2_dims& d = m->d;
+    const int S = s->cap, B = s->B, Np = m->proj_plain.cout, ncol = d.num_mels * d.outputs_per_step;
+    T2_TRY(launch_conv(m, m->proj_plain, y_all, d.decoder_lstm_units, s->proj_tmp, Np, S * B, S * B, 0, nullptr, 0));
+    const long long n = (long long)S * B * (ncol + 1);
+    hipLaunchKernelGGL(proj_scatter_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))), dim3(256), 0, m->ctx->stream,
+                       s->proj_tmp, Np, S, B, ncol, mel, mel_ld, stop, stop_ld);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
 static int enqueue_chunk(t2_state* s, int mode, int chunk) {
     hipStream_t st = s->m->ctx->stream;
     const StepIO io = loop_io(s, mode);
@@ -1464,8 +1511,11 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     HIP_TRY(hipMemcpyAsync(s->i_targets, targets, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     const int mode = teacher_forcing ? 0 : 1;
     if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
+    if (teacher_forcing && m->opt_tfproj) T2_TRY(teacher_projection_buffers(s));
     T2_TRY(decode_prologue(s, mode));
+    const bool deferred = loop_io(s, mode).defer_proj != 0;
     for (int done = 0; done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
+    if (deferred) T2_TRY(teacher_projection(s, s->y_all, s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(align, s->o_hist, (size_t)S * B * T_in * 4, hipMemcpyDeviceToDevice, st));

@@ -703,10 +703,13 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     // TrainingHelper feeds known frames, so the PreNets of all S steps run as batched GEMMs over S*B rows (tape rows
     // xp[i][t][b][:]), followed by the sampled dropout; the last layer also lands as the per-step frag16 operands.
     T2_TRY(teacher_prenets(s, prenet_drop_rate, seed, tr->tape.xp));
+    if (m->opt_tfproj) T2_TRY(teacher_projection_buffers(s));
     StepIO io = loop_io(s, 0);
     io.train = &tr->tape;
+    io.y_all = nullptr;                            // the tape keeps LSTM 2's raw output of every step (hraw[2])
     io.slot_hint = 1;                              // the control block's base stays 0: step t runs as step_off = t
     for (int t = 0; t < S; ++t) T2_TRY(launch_step(s, t, io));       // eager launches: seed and rates are per-call kernel arguments
+    if (io.defer_proj) T2_TRY(teacher_projection(s, tr->tape.hraw[2], s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * S * r * M * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
@@ -1735,6 +1738,9 @@ extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
         HIP_TRY(hipMemcpy2DAsync(wc, (size_t)N * 4, wm, (size_t)M * r * 4, (size_t)M * r * 4, D, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpy2DAsync(wc + M * r, (size_t)N * 4, ws, 4, 4, D, hipMemcpyDeviceToDevice, st));
         repack(st, m->proj, wc, N, 1, N);
+        HIP_TRY(hipMemcpy2DAsync(m->proj_plain.w, (size_t)m->proj_plain.cout * 4, wc, (size_t)N * 4, (size_t)N * 4, D, hipMemcpyDeviceToDevice, st));
+        T2_TRY(copy(m->proj_plain.shift, bm, (size_t)M * r));
+        T2_TRY(copy(m->proj_plain.shift + M * r, bs, 1));
         if (m->proj_fused_ok) {        // the composed projection + PreNet-0 operand is built on the host (t2_model_finalize):
             m->proj_fused_ok = false;  // decode falls back to the separate PreNet-0 launch; cached step graphs are stale
             for (t2_state* s2 : m->states) for (int i = 0; i < 2; ++i) if (s2->gexec[i]) { (void)hipGraphExecDestroy(s2->gexec[i]); s2->gexec[i] = nullptr; }

@@ -243,7 +243,7 @@ def test_load_params_and_training_loop_against_oracle():
     mel_a, _, _ = eng.decode_teacher(mem_a, lens, labels["mel"])
     mel_b, _, _ = eng2.decode_teacher(mem_b, lens, labels["mel"])
     np.testing.assert_allclose(_np(mel_a), _np(mel_b), atol=1e-6)
-    np.testing.assert_allclose(_np(eng.postnet(mel_a)), _np(eng2.postnet(mel_b)), atol=1e-6)
+    np.testing.assert_allclose(_np(eng.postnet(mel_a)), _np(eng2.postnet(mel_b)), atol=1e-6, rtol=2e-6)   # device-side BN fold: 1 ulp
     for o in (tr, eng2, eng):
         o.close()
     opt.close()
