@@ -192,13 +192,15 @@ def main():
         flops, byts = lstm_algorithmic(d, B)
         avg_s = ms * 1e-3 / max(n_l, 1)
         achieved = flops / avg_s / 1e12
-        traffic = None
+        traffic = step_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("lstm_step_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("lstm_step_hbm_bytes_per_launch")
+                step_traffic = tj.get("decoder_step_production", {}).get("hbm_bytes_per_step")
             except Exception:
-                traffic = None
+                traffic = step_traffic = None
         out["roofline"] = {"kernel": "lstm_step_kernel<4,false> (decoder LSTM step, B=64)", "bound": "mfma",
                            "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -209,6 +211,7 @@ def main():
                            "whole_decoder_step": {"us_per_step": ms_step * 1e3, "algorithmic_flops_per_step": step_flops,
                                                   "achieved_TFLOPs": step_flops / (ms_step * 1e-3) / 1e12,
                                                   "frac_of_fp32_mfma_peak": step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                                  "traffic_bytes_per_step": step_traffic,
                                                   "note": "all launches of the production schedule (hoisted products riding in the "
                                                           "PreNet / attention / projection launches), SURVEY.md 8d formula Fd"},
                            "hbm_side": {"achieved_GBs": byts / avg_s / 1e9, "peak_GBs": HBM_PEAK_GBS,
