@@ -256,6 +256,39 @@ def main():
                                           "peak_GBs": HBM_PEAK_GBS, "frac": bytes_step / us_step / 1e3 / HBM_PEAK_GBS,
                                           "note": "latency-bound: 6 dependent launches per step, not the weight stream"}}
 
+    # ---- teacher-forced decoder forward, B = 1, 100 characters / 800 frames (BASELINE.json configs[0], the reference's own
+    # CPU-runnable case): encoder + teacher-forced decode + PostNetV2 on the GPU, the NumPy port on the host beside it ----
+    if rank == 0 and not args.no_batch1:
+        try:
+            ids0, lens0 = make_inputs(1, 100, 100, seed=1234)
+            tgt0 = torch.tensor(np.random.default_rng(1234).uniform(0, 1, (1, S * r, M)).astype(np.float32), device="cuda")
+
+            def teacher1():
+                mem = eng.encode(ids0, lens0)
+                mel_t, stop_t, _ = eng.decode_teacher(mem, lens0, tgt0, teacher_forcing=True)
+                return mel_t, eng.postnet(mel_t)
+            teacher1()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(3):
+                mel_t, _ = teacher1()
+            torch.cuda.synchronize()
+            dt0 = (time.perf_counter() - t0_) / 3
+            out["teacher_forced_b1"] = {"workload": "BASELINE.json configs[0]: encoder + teacher-forced decoder forward + PostNetV2, B=1, "
+                                                    "T_in=100, %d frames" % (S * r), "ms": dt0 * 1e3, "frames_per_s": S * r / dt0}
+            if world == 1 and not args.no_cpu_baseline:
+                from oracle import t2_oracle as O
+                tc = time.perf_counter()
+                mem_o = O.encoder_v2(d, w, O.embedding_lookup(ids0, w["embedding"]), lens0)
+                mel_o, _, _ = O.decoder_v2(d, w, mem_o, is_validation=True, teacher_forcing=True, memory_sequence_length=lens0,
+                                           target=tgt0.cpu().numpy(), max_iters=S)
+                O.postnet_v2(d, w, mel_o)
+                dtc = time.perf_counter() - tc
+                out["teacher_forced_b1"]["cpu_port"] = {"ms": dtc * 1e3, "frames_per_s": S * r / dtc, "kind": "port",
+                                                        "max_abs_mel_diff": float(np.abs(mel_t.cpu().numpy() - mel_o).max())}
+        except Exception as ex:
+            out["teacher_forced_b1"] = {"error": repr(ex)}
+
     # ---- training step (BASELINE.json configs[3]; N=1 only: tools/train_bench.py is the multi-rank version) ----
     if rank == 0 and world == 1 and not args.no_train:
         try:
