@@ -900,7 +900,7 @@ static void state_free(t2_state* s) {
     if (s->fixed) hipFree(s->fixed);
     if (s->outbuf) hipFree(s->outbuf);
     if (s->tf_buf) hipFree(s->tf_buf);
-    if (s->y_all) hipFree(s->y_all);
+    if (s->proj_tmp) hipFree(s->proj_tmp);
     delete s;
 }
 
@@ -1174,7 +1174,8 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
             while (n > 0) {
                 if (slot == 0 && (room == 0 || pre_np[0] == 3)) { slot = 1; room = 1 << 30; }     // the rest: a second round there
                 const int k = std::min(n, room);
-                if (pre_np[slot] < 3) pre_pieces[slot][pre_np[slot]++] = Piece{q.job, off, k};
+                if (pre_np[slot] == 3) return fail(T2_ESTATE, "internal: rider plan needs more than three tile ranges in one launch");
+                pre_pieces[slot][pre_np[slot]++] = Piece{q.job, off, k};
                 off += k; n -= k; room -= k;
             }
         }
@@ -1301,6 +1302,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
         e.zc = d.zoneout_cell; e.zh = d.zoneout_output; e.fb = d.forget_bias;
         taped(e, 2, T2_STREAM_ZONE_L2);
         e.y_all = io.defer_proj ? io.y_all : nullptr;
+        if (io.defer_proj && !io.y_all && !io.train) return fail(T2_ESTATE, "internal: deferred projection without a store for LSTM 2's outputs");
         timed_lstm(timing, MB, m->lstm2.n_wg, st, c, e, (m->opt_splitk && !hoist) ? s->tickets + 2 * s->sk_tiles : nullptr, s->sk_slabs);
     }
     // 8. mel / stop projections + stop rule  (rnn_wrappers.py:105-109, helpers.py:90-94)
@@ -1374,7 +1376,7 @@ static StepIO loop_io(t2_state* s, int mode) {
     StepIO io{};
     io.feed_mode = mode;
     if (mode == 0 && s->tf_frag != nullptr) { io.feed_mode = 3; io.xp_all = s->tf_frag; io.xp_all_stride = (int)s->tf_stride; io.xp_all_slots = s->cap; }
-    if (io.feed_mode == 3 && s->m->opt_tfproj && s->m->opt_hoist && s->m->opt_att3 && s->y_all != nullptr) { io.defer_proj = 1; io.y_all = s->y_all; }
+    if (io.feed_mode == 3 && s->m->opt_tfproj && s->m->opt_hoist && s->m->opt_att3 && s->proj_tmp != nullptr) { io.defer_proj = 1; io.y_all = s->y_all; }
     io.feed_src = s->i_targets ? s->i_targets + (size_t)M * (r - nf) : nullptr;
     io.feed_row_stride = (long long)s->cap * r * M;
     io.feed_t_stride = (long long)r * M;
@@ -1422,13 +1424,14 @@ static int teacher_prenets(t2_state* s, float drop_rate, uint32_t seed, float* c
 // Enqueue one chunk of `chunk` steps followed by the base-step advance.
 // Deferred projection of a teacher-forced decode (rnn_wrappers.py:105-109 for all S steps at once): y_all [S*B][D] .
 // [D][M*r + 1] + bias as one GEMM, then rows (t, b) scattered to mel [B][S*r][M] / stop [B][S].
-static int teacher_projection_buffers(t2_state* s) {
-    if (s->y_all) return T2_OK;
+// with_y: also the [S][B][D] store of LSTM 2's raw outputs (the training tape has its own)
+static int teacher_projection_buffers(t2_state* s, bool with_y) {
+    if (s->proj_tmp) return T2_OK;
     const t2_dims& d = s->m->d;
-    const size_t SB = (size_t)s->cap * s->B, n_y = align_up(SB * d.decoder_lstm_units, 64), n_t = SB * s->m->proj_plain.cout;
-    hipError_t e = hipMalloc((void**)&s->y_all, (n_y + n_t) * 4);
-    if (e != hipSuccess) { s->y_all = nullptr; return fail(T2_ENOMEM, "hipMalloc(deferred projection buffers) failed: %s", hipGetErrorString(e)); }
-    s->proj_tmp = s->y_all + n_y;
+    const size_t SB = (size_t)s->cap * s->B, n_t = align_up(SB * s->m->proj_plain.cout, 64), n_y = with_y ? SB * d.decoder_lstm_units : 0;
+    hipError_t e = hipMalloc((void**)&s->proj_tmp, (n_t + n_y) * 4);
+    if (e != hipSuccess) { s->proj_tmp = nullptr; return fail(T2_ENOMEM, "hipMalloc(deferred projection buffers) failed: %s", hipGetErrorString(e)); }
+    s->y_all = with_y ? s->proj_tmp + n_t : nullptr;
     return T2_OK;
 }
 static int teacher_projection(t2_state* s, const float* y_all, float* mel, long long mel_ld, float* stop, int stop_ld) {
@@ -1511,7 +1514,7 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     HIP_TRY(hipMemcpyAsync(s->i_targets, targets, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     const int mode = teacher_forcing ? 0 : 1;
     if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
-    if (teacher_forcing && m->opt_tfproj) T2_TRY(teacher_projection_buffers(s));
+    if (teacher_forcing && m->opt_tfproj) T2_TRY(teacher_projection_buffers(s, true));
     T2_TRY(decode_prologue(s, mode));
     const bool deferred = loop_io(s, mode).defer_proj != 0;
     for (int done = 0; done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));

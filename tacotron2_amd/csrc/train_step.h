@@ -703,7 +703,7 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     // TrainingHelper feeds known frames, so the PreNets of all S steps run as batched GEMMs over S*B rows (tape rows
     // xp[i][t][b][:]), followed by the sampled dropout; the last layer also lands as the per-step frag16 operands.
     T2_TRY(teacher_prenets(s, prenet_drop_rate, seed, tr->tape.xp));
-    if (m->opt_tfproj) T2_TRY(teacher_projection_buffers(s));
+    if (m->opt_tfproj) T2_TRY(teacher_projection_buffers(s, false));
     StepIO io = loop_io(s, 0);
     io.train = &tr->tape;
     io.y_all = nullptr;                            // the tape keeps LSTM 2's raw output of every step (hraw[2])
