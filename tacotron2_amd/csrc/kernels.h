@@ -1731,6 +1731,7 @@ struct GruEpi {
     const int* lens;          // optional [B]
     float* plain_out;         // optional [B][T][ld]
     int plain_bs, plain_ts, plain_off, reverse;
+    float* y_all;             // optional plain [S][B][H] store of the output of every step (deferred projection)
 };
 
 template <int MB, int PHASE>
@@ -1771,6 +1772,7 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void gru_step_kernel(SkinnyCore 
             frag_slot(e.hstate, t)[frag_idx(row, e.hstate.koff + col, MB)] = hn;
             if (e.xres.base != nullptr) outv += frag_slot(e.xres, t)[frag_idx(row, e.xres.koff + col, MB)];
             if (e.out.base != nullptr) frag_slot(e.out, t)[frag_idx(row, e.out.koff + col, MB)] = outv;
+            if (e.y_all != nullptr) e.y_all[((size_t)t * a.B + row) * e.H + col] = outv;
             if (e.plain_out != nullptr && live) {
                 const int tpos = (e.reverse && e.lens != nullptr) ? (len - 1 - t) : t;
                 e.plain_out[(size_t)row * e.plain_bs + (size_t)tpos * e.plain_ts + e.plain_off + col] = outv;

@@ -28,6 +28,8 @@ struct t2v1_model {
     CbhgW enc_cbhg, post_cbhg;
     ConvLayer post_linear, memory_layer;
     Packed dec_prenet[2], query, outproj, proj;
+    ConvLayer dec_prenet_plain[2], proj_plain;   // teacher-forced decodes: PreNets and projections of all steps as batched GEMMs
+    int opt_tfbatch = 1;
     GruPacked att_gru, gru1, gru2;
     float* v_a = nullptr;
     float* zeros = nullptr;               // stands in for the location terms the plain Bahdanau score lacks
@@ -53,6 +55,9 @@ struct t2v1_state {
     float *o_mel = nullptr, *o_stop = nullptr, *o_hist = nullptr, *i_targets = nullptr;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     int gchunk[2] = {0, 0};
+    // teacher-forced decodes (lazy): gathered inputs, PreNet outputs, per-step frag16 operands, GRU 2 outputs, projection GEMM output
+    float *tf_buf = nullptr, *tf_xin = nullptr, *tf_x[2] = {nullptr, nullptr}, *tf_frag = nullptr, *y_all = nullptr, *proj_tmp = nullptr;
+    long long tf_stride = 0;
 };
 
 // ---- weights ---------------------------------------------------------------------------------------
@@ -147,10 +152,20 @@ extern "C" int t2v1_model_set_weight(t2v1_model* m, const char* name, const floa
     return t2_model_set_weight(&m->base, name, host_ptr, shape, rank);
 }
 
+static void v1_state_free(t2v1_state* s);
+
 extern "C" int t2v1_model_set_option(t2v1_model* m, const char* name, int value) {
     if (!m || !name) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "graph")) m->opt_graph = value;
     else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
+    else if (!strcmp(name, "tfbatch")) {      // teacher-forced decodes: batched PreNets / projections; states are shaped by it
+        if (value != m->opt_tfbatch) {
+            HIP_TRY(hipStreamSynchronize(m->base.ctx->stream));
+            for (t2v1_state* s : m->states) v1_state_free(s);
+            m->states.clear();
+        }
+        m->opt_tfbatch = value;
+    }
     else return fail(T2_EINVAL, "unknown option %s", name);
     return T2_OK;
 }
@@ -176,6 +191,8 @@ extern "C" int t2v1_model_finalize(t2v1_model* m) {
     T2_TRY(v1_dense_conv(b, &m->memory_layer, "v1/attention/memory_layer", E, A, false));
     T2_TRY(v1_pack_dense(b, &m->dec_prenet[0], "v1/decoder/prenet_0/dense", {{0, M * d.n_feed_frame}}, M * d.n_feed_frame, P0, true));
     T2_TRY(v1_pack_dense(b, &m->dec_prenet[1], "v1/decoder/prenet_1/dense", {{0, P0}}, P0, P1, true));
+    T2_TRY(v1_dense_conv(b, &m->dec_prenet_plain[0], "v1/decoder/prenet_0/dense", M * d.n_feed_frame, P0, true));
+    T2_TRY(v1_dense_conv(b, &m->dec_prenet_plain[1], "v1/decoder/prenet_1/dense", P0, P1, true));
     T2_TRY(v1_pack_gru(b, &m->att_gru, "v1/decoder/attention_gru", {{0, P1}, {P1, E}, {P1 + E, A}}, P1 + E + A, A));
     T2_TRY(v1_pack_dense(b, &m->query, "v1/attention/query_layer", {{0, A}}, A, A, false));
     // OutputProjectionWrapper input = concat(cell output, attention) (rnn_wrappers.py:76-78); the operand buffer holds [ctx | h]
@@ -197,6 +214,13 @@ extern "C" int t2v1_model_finalize(t2v1_model* m) {
         for (int c = 0; c < M * r; ++c) bcat[c] = bm->data[c];
         bcat[M * r] = bst->data[0];
         T2_TRY(pack_skinny(b, &m->proj, wcat.data(), N, {{0, D}}, 0, N, bcat.data()));
+        const int Np = (N + 3) & ~3;             // plain copy, columns padded to a multiple of 4 (batched projection)
+        std::vector<float> wp((size_t)D * Np, 0.f), bp(Np, 0.f);
+        for (int k = 0; k < D; ++k) for (int c = 0; c < N; ++c) wp[(size_t)k * Np + c] = wcat[(size_t)k * N + c];
+        for (int c = 0; c < N; ++c) bp[c] = bcat[c];
+        m->proj_plain.k = 1; m->proj_plain.cin = D; m->proj_plain.cout = Np;
+        T2_TRY(upload(b, &m->proj_plain.w, wp));
+        T2_TRY(upload(b, &m->proj_plain.shift, bp));
     }
     T2_TRY(get_w(b, "v1/attention/attention_v", &w, {A}));
     T2_TRY(upload(b, &m->v_a, w->data));
@@ -214,6 +238,7 @@ static void v1_state_free(t2v1_state* s) {
     if (s->fixed) hipFree(s->fixed);
     if (s->slab) hipFree(s->slab);
     if (s->outbuf) hipFree(s->outbuf);
+    if (s->tf_buf) hipFree(s->tf_buf);
     delete s;
 }
 
@@ -256,13 +281,14 @@ struct GruStep {
     FragBuf hprev, rh, hstate, out, xres;
     float* u;
     const int* lens; float* plain_out; int plain_bs, plain_ts, plain_off, reverse;
+    float* y_all;
 };
 
 static void v1_gru_step(int MB, int B, hipStream_t st, const int* ctl, int step_off, int t_hint, const GruStep& gs) {
     GruEpi e{};
     e.H = gs.g->H; e.hprev = gs.hprev; e.rh = gs.rh; e.u = gs.u; e.hstate = gs.hstate; e.out = gs.out; e.xres = gs.xres;
     e.lens = gs.lens; e.plain_out = gs.plain_out; e.plain_bs = gs.plain_bs; e.plain_ts = gs.plain_ts; e.plain_off = gs.plain_off;
-    e.reverse = gs.reverse;
+    e.reverse = gs.reverse; e.y_all = gs.y_all;
     SkinnyCore c = v1_core(gs.g->gates, ctl, step_off, t_hint, B);
     c.kb0 = gs.kbx; c.seg[0][0] = gs.x; c.seg[0][1] = gs.gates_rest;
     launch_gru<1>(MB, gs.g->gates.n_wg, st, c, e);
@@ -552,15 +578,18 @@ static int v1_launch_step(t2v1_state* s, int step_off, int mode, int slot_hint) 
     auto pp = [&](float* base, int sz, int dt, int koff) { return FragBuf{base, sz, 2, dt, koff}; };
     const FragBuf none{nullptr, 0, 1, 0, 0};
     const int KBe = s->KBe, KBd = s->KBd;
+    // teacher forcing with batched PreNets / projections (v1_teacher_prenets, v1_teacher_projection): the step keeps only
+    // what the recurrence needs
+    const bool batched = mode == 0 && s->tf_frag != nullptr;
     // 1. decoder input frames (teacher forcing only; otherwise the projection of the previous step wrote them)
-    if (mode == 0) {
+    if (mode == 0 && !batched) {
         FeedArgs f{};
         f.src = s->i_targets + (size_t)M * (r - nf); f.row_stride = (long long)s->cap * r * M; f.t_stride = (long long)r * M;
         f.dst = single(s->xf, 0); f.B = B; f.K = M * nf; f.MB = MB; f.go_zero = 1; f.ctl = s->ctl; f.step_off = step_off;
         hipLaunchKernelGGL(feed_frames_kernel, dim3(ceil_div(MB * 16 * pad16(M * nf), 256)), dim3(256), 0, st, f);
     }
     // 2. PreNets (rnn_wrappers.py:51-53)
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2 && !batched; ++i) {
         SkinnyCore c = v1_core(m->dec_prenet[i], s->ctl, step_off, hint, B);
         c.seg[0][1] = single(i == 0 ? s->xf : s->xp[0], 0);
         DenseEpi e{};
@@ -571,7 +600,7 @@ static int v1_launch_step(t2v1_state* s, int step_off, int mode, int slot_hint) 
     {
         GruStep gs{};
         gs.g = &m->att_gru;
-        gs.x = single(s->xp[1], 0); gs.kbx = m->att_gru.gates.seg_kb[0];
+        gs.x = batched ? FragBuf{s->tf_frag, (int)s->tf_stride, s->cap, 0, 0} : single(s->xp[1], 0); gs.kbx = m->att_gru.gates.seg_kb[0];
         gs.gates_rest = pp(s->XA, s->XA_sz, 0, 0);
         gs.cand_rest = single(s->XR, 0);
         gs.hprev = pp(s->XA, s->XA_sz, 0, KBe * 16); gs.rh = single(s->XR, KBe * 16); gs.hstate = pp(s->XA, s->XA_sz, 1, KBe * 16);
@@ -617,10 +646,11 @@ static int v1_launch_step(t2v1_state* s, int step_off, int mode, int slot_hint) 
         gs.out = layer == 0 ? pp(s->X2, s->X1_sz, 0, 0) : single(s->XY, 0);
         gs.xres = pp(X, s->X1_sz, 0, 0);
         gs.u = layer == 0 ? s->u1 : s->u2;
+        gs.y_all = (batched && layer == 1) ? s->y_all : nullptr;
         v1_gru_step(MB, B, st, s->ctl, step_off, hint, gs);
     }
     // 9. mel / stop projections + stop rule (rnn_wrappers.py:105-109, helpers.py:90-94)
-    {
+    if (!batched) {
         SkinnyCore c = v1_core(m->proj, s->ctl, step_off, hint, B);
         c.seg[0][1] = single(s->XY, 0);
         DenseEpi e{};
@@ -630,6 +660,52 @@ static int v1_launch_step(t2v1_state* s, int step_off, int mode, int slot_hint) 
         e.stop_col = M * r; e.out_stop = s->o_stop; e.stop_ld = s->cap; e.stop_t_mul = 1; e.ctl_w = s->ctl;
         launch_dense(MB, dim3(m->proj.n_wg), st, c, e);
     }
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+// Teacher forcing feeds known frames (helpers.py:134-136,182) and nothing of a step's output is fed back: the PreNets of all
+// steps run as two GEMMs over S*B rows before the loop, the projections as one GEMM after it (the same scheme as the V2 path).
+static int v1_teacher_prenets(t2v1_state* s) {
+    t2v1_model* m = s->m;
+    const t2v1_dims& d = m->d;
+    hipStream_t st = m->base.ctx->stream;
+    const int B = s->B, S = s->cap, MB = s->MB, M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame, D = d.decoder_out_units;
+    const long long SB = (long long)S * B;
+    if (!s->tf_buf) {
+        const int pmax = std::max(d.dec_prenet_units[0], d.dec_prenet_units[1]);
+        s->tf_stride = (long long)MB * 16 * pad16(d.dec_prenet_units[1]);
+        const size_t n_xin = align_up((size_t)SB * M * nf, 64), n_x = align_up((size_t)SB * pmax, 64), n_frag = align_up((size_t)S * s->tf_stride, 64),
+                     n_y = align_up((size_t)SB * D, 64), n_p = align_up((size_t)SB * m->proj_plain.cout, 64);
+        hipError_t e = hipMalloc((void**)&s->tf_buf, (n_xin + 2 * n_x + n_frag + n_y + n_p) * 4);
+        if (e != hipSuccess) { s->tf_buf = nullptr; return fail(T2_ENOMEM, "hipMalloc(teacher-forced buffers) failed: %s", hipGetErrorString(e)); }
+        HIP_TRY(hipMemsetAsync(s->tf_buf, 0, (n_xin + 2 * n_x + n_frag) * 4, st));
+        s->tf_xin = s->tf_buf; s->tf_x[0] = s->tf_xin + n_xin; s->tf_x[1] = s->tf_x[0] + n_x; s->tf_frag = s->tf_x[1] + n_x;
+        s->y_all = s->tf_frag + n_frag; s->proj_tmp = s->y_all + n_y;
+    }
+    auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
+    hipLaunchKernelGGL(feed_gather_kernel, grid1(SB * M * nf), dim3(256), 0, st, s->i_targets, s->tf_xin, B, S, M, r, nf);
+    const float* x = s->tf_xin;
+    for (int i = 0; i < 2; ++i) {
+        const ConvLayer& L = m->dec_prenet_plain[i];
+        T2_TRY(launch_conv(&m->base, L, x, L.cin, s->tf_x[i], L.cout, (int)SB, (int)SB, 1, nullptr, 0));
+        if (i == 1)
+            hipLaunchKernelGGL(prenet_dropout_all_kernel, grid1(SB * L.cout), dim3(256), 0, st, s->tf_x[i], s->tf_frag, s->tf_stride, S, B, L.cout, MB,
+                               0.f, 0u, 0);
+        x = s->tf_x[i];
+    }
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+static int v1_teacher_projection(t2v1_state* s) {
+    t2v1_model* m = s->m;
+    const t2v1_dims& d = m->d;
+    const int S = s->cap, B = s->B, Np = m->proj_plain.cout, ncol = d.num_mels * d.outputs_per_step;
+    T2_TRY(launch_conv(&m->base, m->proj_plain, s->y_all, d.decoder_out_units, s->proj_tmp, Np, S * B, S * B, 0, nullptr, 0));
+    const long long n = (long long)S * B * (ncol + 1);
+    hipLaunchKernelGGL(proj_scatter_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))), dim3(256), 0,
+                       m->base.ctx->stream, s->proj_tmp, Np, S, B, ncol, s->o_mel, (long long)s->cap * ncol, s->o_stop, s->cap);
     HIP_TRY(hipGetLastError());
     return T2_OK;
 }
@@ -677,7 +753,10 @@ extern "C" int t2v1_decode_teacher(t2v1_model* m, const float* memory, const int
     T2_TRY(v1_get_state(m, B, T_in, S, &s));
     T2_TRY(v1_state_init(s, memory, lens, S, 0, 0));
     HIP_TRY(hipMemcpyAsync(s->i_targets, targets, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
+    const bool batched = teacher_forcing && m->opt_tfbatch;
+    if (batched) T2_TRY(v1_teacher_prenets(s));
     for (int done = 0; done < S; done += m->opt_chunk) T2_TRY(v1_run_chunk(s, teacher_forcing ? 0 : 1));
+    if (batched) T2_TRY(v1_teacher_projection(s));
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(align, s->o_hist, (size_t)S * B * T_in * 4, hipMemcpyDeviceToDevice, st));

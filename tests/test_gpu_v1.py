@@ -93,6 +93,14 @@ def test_decoder_v1_teacher_and_validation(name, B, T, S, teacher_forcing):
     np.testing.assert_allclose(_np(mel), mel_o, atol=ATOL)
     np.testing.assert_allclose(_np(stop), stop_o, atol=ATOL)
     np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=ATOL)
+    if teacher_forcing:          # the per-step PreNet / projection launches (option tfbatch = 0) give the same frames
+        eng.set_option("tfbatch", 0)
+        mel2, stop2, align2 = eng.decode_teacher(memory, lens, target, teacher_forcing=True)
+        eng.set_option("tfbatch", 1)
+        np.testing.assert_allclose(_np(mel2), mel_o, atol=ATOL)
+        np.testing.assert_allclose(_np(mel2), _np(mel), atol=1e-5)
+        np.testing.assert_allclose(_np(stop2), _np(stop), atol=1e-5)
+        np.testing.assert_allclose(_np(align2), _np(align), atol=1e-6)
 
 
 def _stop_tuned(d, w, memory, lens, lo, hi, min_gap=4e-3):
