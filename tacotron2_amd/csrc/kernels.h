@@ -1781,6 +1781,110 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void gru_step_kernel(SkinnyCore 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Whole-sequence GRU of the CBHG's bidirectional_dynamic_rnn (modules.py:222-229) as ONE persistent launch: a workgroup
+// owns 16 batch rows of one direction and walks all T steps by itself (rows are independent, so no cross-workgroup
+// synchronisation exists).  The recurrent halves of the kernels ([H, 2H] gates, [H, H] candidate; H = 128: 192 KB)
+// stay in REGISTERS for the whole sequence as MFMA B fragments (wave w: gate column tiles 2w, 2w + 1 and candidate
+// tile w = 96 VGPRs); the input halves were applied to all positions beforehand by one GEMM (xz, biases included).
+// h, r*h and u live in LDS.  Per step: gates MFMAs -> sigmoid -> r*h, u -> barrier -> candidate MFMAs -> tanh, blend,
+// sequence-length masking (state copied through, no output past the end), per-row reversed positions for the backward
+// direction -> barrier.  TF GRUCell arithmetic as gru_step_kernel.
+// ------------------------------------------------------------------------------------------------
+struct GruSeqArgs {
+    const float* xz[2];        // per direction [B*T][3H]: x . [Wg_x | Wc_x] + [bg | bc] at every position
+    const float* whg[2];       // [H][2H] recurrent rows of the gates kernel
+    const float* whc[2];       // [H][H] recurrent rows of the candidate kernel
+    const int* lens;           // [B]
+    float* out;                // [B][T][2H]: forward half | backward half
+    int B, T;
+};
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
+    static_assert(H == 128, "register plan below: 8 waves x (2 gate tiles + 1 candidate tile) of 16 columns");
+    constexpr int KS = H / 4, LDH = H + 4;
+    __shared__ float hs[16][LDH];
+    __shared__ float rhs[16][LDH];
+    __shared__ float us[16][H];
+    const int dir = blockIdx.y, row0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kg = lane >> 4, c16 = lane & 15;
+    const float* __restrict__ whg = a.whg[dir];
+    const float* __restrict__ whc = a.whc[dir];
+    const float* __restrict__ xz = a.xz[dir];
+    float wg0[KS], wg1[KS], wc[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + kg;
+        wg0[ks] = whg[(size_t)k * 2 * H + (2 * wave) * 16 + c16];
+        wg1[ks] = whg[(size_t)k * 2 * H + (2 * wave + 1) * 16 + c16];
+        wc[ks] = whc[(size_t)k * H + wave * 16 + c16];
+    }
+    for (int i = threadIdx.x; i < 16 * LDH; i += 512) { (&hs[0][0])[i] = 0.f; (&rhs[0][0])[i] = 0.f; }
+    // this lane's four output rows (D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg)
+    int len4[4];
+    long long base4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = row0 + 4 * kg + r;
+        len4[r] = b < a.B ? a.lens[b] : 0;
+        base4[r] = (long long)min(b, a.B - 1) * a.T;
+    }
+    const int cg0 = (2 * wave) * 16 + c16, cg1 = cg0 + 16, cc = wave * 16 + c16;     // gate columns (r | u), candidate column
+    auto pos_of = [&](int r, int t) { return dir ? len4[r] - 1 - t : t; };
+    float xg0[4], xg1[4], xc[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (t < len4[r]) {
+                const float* p = xz + (size_t)(base4[r] + pos_of(r, t)) * 3 * H;
+                xg0[r] = p[cg0]; xg1[r] = p[cg1]; xc[r] = p[2 * H + cc];
+            } else { xg0[r] = xg1[r] = xc[r] = 0.f; }
+        }
+    };
+    fetch(0);
+    __syncthreads();
+    for (int t = 0; t < a.T; ++t) {
+        // ---- gates: [r | u] = sigmoid(x . Wg_x + bg + h . Wg_h)
+        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float av = hs[c16][4 * ks + kg];
+            g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg0[ks], g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg1[ks], g1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kg + r;
+            const float s0 = sigmoidf_(g0[r] + xg0[r]), s1 = sigmoidf_(g1[r] + xg1[r]);
+            if (cg0 < H) rhs[row][cg0] = s0 * hs[row][cg0]; else us[row][cg0 - H] = s0;
+            if (cg1 < H) rhs[row][cg1] = s1 * hs[row][cg1]; else us[row][cg1 - H] = s1;
+        }
+        __syncthreads();
+        // ---- candidate and blend: c = tanh(x . Wc_x + bc + (r*h) . Wc_h);  h' = u*h + (1 - u)*c
+        f32x4 ca = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(rhs[c16][4 * ks + kg], wc[ks], ca, 0, 0, 0);
+        float hn4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kg + r;
+            const float cand = tanhf(ca[r] + xc[r]);
+            const float u = us[row][cc], hp = hs[row][cc];
+            const bool live = t < len4[r];
+            hn4[r] = live ? u * hp + (1.0f - u) * cand : hp;
+            if (live) a.out[(size_t)(base4[r] + pos_of(r, t)) * 2 * H + dir * H + cc] = hn4[r];
+        }
+        if (t + 1 < a.T) fetch(t + 1);
+        // own columns only: no other wave reads them before the barrier (the gates of step t are done, the blend of the
+        // other waves touches their own columns)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hs[4 * kg + r][cc] = hn4[r];
+        __syncthreads();           // h of step t complete; every wave is past its reads of r*h
+    }
+}
+
 // tf.layers.MaxPooling1D(pool_size=2, strides=1, padding="SAME") (modules.py:182): y[t] = max(x[t], x[t+1]),
 // the last frame of every utterance passes through.  x, y: [B*T][C]
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, long long Mtot, int T, int C) {

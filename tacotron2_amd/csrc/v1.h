@@ -15,6 +15,10 @@ struct CbhgW {
     bool has_adj = false;
     std::vector<ConvLayer> highway;       // one GEMM per layer: [Wh | Wt], shift = [bh | bt]
     GruPacked gru[2];
+    // whole-sequence GRU (gru_seq_kernel, half == 128): input halves of both kernels as one GEMM operand [half][3 half] + biases,
+    // recurrent halves in plain layout
+    ConvLayer gru_x[2];
+    float *gru_hg[2] = {nullptr, nullptr}, *gru_hc[2] = {nullptr, nullptr};
     int cin = 0, out_units = 0, half = 0, C = 0, K = 0, P1 = 0, P2 = 0;
 };
 
@@ -30,6 +34,7 @@ struct t2v1_model {
     Packed dec_prenet[2], query, outproj, proj;
     ConvLayer dec_prenet_plain[2], proj_plain;   // teacher-forced decodes: PreNets and projections of all steps as batched GEMMs
     int opt_tfbatch = 1;
+    int opt_gruseq = 1;                   // CBHG BiGRU of 128 units per direction as one persistent launch (gru_seq_kernel)
     GruPacked att_gru, gru1, gru2;
     float* v_a = nullptr;
     float* zeros = nullptr;               // stands in for the location terms the plain Bahdanau score lacks
@@ -120,8 +125,35 @@ static int v1_make_cbhg(t2_model* b, CbhgW* c, const std::string& p, int cin, in
         T2_TRY(upload(b, &L.shift, sh));
     }
     const char* dirs[2] = {"fw", "bw"};
-    for (int dir = 0; dir < 2; ++dir)
+    for (int dir = 0; dir < 2; ++dir) {
         T2_TRY(v1_pack_gru(b, &c->gru[dir], p + "/bidirectional_rnn/" + dirs[dir] + "/gru_cell", {{0, half}, {half, half}}, 2 * half, half));
+        {
+            const std::string gp = p + "/bidirectional_rnn/" + dirs[dir] + "/gru_cell";
+            const HostWeight *wg, *bg, *wcd, *bc;
+            T2_TRY(get_w(b, gp + "/gates/kernel", &wg, {2 * half, 2 * half}));
+            T2_TRY(get_w(b, gp + "/gates/bias", &bg, {2 * half}));
+            T2_TRY(get_w(b, gp + "/candidate/kernel", &wcd, {2 * half, half}));
+            T2_TRY(get_w(b, gp + "/candidate/bias", &bc, {half}));
+            std::vector<float> wx((size_t)half * 3 * half), bx(3 * half), hg((size_t)half * 2 * half), hc((size_t)half * half);
+            for (int k = 0; k < half; ++k) {
+                for (int n = 0; n < 2 * half; ++n) {
+                    wx[(size_t)k * 3 * half + n] = wg->data[(size_t)k * 2 * half + n];
+                    hg[(size_t)k * 2 * half + n] = wg->data[(size_t)(half + k) * 2 * half + n];
+                }
+                for (int n = 0; n < half; ++n) {
+                    wx[(size_t)k * 3 * half + 2 * half + n] = wcd->data[(size_t)k * half + n];
+                    hc[(size_t)k * half + n] = wcd->data[(size_t)(half + k) * half + n];
+                }
+            }
+            for (int n = 0; n < 2 * half; ++n) bx[n] = bg->data[n];
+            for (int n = 0; n < half; ++n) bx[2 * half + n] = bc->data[n];
+            c->gru_x[dir].k = 1; c->gru_x[dir].cin = half; c->gru_x[dir].cout = 3 * half;
+            T2_TRY(upload(b, &c->gru_x[dir].w, wx));
+            T2_TRY(upload(b, &c->gru_x[dir].shift, bx));
+            T2_TRY(upload(b, &c->gru_hg[dir], hg));
+            T2_TRY(upload(b, &c->gru_hc[dir], hc));
+        }
+    }
     return T2_OK;
 }
 
@@ -158,6 +190,7 @@ extern "C" int t2v1_model_set_option(t2v1_model* m, const char* name, int value)
     if (!m || !name) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "graph")) m->opt_graph = value;
     else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
+    else if (!strcmp(name, "gruseq")) m->opt_gruseq = value;
     else if (!strcmp(name, "tfbatch")) {      // teacher-forced decodes: batched PreNets / projections; states are shaped by it
         if (value != m->opt_tfbatch) {
             HIP_TRY(hipStreamSynchronize(m->base.ctx->stream));
@@ -315,6 +348,7 @@ static size_t cbhg_ws_bytes(const CbhgW& c, int B, int T) {
     cv.take(2 * (size_t)MB * 16 * KPh * 4);                     // r*h
     cv.take(2 * (size_t)MB * 16 * c.half * 4);                  // u
     cv.take(64);                                                // ctl
+    cv.take(2 * Mtot * 3 * c.half * 4);                         // whole-sequence GRU: x-halves at every position, both directions
     return cv.off;
 }
 
@@ -362,6 +396,21 @@ static int cbhg_forward(t2v1_model* m, const CbhgW& c, const float* x, int B, in
         nxt = (cur == hwa) ? hwb : hwa;
     }
     // BiGRU (modules.py:222-229)
+    if (half == 128 && m->opt_gruseq) {
+        // one GEMM per direction for the input halves at every position, then ONE persistent launch for the recurrence
+        float* xz = (float*)(ws + cv.take(2 * (size_t)Mtot * 3 * half * 4));
+        GruSeqArgs ga{};
+        for (int dir = 0; dir < 2; ++dir) {
+            float* xd = xz + (size_t)dir * Mtot * 3 * half;
+            T2_TRY(launch_conv(b, c.gru_x[dir], cur, half, xd, 3 * half, Mtot, Mtot, 0, nullptr, 0));
+            ga.xz[dir] = xd; ga.whg[dir] = c.gru_hg[dir]; ga.whc[dir] = c.gru_hc[dir];
+        }
+        ga.lens = d_lens; ga.out = out; ga.B = B; ga.T = T;
+        HIP_TRY(hipMemsetAsync(out, 0, (size_t)Mtot * c.out_units * 4, st));
+        hipLaunchKernelGGL(gru_seq_kernel<128>, dim3(ceil_div(B, 16), 2), dim3(512), 0, st, ga);
+        HIP_TRY(hipGetLastError());
+        return T2_OK;
+    }
     {
         const long long n = 2LL * T * per_step;
         hipLaunchKernelGGL(seq_to_frag_kernel, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, st,

@@ -55,6 +55,27 @@ def test_encoder_v1(name, B, T, with_lens):
     np.testing.assert_allclose(_np(eng.encode_embedded(emb, lens)), ref, atol=ATOL)
 
 
+@pytest.mark.parametrize("B,T", [(20, 37), (1, 5), (33, 12)])
+def test_cbhg_whole_sequence_gru(B, T):
+    """The CBHG BiGRU of 128 units per direction as one persistent launch (gru_seq_kernel, option gruseq) against the
+    oracle and against the per-step launches, with ragged lengths (state copied through, zero output past the end,
+    per-row reversed positions for the backward direction) and partially filled 16-row tiles."""
+    d, w, eng = _engine("ref")
+    assert d.post_net_cbhg_out_units // 2 == 128
+    rng = np.random.default_rng(B + T)
+    mel = rng.uniform(0, 1, (B, T, d.num_mels)).astype(np.float32)
+    lens = _lens(rng, B, T)
+    ref = V.cbhg(w, "v1/postnet/cbhg", mel, d.post_net_cbhg_out_units, d.post_net_max_filter_width, d.post_net_num_highway, lens, d.bn_eps)
+    got = _np(eng.cbhg(1, mel, lens))
+    np.testing.assert_allclose(got, ref, atol=ATOL)
+    eng.set_option("gruseq", 0)
+    steps = _np(eng.cbhg(1, mel, lens))
+    eng.set_option("gruseq", 1)
+    np.testing.assert_allclose(got, steps, atol=1e-5)
+    for b in range(B):
+        assert not got[b, lens[b]:].any()
+
+
 def test_embedding_range_and_shape_errors():
     from tacotron2_amd._lib import T2Error
     d, w, eng = _engine("tiny")
