@@ -1804,8 +1804,8 @@ template <int H>
 __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
     static_assert(H == 128, "register plan below: 8 waves x (2 gate tiles + 1 candidate tile) of 16 columns");
     constexpr int KS = H / 4, LDH = H + 4;
-    __shared__ float hs[16][LDH];
-    __shared__ float rhs[16][LDH];
+    __shared__ __attribute__((aligned(16))) float hs[16][LDH];
+    __shared__ __attribute__((aligned(16))) float rhs[16][LDH];
     __shared__ float us[16][H];
     const int dir = blockIdx.y, row0 = blockIdx.x * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1814,9 +1814,11 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
     const float* __restrict__ whc = a.whc[dir];
     const float* __restrict__ xz = a.xz[dir];
     float wg0[KS], wg1[KS], wc[KS];
+    // MFMA step ks takes k = 16 (ks / 4) + 4 kg + ks % 4 from lane group kg: a lane's four k of one k-block are contiguous,
+    // so the A operand of four steps is ONE 16-byte LDS read
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const int k = 4 * ks + kg;
+        const int k = 16 * (ks >> 2) + 4 * kg + (ks & 3);
         wg0[ks] = whg[(size_t)k * 2 * H + (2 * wave) * 16 + c16];
         wg1[ks] = whg[(size_t)k * 2 * H + (2 * wave + 1) * 16 + c16];
         wc[ks] = whc[(size_t)k * H + wave * 16 + c16];
@@ -1848,11 +1850,13 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
     for (int t = 0; t < a.T; ++t) {
         // ---- gates: [r | u] = sigmoid(x . Wg_x + bg + h . Wg_h)
         f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 av[KS / 4];
+#pragma unroll
+        for (int kb = 0; kb < KS / 4; ++kb) av[kb] = *reinterpret_cast<const f32x4*>(&hs[c16][16 * kb + 4 * kg]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const float av = hs[c16][4 * ks + kg];
-            g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg0[ks], g0, 0, 0, 0);
-            g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg1[ks], g1, 0, 0, 0);
+            g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][ks & 3], wg0[ks], g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][ks & 3], wg1[ks], g1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1863,9 +1867,15 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
         }
         __syncthreads();
         // ---- candidate and blend: c = tanh(x . Wc_x + bc + (r*h) . Wc_h);  h' = u*h + (1 - u)*c
-        f32x4 ca = {0.f, 0.f, 0.f, 0.f};
+        f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = ca;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(rhs[c16][4 * ks + kg], wc[ks], ca, 0, 0, 0);
+        for (int kb = 0; kb < KS / 4; ++kb) av[kb] = *reinterpret_cast<const f32x4*>(&rhs[c16][16 * kb + 4 * kg]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][ks & 3], wc[ks], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][(ks & 3) + 1], wc[ks + 1], cb, 0, 0, 0);
+        }
+        ca += cb;
         float hn4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
