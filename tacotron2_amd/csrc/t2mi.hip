@@ -3,6 +3,7 @@
 // kernels.h.  No CPU fallback: every entry point runs HIP kernels or fails.
 #include "../../include/t2mi.h"
 #include "kernels.h"
+#include "persist.h"
 
 #include <algorithm>
 #include <cmath>
@@ -118,6 +119,7 @@ struct t2_model {
     int n_cu = 256;                     // compute units of the device (rider capacity of a launch)
     int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
+    int opt_persist = 1;                // free-running decodes of the paper-size dimension class run as ONE persistent launch (persist.h)
 };
 
 struct t2_state {
@@ -146,6 +148,9 @@ struct t2_state {
     unsigned long long* sk_slabs = nullptr;      // split-K partial slabs [tiles][2][512][2]
     int sk_tiles = 0;
     int* ctl = nullptr;
+    // persistent decoder (persist.h): exchange slab and hop counters, carved from the zeroable slab; null when not eligible
+    float* pz_xs = nullptr; unsigned pz_bytes = 0; unsigned* pz_bar = nullptr;
+    unsigned pz_off[13] = {0};
     // output staging (graph-stable addresses)
     float *o_mel = nullptr, *o_stop = nullptr, *o_hist = nullptr, *i_targets = nullptr;
     float *tf_buf = nullptr, *tf_xin = nullptr, *tf_x[2] = {nullptr, nullptr}, *tf_frag = nullptr;   // batched teacher-forced PreNets (lazy)
@@ -404,6 +409,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
         m->opt_lstm_only = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
+    else if (!strcmp(name, "persist")) m->opt_persist = value;
     else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
     else return fail(T2_EINVAL, "unknown option %s", name);
     return T2_OK;
@@ -561,6 +567,10 @@ extern "C" int t2_model_finalize(t2_model* m) {
     HIP_TRY(hipHostMalloc((void**)&m->h_ctl, 8 * sizeof(int), hipHostMallocDefault));
     if (d.attention_filters > 64 || U > 256) return fail(T2_EINVAL, "attention_filters <= 64 and attention_dim <= 256 supported");
     T2_TRY(set_attention_func_attributes());
+    {
+        const void* pk[] = {(const void*)pz::decode_kernel<1>, (const void*)pz::decode_kernel<2>, (const void*)pz::decode_kernel<4>};
+        for (const void* f : pk) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    }
     // the host copies stay: a trainer packs the transposed operands of the backward pass from them
     m->finalized = true;
     return T2_OK;
@@ -904,6 +914,22 @@ static void state_free(t2_state* s) {
     delete s;
 }
 
+// The persistent decoder serves one dimension class (persist.h): the Tacotron2-paper sizes of SURVEY.md section 8d.
+static bool persist_dims_ok(const t2_model* m, int B, int T) {
+    const t2_dims& d = m->d;
+    if (d.num_prenet_layers != 2 || d.prenet_units[0] != pz::KBX * 16 || d.prenet_units[1] != pz::KBX * 16) return false;
+    if (d.enc_units != pz::EW || d.attention_lstm_units != pz::NWG * 4 || d.decoder_lstm_units != pz::NWG * 4) return false;
+    if (d.attention_dim != pz::UA || d.attention_filters > 32 || d.attention_kernel > 32) return false;
+    if (d.num_mels * d.outputs_per_step != 160) return false;
+    if (m->n_cu < pz::NWG || B < 1 || B > 64 || T < 1 || T > 2048) return false;
+    return true;
+}
+static inline int persist_chunks(int B) { int c = 16; while (c > 4 && B * c > pz::NWG) c >>= 1; return c; }
+static inline size_t persist_lds_bytes(int B, int T) {
+    const int C = persist_chunks(B), CH = (T + C - 1) / C, mb = (B + 15) / 16;
+    return (size_t)pz::lds_floats(mb == 3 ? 4 : mb, T, CH) * 4;
+}
+
 static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2_state** out) {
     const t2_dims& d = m->d;
     t2_state* s = new t2_state();
@@ -939,6 +965,23 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
                  o_Z2 = carve((size_t)m->lstm2.n_wg * MB * 256 * 4), o_Z1x = carve((size_t)m->lstm1.n_wg * MB * 256 * 4);
     size_t o_xp[T2_MAX_PRENET_LAYERS];
     for (int i = 0; i < d.num_prenet_layers; ++i) o_xp[i] = carve((size_t)R * pad16(d.prenet_units[i]) * 4);
+    const bool pz_ok = persist_dims_ok(m, B, T) && persist_lds_bytes(B, T) <= 150 * 1024;
+    size_t o_pz = 0, o_pzbar = 0, pz_total = 0;
+    if (pz_ok) {
+        auto pcarve = [&](size_t bytes) { size_t o = pz_total; pz_total = align_up(pz_total + bytes, 256); return (unsigned)o; };
+        const size_t h = (size_t)R * 1024 * 4, x = (size_t)R * 256 * 4;
+        s->pz_off[0] = pcarve(x); s->pz_off[1] = pcarve(x);                       // X1, X2
+        s->pz_off[2] = pcarve(h); s->pz_off[3] = pcarve(h);                       // h_att raw, h_att state
+        s->pz_off[4] = pcarve((size_t)R * 512 * 4);                               // context
+        s->pz_off[5] = pcarve(h); s->pz_off[6] = pcarve(h);                       // y1 raw, h1 state
+        s->pz_off[7] = pcarve(h); s->pz_off[8] = pcarve(h);                       // y2 raw, h2 state
+        s->pz_off[9] = pcarve((size_t)pz::NWG * R * pz::UA * 4);                  // partial processed queries
+        s->pz_off[10] = pcarve((size_t)B * T * 4);                                // energies
+        s->pz_off[11] = pcarve(2 * (size_t)B * T * 4);                            // attention state, two step parities
+        s->pz_off[12] = pcarve(256);                                              // stop logits
+        o_pz = carve(pz_total);
+        o_pzbar = carve((size_t)(pz::NSHARD + 64) * 32 * 4);
+    }
     s->slab_bytes = off;
     e1 = hipMalloc(&s->slab, off);
     if (e1 != hipSuccess) { state_free(s); return fail(T2_ENOMEM, "hipMalloc(state slab) failed: %s", hipGetErrorString(e1)); }
@@ -952,6 +995,7 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
     s->ZA = (float*)(p + o_ZA); s->Z1 = (float*)(p + o_Z1); s->Z2 = (float*)(p + o_Z2); s->Z1x = (float*)(p + o_Z1x);
     s->tickets = (unsigned*)(p + o_tk); s->sk_slabs = (unsigned long long*)(p + o_sk);
     for (int i = 0; i < d.num_prenet_layers; ++i) s->xp[i] = (float*)(p + o_xp[i]);
+    if (pz_ok) { s->pz_xs = (float*)(p + o_pz); s->pz_bytes = (unsigned)pz_total; s->pz_bar = (unsigned*)(p + o_pzbar); }
     // output staging
     off = 0;
     const size_t o_mel = carve((size_t)B * cap * r * M * 4), o_stop = carve((size_t)B * cap * 4);
@@ -1495,6 +1539,48 @@ static int run_chunk(t2_state* s, int mode) {
     return T2_OK;
 }
 
+// Free-running decode (the helper feeds the model's own output back: helpers.py:86, :135-136) as ONE persistent launch.
+static inline bool persist_mode(const t2_state* s) {
+    const t2_model* m = s->m;
+    return m->opt_persist && s->pz_xs != nullptr && m->proj_fused_ok && m->opt_projfuse && !m->opt_lstm_only;
+}
+static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en) {
+    t2_model* m = s->m;
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    pz::PArgs a{};
+    a.wA = m->att_lstm.w; a.bA = m->att_lstm.bias; a.w1 = m->lstm1.w; a.b1 = m->lstm1.bias; a.w2 = m->lstm2.w; a.b2 = m->lstm2.bias;
+    a.wP = m->proj_fused.w; a.bP = m->proj_fused.bias; a.wN = m->prenet[1].w; a.bN = m->prenet[1].bias;
+    a.wq = m->wq; a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
+    a.keys = s->keys; a.values = s->values; a.lens = s->lens;
+    a.xs = s->pz_xs; a.xs_bytes = s->pz_bytes;
+    a.oX1 = s->pz_off[0]; a.oX2 = s->pz_off[1]; a.oHAr = s->pz_off[2]; a.oHA = s->pz_off[3]; a.oCTX = s->pz_off[4];
+    a.oY1 = s->pz_off[5]; a.oH1 = s->pz_off[6]; a.oY2 = s->pz_off[7]; a.oH2 = s->pz_off[8]; a.oQP = s->pz_off[9];
+    a.oEN = s->pz_off[10]; a.oCUM = s->pz_off[11]; a.oSTOP = s->pz_off[12];
+    a.bar = s->pz_bar; a.ctl = s->ctl;
+    const int M = d.num_mels, r = d.outputs_per_step;
+    a.mel = s->o_mel; a.mel_ld = (long long)s->cap * r * M; a.mel_ts = (long long)r * M;
+    a.stop = s->o_stop; a.stop_ld = s->cap; a.hist = s->o_hist;
+    a.B = s->B; a.T = s->T; a.C = persist_chunks(s->B); a.CH = (s->T + a.C - 1) / a.C;
+    a.F = d.attention_filters; a.KA = d.attention_kernel; a.MR = M * r;
+    a.max_steps = max_steps; a.min_iters = min_iters; a.stop_en = stop_en; a.cumulative = d.cumulative_weights;
+    a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
+    if (m->att_lstm.n_wg != pz::NWG || m->att_lstm.kbtot != pz::KBX + pz::KBE + pz::KBH || m->lstm1.kbtot != 2 * pz::KBH + pz::KBE ||
+        m->lstm2.kbtot != 2 * pz::KBH || m->proj_fused.n_wg != 28 || m->proj_fused.kbtot != pz::KBH || m->prenet[1].n_wg != 16 ||
+        m->prenet[1].kbtot != pz::KBX)
+        return fail(T2_ESTATE, "internal: packed operands do not have the persistent decoder's geometry");
+    // x1 of step 0 = relu(bias of the first PreNet layer): the go frame is zeros (helpers.py:187-188)
+    hipLaunchKernelGGL(pz::init_x1_kernel, dim3(ceil_div(s->B * d.prenet_units[0], 256)), dim3(256), 0, st, s->pz_xs + a.oX1 / 4,
+                       m->prenet[0].bias, s->B, s->MB, d.prenet_units[0]);
+    const size_t lds = persist_lds_bytes(s->B, s->T);
+    const dim3 grid(pz::NWG), blk(pz::NT);
+    if (s->MB == 1) hipLaunchKernelGGL(pz::decode_kernel<1>, grid, blk, lds, st, a);
+    else if (s->MB == 2) hipLaunchKernelGGL(pz::decode_kernel<2>, grid, blk, lds, st, a);
+    else hipLaunchKernelGGL(pz::decode_kernel<4>, grid, blk, lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
 extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t* lens, const float* targets,
                                  int B, int T_in, int T_out, int teacher_forcing,
                                  float* mel, float* stop, float* align) {
@@ -1515,9 +1601,11 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     const int mode = teacher_forcing ? 0 : 1;
     if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
     if (teacher_forcing && m->opt_tfproj) T2_TRY(teacher_projection_buffers(s, true));
-    T2_TRY(decode_prologue(s, mode));
-    const bool deferred = loop_io(s, mode).defer_proj != 0;
-    for (int done = 0; done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
+    const bool persist = !teacher_forcing && persist_mode(s);
+    if (persist) T2_TRY(persist_decode(s, S, 0, 0));
+    else T2_TRY(decode_prologue(s, mode));
+    const bool deferred = !persist && loop_io(s, mode).defer_proj != 0;
+    for (int done = 0; !persist && done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
     if (deferred) T2_TRY(teacher_projection(s, s->y_all, s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
@@ -1557,6 +1645,7 @@ static int read_steps(t2_state* s, int* steps_out) {
     HIP_TRY(hipMemcpyAsync(h, s->ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *steps_out = h[CTL_FINAL] != 0 ? h[CTL_FINAL] : h[CTL_MAX];
+    if (h[5] != 0 || h[6] != 0) return fail(T2_EHIP, "persistent decoder: a hop timed out (workgroups not co-resident?); outputs are invalid");
     return T2_OK;
 }
 
@@ -1564,8 +1653,11 @@ extern "C" int t2_decode_free_launch(t2_model* m, const float* memory, const int
                                      int max_iters, int min_iters, float* mel, float* stop, float* align) {
     t2_state* s = nullptr;
     T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
-    T2_TRY(decode_prologue(s, 1));
-    for (int done = 0; done < max_iters; done += m->opt_chunk) T2_TRY(run_chunk(s, 1));
+    if (persist_mode(s)) T2_TRY(persist_decode(s, max_iters, min_iters, 1));
+    else {
+        T2_TRY(decode_prologue(s, 1));
+        for (int done = 0; done < max_iters; done += m->opt_chunk) T2_TRY(run_chunk(s, 1));
+    }
     T2_TRY(free_copy_out(s, mel, stop, align));
     m->pending = s;
     return T2_OK;
@@ -1584,6 +1676,11 @@ extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* l
     if (!steps_out) return fail(T2_EINVAL, "steps_out is null");
     t2_state* s = nullptr;
     T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
+    if (persist_mode(s)) {
+        T2_TRY(persist_decode(s, max_iters, min_iters, 1));
+        T2_TRY(free_copy_out(s, mel, stop, align));
+        return read_steps(s, steps_out);
+    }
     hipStream_t st = m->ctx->stream;
     // chunks are enqueued two ahead of the host's view of the finished flag: chunks after the stop
     // step are no-ops on the device, so over-enqueueing is harmless and the host never stalls the GPU.

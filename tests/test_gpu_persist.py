@@ -1,0 +1,126 @@
+"""The persistent decoder (csrc/persist.h: the whole free-running dynamic_decode loop as ONE launch, paper-size
+dimension class) against the oracle and against the launch-per-phase schedule it replaces."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import t2_oracle as O
+from tacotron2_amd.hparams import PROFILE_P
+from tacotron2_amd.weights import init_weights
+
+
+@pytest.fixture(scope="module")
+def paper():
+    from tacotron2_amd.engine import Engine
+    d = PROFILE_P
+    w = init_weights(d, seed=91, perturb=True)
+    eng = Engine(d, w)
+    rng = np.random.default_rng(65)
+    B = 64
+    lens = rng.integers(60, 141, size=B).astype(np.int64)
+    lens[2] = 140
+    T = int(lens.max())
+    ids = np.zeros((B, T), np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(32, 91, size=n)
+    memory_o = O.encoder_v2(d, w, O.embedding_lookup(ids, w["embedding"]), lens)
+    yield d, w, eng, memory_o, lens
+    eng.close()
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("B", [1, 5, 16, 20, 33, 64])
+def test_persistent_free_run_against_oracle(paper, B):
+    """1, 2 and 4 row blocks, every attention split (16, 8, 4 workgroups per row), ragged lengths."""
+    d, w, eng, memory_o, lens = paper
+    eng.set_option("persist", 1)
+    S = 7
+    T = int(lens[:B].max())
+    mem = memory_o[:B, :T]
+    mel_o, stop_o, st = O.decoder_v2(d.replace(min_iters=100), w, mem, memory_sequence_length=lens[:B], max_iters=S)
+    mel, stop, align, n = eng.decode_free(mem, lens[:B], max_iters=S, min_iters=100)
+    assert n == S
+    np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
+    np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
+    np.testing.assert_allclose(_np(stop), stop_o, atol=2e-4)
+
+
+@pytest.mark.parametrize("B", [1, 64])
+def test_persistent_equals_launch_schedule(paper, B):
+    """Same decode, 48 free-running steps, one persistent launch against six launches per step."""
+    d, w, eng, memory_o, lens = paper
+    S = 48
+    T = int(lens[:B].max())
+    mem = memory_o[:B, :T]
+    eng.set_option("persist", 0)
+    mel0, stop0, align0, n0 = eng.decode_free(mem, lens[:B], max_iters=S, min_iters=100)
+    mel0, stop0, align0 = _np(mel0).copy(), _np(stop0).copy(), _np(align0).copy()
+    eng.set_option("persist", 1)
+    mel1, stop1, align1, n1 = eng.decode_free(mem, lens[:B], max_iters=S, min_iters=100)
+    assert n0 == n1 == S
+    np.testing.assert_allclose(_np(mel1), mel0, atol=1e-4)
+    np.testing.assert_allclose(_np(stop1), stop0, atol=1e-4)
+    np.testing.assert_allclose(_np(align1), align0, atol=1e-5)
+
+
+@pytest.mark.parametrize("B", [1, 64])
+def test_persistent_stop_index_at_paper_sizes(paper, B):
+    """SURVEY.md 8c fixture (4) at paper sizes: the batch-coupled stop rule (helpers.py:90-94) fires mid-sequence; the step
+    count must equal the oracle's, with every row's decision clear of the tolerance around the crossing."""
+    from tacotron2_amd.engine import Engine
+    d, w, _, memory_o, lens = paper
+    T = int(lens[:B].max())
+    mem = memory_o[:B, :T]
+    # a stop projection that reads the decoder's drift: find a bias that makes the oracle stop between steps 13 and 20
+    # the random-init stop logit drifts by ~5e-3 per step: scale the stop projection so that consecutive decisions differ by ~0.1
+    w = dict(w)
+    w["decoder/stop_token_projection/kernel"] = (w["decoder/stop_token_projection/kernel"] * 25.0).astype(np.float32)
+    mel_o, stop_o, _ = O.decoder_v2(d.replace(min_iters=100), w, mem, memory_sequence_length=lens[:B], max_iters=24)
+    logits = stop_o[..., 0]                                              # [B, S]; the stop logit is never fed back
+    # the rule looks at min over rows; pick the first step k > 12 whose row-minimum is a record high by a clear margin and
+    # shift the bias to the middle of the gap: every earlier decision is "no" and the one at k is "yes" by >= 1e-2
+    mrow = logits.min(axis=0)
+    k, shift = None, 0.0
+    for kk in range(15, 24):
+        prev = float(mrow[11:kk].max())
+        if float(mrow[kk]) - prev > 0.03:
+            k, shift = kk, -(float(mrow[kk]) + prev) / 2
+            break
+    assert k is not None, "no usable crossing in this trajectory"
+    w2 = dict(w)
+    w2["decoder/stop_token_projection/bias"] = (w["decoder/stop_token_projection/bias"] + shift).astype(np.float32)
+    mel_r, stop_r, _ = O.decoder_v2(d, w2, mem, memory_sequence_length=lens[:B], max_iters=24)
+    steps_o = mel_r.shape[1] // d.outputs_per_step
+    assert steps_o == k + 1
+    m2 = stop_r[..., 0].min(axis=0)
+    assert float(m2[k]) > 1e-2 and float(m2[11:k].max()) < -1e-2, "fixture too close to the decision boundary"
+    eng2 = Engine(d, w2)
+    try:
+        for persist in (1, 0):
+            eng2.set_option("persist", persist)
+            mel, stop, align, n = eng2.decode_free(mem, lens[:B], max_iters=24)
+            assert n == steps_o, (persist, n, steps_o)
+            np.testing.assert_allclose(_np(mel), mel_r, atol=1e-3)
+            np.testing.assert_allclose(_np(stop), stop_r, atol=1e-3)
+    finally:
+        eng2.close()
+
+
+def test_persistent_validation_free_run(paper):
+    """ValidationHelper(teacher_forcing=False) (helpers.py:131-138): fixed step count, own output fed back."""
+    d, w, eng, memory_o, lens = paper
+    B, S = 9, 6
+    T = int(lens[:B].max())
+    mem = memory_o[:B, :T]
+    target = np.zeros((B, S * d.outputs_per_step, d.num_mels), np.float32)
+    eng.set_option("persist", 1)
+    mel, stop, align = eng.decode_teacher(mem, lens[:B], target, teacher_forcing=False)
+    mel_o, stop_o, st = O.decoder_v2(d, w, mem, is_validation=True, teacher_forcing=False, memory_sequence_length=lens[:B],
+                                     target=target, max_iters=S)
+    np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
+    np.testing.assert_allclose(_np(stop), stop_o, atol=2e-4)
+    np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
