@@ -119,6 +119,7 @@ struct t2_model {
     int n_cu = 256;                     // compute units of the device (rider capacity of a launch)
     int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
+    long long n_persist = 0;            // persistent decodes launched (stat "persist_launches")
     int opt_persist = 1;                // free-running decodes of the paper-size dimension class run as ONE persistent launch (persist.h)
 };
 
@@ -1578,6 +1579,7 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     else if (s->MB == 2) hipLaunchKernelGGL(pz::decode_kernel<2>, grid, blk, lds, st, a);
     else hipLaunchKernelGGL(pz::decode_kernel<4>, grid, blk, lds, st, a);
     HIP_TRY(hipGetLastError());
+    ++m->n_persist;
     return T2_OK;
 }
 
@@ -1710,6 +1712,7 @@ extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* l
 
 extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
     if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
+    if (!strcmp(name, "persist_launches")) { *out = (double)m->n_persist; return T2_OK; }
     if (!strcmp(name, "lstm_launches")) { *out = (double)(g_timer.used / 2); return T2_OK; }
     if (!strcmp(name, "lstm_ms")) {
         HIP_TRY(hipStreamSynchronize(m->ctx->stream));

@@ -42,7 +42,9 @@ def test_persistent_free_run_against_oracle(paper, B):
     T = int(lens[:B].max())
     mem = memory_o[:B, :T]
     mel_o, stop_o, st = O.decoder_v2(d.replace(min_iters=100), w, mem, memory_sequence_length=lens[:B], max_iters=S)
+    before = eng.get_stat("persist_launches")
     mel, stop, align, n = eng.decode_free(mem, lens[:B], max_iters=S, min_iters=100)
+    assert eng.get_stat("persist_launches") == before + 1, "the persistent kernel did not run"
     assert n == S
     np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
     np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
