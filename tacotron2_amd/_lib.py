@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2mi.so")
+LIB_PATH = os.environ.get("T2MI_LIB") or os.path.join(_HERE, "libt2mi.so")     # T2MI_LIB: diagnostic builds (tools/)
 
 T2_OK, T2_EINVAL, T2_ENOMEM, T2_EHIP, T2_ESTATE, T2_ERANGE = 0, -1, -2, -3, -4, -5
 T2_MAX_BATCH = 64

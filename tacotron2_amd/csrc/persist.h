@@ -49,13 +49,14 @@ struct PArgs {
     const float *wA, *bA, *w1, *b1, *w2, *b2;   // packed LSTM slabs [256][kbtot][64][4] (pack_skinny), biases [256][16]
     const float *wP, *bP;                       // projection + composed first PreNet layer: [28][64][64][4], bias [448]
     const float *wN, *bN;                       // last PreNet layer: [16][16][64][4], bias [256]
-    const float *wq, *conv_w, *conv_b, *wloc, *v_a, *b_a;
+    const float *wQ;                            // query layer packed like a dense layer: [8 column tiles][64][64][4]
+    const float *conv_w, *conv_b, *wloc, *v_a, *b_a;
     const float *keys, *values;                 // [B][T][128], [B][T][512]
     const int* lens;
     float* xs;                                  // exchange slab (zeroed before the launch)
     unsigned xs_bytes;
     unsigned oX1, oX2, oHAr, oHA, oCTX, oY1, oH1, oY2, oH2, oQP, oEN, oCUM, oSTOP;   // byte offsets into xs
-    unsigned* bar;                              // [NSHARD][32] hop counters, then [64][32] attention group counters (zeroed)
+    unsigned* bar;                              // [NSHARD][32] hop counters, [64][32] attention row groups, [4][32] + [4][32] row-block groups (zeroed)
     int* ctl;
     float *mel, *stop, *hist;
     long long mel_ld, mel_ts;
@@ -67,7 +68,7 @@ struct PArgs {
 __host__ __device__ inline int lds_floats(int MB, int T, int CH) {
     const int CHP = (CH + 15) & ~15, TP = (T + 3) & ~3;
     const int red = NWAVE * MB * 64 * 4;
-    return red + MB * 64 + 32 * 32 + 32 + (CHP + 32) + CHP * 36 + 16 * UA + UA + NWAVE * CHP + 2 * TP + 2048 + 64 + 16 * 16 + 16 + 64;
+    return red + MB * 64 + 32 * 32 + 32 + (CHP + 48) + CHP * 36 + 16 * UA + UA + NWAVE * CHP + (NWAVE + 1) * TP + 2048 + 64 + 16 * 16 + 16 + 64;
 }
 
 // ---- exchange-slab accessors: write-through stores, L1-bypassing loads ----
@@ -91,20 +92,25 @@ __device__ __forceinline__ void hop_arrive(unsigned* bar) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(bar + (blockIdx.x & (NSHARD - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wait: wave 0 polls the NSHARD shards (one lane each) until each has seen `per_shard` arrivals.  Returns false on
-// timeout or when another wait of this workgroup already failed (s_abort).
-__device__ __forceinline__ bool hop_wait(unsigned* bar, unsigned per_shard, int* s_abort) {
+// peek: issue the shard loads early (in the middle of gap work) so that their latency is hidden; the value goes to hop_wait
+__device__ __forceinline__ unsigned hop_peek(unsigned* bar) {
+    unsigned v = 0u;
+    if (threadIdx.x < NSHARD) v = __hip_atomic_load(bar + threadIdx.x * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+// wait: wave 0 polls the NSHARD shards (one lane each) until each has seen `per_shard` arrivals; the first check uses the
+// peeked values.  Returns false on timeout or when another wait of this workgroup already failed (s_abort).
+__device__ __forceinline__ bool hop_wait(unsigned* bar, unsigned per_shard, int* s_abort, unsigned peek = 0u) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        bool ok = false, bad = false;
+        bool bad = false;
+        unsigned v = lane < NSHARD ? peek : per_shard;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
-            unsigned v = per_shard;
-            if (lane < NSHARD) v = __hip_atomic_load(bar + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = __all((int)(v - per_shard) >= 0);
-            if (ok) break;
+            if (__all((int)(v - per_shard) >= 0)) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { bad = true; break; }
             __builtin_amdgcn_s_sleep(1);
+            if (lane < NSHARD) v = __hip_atomic_load(bar + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (bad && lane == 0) *s_abort = 1;
     }
@@ -200,6 +206,15 @@ __device__ __forceinline__ unsigned frag_off16(int row, int q4, int MB) {
     return (unsigned)((((kb * MB + (row >> 4)) * 64) + kg * 16 + (row & 15)) * 16);
 }
 
+// Diagnostic builds only (-DPZ_STAMPS, tools/persist_stamps.py): thread 0 of every workgroup sums the wall-clock time
+// (s_memrealtime, 10 ns ticks) between consecutive stamp points over all steps; the product build has no stamps.
+#ifdef PZ_STAMPS
+__device__ unsigned long long g_pz_stamps[NWG][24];
+#define PZ_STAMP(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += now_ - st_prev; st_prev = now_; } } while (0)
+#else
+#define PZ_STAMP(i) do { } while (0)
+#endif
+
 template <int MB>
 __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -216,12 +231,12 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     float* s_cw = s_h + MB * 64;                                 // [32 taps][32 filters]
     float* s_cb = s_cw + 32 * 32;                                // [32]
     float* s_cum = s_cb + 32;                                    // [CHP + 32]
-    float* s_f = s_cum + CHP + 32;                               // [CHP][36]
+    float* s_f = s_cum + CHP + 48;                               // [CHP][36]
     float* s_qp = s_f + CHP * 36;                                // [16][128]
     float* s_q = s_qp + 16 * UA;                                 // [128]
     float* s_ep = s_q + UA;                                      // [8][CHP]
-    float* s_e = s_ep + NWAVE * CHP;                             // [TP]
-    float* s_a = s_e + TP;                                       // [TP]
+    float* s_e = s_ep + NWAVE * CHP;                             // [8][TP]: every wave's copy of the energies
+    float* s_a = s_e + NWAVE * TP;                               // [TP]
     float* s_cx = s_a + TP;                                      // [2048]
     float* s_rw = s_cx + 2048;                                   // [64]
     float* s_tile = s_rw + 64;                                   // [16][16]
@@ -229,7 +244,8 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     float* s_bias = s_tile + 256 + 16;                           // [3][16] gate biases of this workgroup's units
 
     const rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(a.xs, 0, (int)a.xs_bytes, 0x00020000);
-    unsigned* grp = a.bar + NSHARD * 32;
+    unsigned* grp = a.bar + NSHARD * 32;                          // [64] attention row groups
+    unsigned* grpx = grp + 64 * 32;                                // [4] row-block groups: projection tiles -> last PreNet layer
 
     // ---- roles ----
     const bool isAtt = wg < B * C;
@@ -241,6 +257,12 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     const int jN = NWG - 1 - 27 * MB - wg;                        // last-PreNet tile job (16 column tiles x MB row blocks)
     const bool isN = jN >= 0 && jN < 16 * MB;
     const int ntile = isN ? jN / MB : 0, nrb = isN ? jN - ntile * MB : 0;
+
+    constexpr int KSQ = 8;                                        // K splits of the query layer product
+    const bool isQ = wg < 8 * KSQ * MB;                           // query tile job: column tile, K split, row block
+    const int qct = wg & 7, qks = (wg >> 3) & (KSQ - 1), qrb = wg >> 6;
+    unsigned long long* qgr = reinterpret_cast<unsigned long long*>(a.xs + a.oQP / 4);     // [8 K splits][rows][128] query partial granules
+    const rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wQ), 0, 8 * KBH * 1024, 0x00020000);
 
     // ---- one-time set-up ----
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
@@ -318,15 +340,101 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         if (eown && euu == 0) st16(xs, off_buf + frag_off16(erow, wg, MB), q);
     };
 
+#ifdef PZ_STAMPS
+    unsigned long long st_acc[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) st_acc[i] = 0;
+    unsigned long long st_prev = __builtin_amdgcn_s_memrealtime();
+#endif
     unsigned epoch = 0;        // hops completed so far (identical in every workgroup)
     int t = 0, final_steps = 0;
     bool alive = true;
+    // attention pre-work of the NEXT step, done in a gap: everything of the energies that does not need the query.
+    // pre[r][g] = keys[p][u] + (f . W_loc)[p][u] for this lane's (position 16 r + 4 kg + g of the chunk, unit 16 wave + c16)
+    float pre[4][4];
+    const int att_p0 = ac * CH;
+    const int att_n = isAtt ? max(0, min(CH, T - att_p0)) : 0;
+    const int att_pl = (a.KA - 1) >> 1;
+    auto attention_pre = [&](int tt) {
+        // previous (cumulative) alignments of this chunk with the conv halo: s_cum[i] <-> position p0 - pad_l + i
+        const unsigned cum_prev = a.oCUM + (unsigned)(((tt + 1) & 1) * B * T * 4);
+        for (int i = tid; i < CHP + 48; i += NT) {
+            const int p = att_p0 - att_pl + i;
+            float v = 0.f;
+            if (tt > 0 && p >= 0 && p < T && i < att_n + a.KA - 1) v = ld4(xs, cum_prev + (unsigned)((ab * T + p) * 4));
+            s_cum[i] = v;
+        }
+        const int NRT = (att_n + 15) >> 4;
+        const float* keys_b = a.keys + (size_t)ab * T * UA + wave * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int p = min(att_p0 + 16 * r + 4 * kg + g, T - 1);
+                pre[r][g] = r < NRT ? keys_b[(size_t)p * UA] : 0.f;
+            }
+        __syncthreads();
+        // location features f[p][c] = sum_j w[j][c] cum[p + j - pad_l] + b[c]   (tacotron_v2.py:128-130): one thread = one
+        // filter x four positions, the 32 (zero-padded) taps unrolled over a register window
+        {
+            const int f = tid & 31, pq = tid >> 5;
+            if (4 * pq < CHP) {
+                float win[36];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_cum + 4 * pq + 4 * i);
+                    win[4 * i] = w4[0]; win[4 * i + 1] = w4[1]; win[4 * i + 2] = w4[2]; win[4 * i + 3] = w4[3];
+                }
+                const float cb = s_cb[f];
+                float acc[4] = {cb, cb, cb, cb};
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const float wj = s_cw[j * 32 + f];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(wj, win[i + j], acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_f[(4 * pq + i) * 36 + f] = (4 * pq + i < att_n) ? acc[i] : 0.f;
+            }
+        }
+        __syncthreads();
+        // processed location features on the matrix pipe (tacotron_v2.py:131): [16 positions x 32 filters] . [32 x 16 units]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < NRT) {
+                f32x4 pf = {0.f, 0.f, 0.f, 0.f};
+                const float* fr = s_f + (16 * r + c16) * 36 + 4 * kg;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(fr), a1 = *reinterpret_cast<const f32x4*>(fr + 16);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], wlB[s], pf, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], wlB[4 + s], pf, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[r][g] += pf[g];
+            }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[r][g] = 0.f;
+
     for (; t < a.max_steps; ++t) {
         fresh();
+        // gap work of the P5 -> P6 chain: the query-independent part of this step's attention.  The owners of a last-PreNet
+        // tile do it BEFORE their tile (they are waiting for the projection tiles anyway), everybody else after arriving.
+        auto gap6 = [&]() {
+            if (isAtt) attention_pre(t);
+        };
         // ================= P6: last PreNet layer  x2 = relu(x1 . Wn + bn)   (modules.py:88-91) =================
         if (isN) {
+            gap6(); fresh();
             f32x4 b[2];
             wload<2>(b, rN, (unsigned)((ntile * KBX + wave * 2) * 1024), l16);
+            const float bias_n = a.bN[ntile * 16 + (tid & 15)];
+            // x1 of this row block comes from the 16 projection tiles of the previous step (row-block group hop)
+            if (t > 0 && !word_wait(grpx + nrb * 32, 16u * (unsigned)t, s_flag)) { alive = false; break; }
+            fresh();
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             tile_mma<2>(acc, b, xs, a.oX1 + (unsigned)((wave * 2 * MB + nrb) * 1024), MB, l16);
             red[wave * 64 + lane] = acc;
@@ -337,7 +445,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < NWAVE; ++w) s += red[w * 64 + sl][reg];
-                s_tile[r16 * 16 + c] = fmaxf(s + a.bN[ntile * 16 + c], 0.f);
+                s_tile[r16 * 16 + c] = fmaxf(s + bias_n, 0.f);
             }
             __syncthreads();
             if (tid < 64) {
@@ -345,144 +453,129 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
                 if (row < B) st16(xs, a.oX2 + frag_off16(row, ntile * 4 + q, MB), *reinterpret_cast<const f32x4*>(s_tile + r16 * 16 + q * 4));
             }
         }
-        hop_arrive(a.bar); ++epoch; fresh();
+        PZ_STAMP(0); hop_arrive(a.bar); ++epoch; fresh();
+        if (!isN) { gap6(); fresh(); }
         // critical weights of P1 (the PreNet rows of the attention LSTM kernel) while the hop completes
         f32x4 bx[2];
         wload<2>(bx, rA, slabA + (unsigned)(wave * 2 * 1024), l16);
+        PZ_STAMP(1);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
+        fresh(); PZ_STAMP(2);
+        // ---- stop rule of StopTokenBasedInferenceHelper (helpers.py:90-94) for the step just finished: every row says stop
+        //      and time > min_iters; the finishing step's outputs are kept, so the decode emits t steps.  Every workgroup
+        //      evaluates it on the same published logits (stored before their owner arrived at this hop), so all of them
+        //      leave the loop together.
+        if (t > 0) {
+            if (tid < 64) {
+                const float v = lane < B ? ld4(xs, a.oSTOP + (unsigned)(lane * 4)) : 1.0f;
+                const bool all_stop = __all(v > 0.f);
+                if (lane == 0) s_flag[1] = (a.stop_en && all_stop && t - 1 > a.min_iters) ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_flag[1]) { final_steps = t; break; }
+        }
 
         // ================= P1: attention LSTM (AttentionWrapper cell call, App. A6)  =================
         seg_mma<MB, 2>(accA, bx, xs, a.oX2 + (unsigned)(wave * 2 * MB * 1024), l16);
         put_red(accA);
         __syncthreads();
-        {
-            float hn = 0.f;
-            if (tid < MB * 64) {
-                float z[4];
-                gate4(z);
-                hn = cell(z, s_bias, cA, hA);
-                publish4(hn, a.oHAr);
-                publish4(hA, a.oHA);
-                s_h[tid] = eown ? hn : 0.f;
-            }
+        if (tid < MB * 64) {
+            float z[4];
+            gate4(z);
+            const float hn = cell(z, s_bias, cA, hA);
+            publish4(hn, a.oHAr);
+            publish4(hA, a.oHA);
+        }
 #pragma unroll
-            for (int rb = 0; rb < MB; ++rb) accA[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rb = 0; rb < MB; ++rb) accA[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        PZ_STAMP(3); hop_arrive(a.bar); ++epoch; fresh();
+        // gap: first half of LSTM 2's recurrent K range (h2 of the previous step)
+        if (t > 0) {
+            f32x4 b[4];
+            wload<4>(b, r2, slab2 + (unsigned)((KBH + wave * 8) * 1024), l16);
+            seg_mma<MB, 4>(acc2, b, xs, a.oH2 + (unsigned)(wave * 8 * MB * 1024), l16);
+        }
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (isQ) bq = ldw(rQ, l16, (unsigned)((qct * KBH + qks * 8 + wave) * 1024));
+        PZ_STAMP(4);
+        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+        fresh(); PZ_STAMP(5);
+
+        // ================= P2a: processed query (tacotron_v2.py:122) as 8 column tiles x 8 K splits per row block =================
+        if (isQ) {
+            const f32x4 av = ldx(xs, l16, a.oHAr + (unsigned)(((qks * 8 + wave) * MB + qrb) * 1024));
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[j], acc, 0, 0, 0);
+            red[wave * 64 + lane] = acc;
             __syncthreads();
-            // this workgroup's share of the processed query (tacotron_v2.py:122): qpart[wg][row][u] = sum_uu h[row][uu] wq[4 wg + uu][u]
-            const int u4 = tid & 31, r16 = tid >> 5;
-            f32x4 wqv[4];
+            // partial tile -> tagged 8-byte granules {value, tag = step + 1}: the data is the flag (no drain, no counter)
+            if (tid < 256) {
+                const int r16 = tid >> 4, c = tid & 15;
+                const int sl = (r16 >> 2) * 16 + c, reg = r16 & 3;
+                float sacc = 0.f;
 #pragma unroll
-            for (int uu = 0; uu < 4; ++uu) wqv[uu] = *reinterpret_cast<const f32x4*>(a.wq + (size_t)(wg * 4 + uu) * UA + u4 * 4);
-#pragma unroll
-            for (int ps = 0; ps < MB; ++ps) {
-                const int row = ps * 16 + r16;
-                if (row < B) {
-                    f32x4 q = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int uu = 0; uu < 4; ++uu) q += s_h[row * 4 + uu] * wqv[uu];
-                    st16(xs, a.oQP + (unsigned)((((wg * MB * 16) + row) * UA + u4 * 4) * 4), q);
-                }
+                for (int w = 0; w < NWAVE; ++w) sacc += red[w * 64 + sl][reg];
+                const int row = qrb * 16 + r16;
+                if (row < B)
+                    __hip_atomic_store(qgr + ((size_t)(qks * MB * 16 + row) * UA + qct * 16 + c),
+                                       ((unsigned long long)(unsigned)(t + 1) << 32) | __builtin_bit_cast(unsigned, sacc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        hop_arrive(a.bar); ++epoch; fresh();
-        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
 
         // ================= P2: location-sensitive attention (tacotron_v2.py:118-141) =================
         if (isAtt) {
-            const int p0 = ac * CH;
-            const int n = max(0, min(CH, T - p0));
-            const int pl = (a.KA - 1) >> 1;
-            // (a) processed query: 256 partial rows of 128, 16 in flight per thread
-            {
-                const int u4 = tid & 31, pg = tid >> 5;
-                f32x4 s = {0.f, 0.f, 0.f, 0.f};
-                f32x4 v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    v[i] = ld16(xs, a.oQP + (unsigned)(((((pg + 16 * i) * MB * 16) + ab) * UA + u4 * 4) * 4));
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s += v[i];
-                *reinterpret_cast<f32x4*>(s_qp + pg * UA + u4 * 4) = s;
-            }
-            // (b) previous (cumulative) alignments of this chunk with the conv halo
-            {
-                const unsigned cum_prev = a.oCUM + (unsigned)(((t + 1) & 1) * B * T * 4);
-                for (int i = tid; i < CHP + 32; i += NT) {
-                    const int p = p0 - pl + i;
-                    float v = 0.f;
-                    if (t > 0 && p >= 0 && p < T && i < n + a.KA - 1) v = ld4(xs, cum_prev + (unsigned)((ab * T + p) * 4));
-                    s_cum[i] = v;
-                }
-            }
-            // keys of this lane's (position, unit) pairs for the first four row tiles
-            float kreg[4][4];
+            const int p0 = att_p0, n = att_n, pl = att_pl;
             const int NRT = (n + 15) >> 4;
-            const float* keys_b = a.keys + (size_t)ab * T * UA + wave * 16 + c16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int p = min(p0 + 16 * r + 4 * kg + g, T - 1);
-                    kreg[r][g] = r < NRT ? keys_b[(size_t)p * UA] : 0.f;
-                }
-            __syncthreads();
+            // (a) processed query of this row: bias + the 8 K-split partials of its row block's query tiles (granule sweep by
+            //     the two waves that own the 128 units)
             if (tid < UA) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned long long g[KSQ];
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < KSQ; ++k) {
+                        g[k] = __hip_atomic_load(qgr + ((size_t)(k * MB * 16 + ab) * UA + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= (unsigned)(g[k] >> 32) == (unsigned)(t + 1);
+                    }
+                    if (__all(ok)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { s_flag[0] = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
                 float q = a.b_a[tid];
 #pragma unroll
-                for (int g = 0; g < 16; ++g) q += s_qp[g * UA + tid];
+                for (int k = 0; k < KSQ; ++k) q += __builtin_bit_cast(float, (unsigned)g[k]);
                 s_q[tid] = q;
             }
-            // (c) location features f[p][c] = sum_j w[j][c] cum[p + j - pad_l] + b[c]   (:128-130)
-            for (int item = tid; item < CHP * 32; item += NT) {
-                const int pp = item >> 5, f = item & 31;
-                float acc = 0.f;
-                if (pp < n) {
-                    acc = s_cb[f];
-                    for (int j = 0; j < a.KA; ++j) acc = fmaf(s_cw[j * 32 + f], s_cum[pp + j], acc);
-                }
-                s_f[pp * 36 + f] = acc;
-            }
             __syncthreads();
-            // (d) processed location features on the matrix pipe + energies (:131-133, :66-78)
+            if (s_flag[0]) { alive = false; break; }
+            // (b) energies e[p] = sum_u v[u] tanh(keys + q + processed location)[p][u]   (:66-78, :133)
             const float q_l = s_q[wave * 16 + c16];
-            auto energy_tile = [&](int r, const float (&kk)[4]) {
-                f32x4 pf = {0.f, 0.f, 0.f, 0.f};
-                const float* fr = s_f + (16 * r + c16) * 36 + 4 * kg;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(fr), a1 = *reinterpret_cast<const f32x4*>(fr + 16);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], wlB[s], pf, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                if (r < NRT) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], wlB[4 + s], pf, 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float e = va_l * fast_tanhf(kk[g] + q_l + pf[g]);
-                    e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4); e += __shfl_xor(e, 8);
-                    if (c16 == 0) s_ep[wave * CHP + 16 * r + 4 * kg + g] = e;
+                    for (int g = 0; g < 4; ++g) {
+                        float e = va_l * fast_tanhf(pre[r][g] + q_l);
+                        e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4); e += __shfl_xor(e, 8);
+                        if (c16 == 0) s_ep[wave * CHP + 16 * r + 4 * kg + g] = e;
+                    }
                 }
-            };
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < NRT) energy_tile(r, kreg[r]);
-            for (int r = 4; r < NRT; ++r) {          // only for chunks of more than 64 positions
-                float kk[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) kk[g] = keys_b[(size_t)min(p0 + 16 * r + 4 * kg + g, T - 1) * UA];
-                energy_tile(r, kk);
             }
             __syncthreads();
+            // (c) group exchange of the energies as tagged 8-byte granules {value, tag = step + 1} (the data is the flag:
+            //     one aligned 8-byte sc1 store per position; readers re-read until every tag matches)
+            unsigned long long* eng = reinterpret_cast<unsigned long long*>(a.xs + a.oEN / 4) + (size_t)ab * T;
             if (tid < n) {
                 float e = 0.f;
 #pragma unroll
                 for (int w = 0; w < NWAVE; ++w) e += s_ep[w * CHP + tid];
-                st4(xs, a.oEN + (unsigned)((ab * T + p0 + tid) * 4), e);
+                __hip_atomic_store(eng + p0 + tid, ((unsigned long long)(unsigned)(t + 1) << 32) | __builtin_bit_cast(unsigned, e), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             }
-            // (e) group hop: the C workgroups of this row exchange their energies
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(grp + ab * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // values of the context slice: in flight during the group hop, consumed after the softmax
+            PZ_STAMP(18);
+            // values of the context slice: in flight during the exchange, consumed after the softmax
             const int ES = EW / C, nc4 = ES >> 2, NPG = NT / nc4;
             const int c4 = tid % nc4, pg = tid / nc4;
             const f32x4* vp = reinterpret_cast<const f32x4*>(a.values + (size_t)ab * T * EW + ac * ES) + c4;
@@ -490,41 +583,52 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             f32x4 vv[VN];
 #pragma unroll
             for (int i = 0; i < VN; ++i) vv[i] = vp[(size_t)min(pg + i * NPG, len_b - 1) * (EW / 4)];
-            if (!word_wait(grp + ab * 32, (unsigned)C * (unsigned)(t + 1), s_flag)) { alive = false; break; }
-            for (int i = tid; i < T; i += NT) s_e[i] = ld4(xs, a.oEN + (unsigned)((ab * T + i) * 4));
-            __syncthreads();
-            // (f) masked softmax over positions < len (score mask -inf -> probability exactly 0; App. A5)
-            float m = -INFINITY;
-            for (int i = tid; i < len_b; i += NT) m = fmaxf(m, s_e[i]);
+            // (d) every wave sweeps all T granules and computes the masked softmax redundantly (score mask -inf -> probability
+            //     exactly 0; App. A5): no workgroup barrier between the exchange and the alignments
+            {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                bool bad = false;
+                float m = -INFINITY;
+                for (int i0 = 0; i0 < T; i0 += 64) {
+                    const int i = i0 + lane;
+                    float e = -INFINITY;
+                    for (;;) {
+                        unsigned long long g = (unsigned long long)(unsigned)(t + 1) << 32;
+                        if (i < T) g = __hip_atomic_load(eng + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all((unsigned)(g >> 32) == (unsigned)(t + 1))) { if (i < len_b) e = __builtin_bit_cast(float, (unsigned)g); break; }
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { bad = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (bad) break;
+                    if (i < T) s_e[wave * TP + i] = e;
+                    m = fmaxf(m, e);
+                }
+                if (bad) s_flag[0] = 1;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-            if (lane == 0) s_rw[wave] = m;
-            __syncthreads();
-            m = s_rw[0];
+                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+                float sum = 0.f;
+                for (int i = lane; i < T; i += 64) {
+                    const float ex = (i < len_b) ? expf(s_e[wave * TP + i] - m) : 0.f;
+                    s_e[wave * TP + i] = ex;
+                    sum += ex;
+                }
 #pragma unroll
-            for (int w = 1; w < NWAVE; ++w) m = fmaxf(m, s_rw[w]);
-            float sum = 0.f;
-            for (int i = tid; i < T; i += NT) {
-                const float ex = (i < len_b) ? expf(s_e[i] - m) : 0.f;
-                s_a[i] = ex;
-                sum += ex;
+                for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                // wave w publishes the probabilities of positions i with (i >> 6) % 8 == w ... every wave holds all of them; each
+                // writes the same values, so one copy per position is enough: wave (i / 64) % 8 writes block i / 64
+                for (int i0 = 0; i0 < T; i0 += 64)
+                    if (((i0 >> 6) & (NWAVE - 1)) == wave && i0 + lane < T) s_a[i0 + lane] = s_e[wave * TP + i0 + lane] / sum;
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-            if (lane == 0) s_rw[32 + wave] = sum;
             __syncthreads();
-            sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWAVE; ++w) sum += s_rw[32 + w];
-            for (int i = tid; i < T; i += NT) s_a[i] = s_a[i] / sum;
-            __syncthreads();
-            // (g) this chunk's alignments: history row and the next attention state (:137-140)
+            if (s_flag[0]) { alive = false; break; }
+            PZ_STAMP(20);
+            // (e) this chunk's alignments: history row and the next attention state (:137-140)
             if (tid < n) {
                 const float p = s_a[p0 + tid];
                 a.hist[((size_t)t * B + ab) * T + p0 + tid] = p;
                 st4(xs, a.oCUM + (unsigned)((t & 1) * B * T * 4) + (unsigned)((ab * T + p0 + tid) * 4), a.cumulative ? p + s_cum[tid + pl] : p);
             }
-            // (h) context slice = alignments . values[:, slice]   (AttentionWrapper._compute_attention)
+            // (f) context slice = alignments . values[:, slice]   (AttentionWrapper._compute_attention)
             {
                 f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -542,17 +646,25 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
                 st16(xs, a.oCTX + frag_off16(ab, (ac * ES >> 2) + tid, MB), s);
             }
         }
-        hop_arrive(a.bar); ++epoch; fresh();
+        PZ_STAMP(6); hop_arrive(a.bar); ++epoch; fresh();
         // gap: attention cell output into LSTM 1 (rnn_wrappers.py:76-78 concat, first K segment)
         {
             f32x4 b[8];
             wload<8>(b, r1, slab1 + (unsigned)(wave * 8 * 1024), l16);
             seg_mma<MB, 8>(acc1, b, xs, a.oHAr + (unsigned)(wave * 8 * MB * 1024), l16);
         }
+        const unsigned pk2 = hop_peek(a.bar);
+        // ... and the second half of LSTM 2's recurrent K range
+        if (t > 0) {
+            f32x4 b[4];
+            wload<4>(b, r2, slab2 + (unsigned)((KBH + wave * 8 + 4) * 1024), l16);
+            seg_mma<MB, 4>(acc2, b, xs, a.oH2 + (unsigned)((wave * 8 + 4) * MB * 1024), l16);
+        }
         f32x4 bc1[4];
         wload<4>(bc1, r1, slab1 + (unsigned)((KBH + wave * 4) * 1024), l16);
-        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
+        PZ_STAMP(7);
+        if (!hop_wait(a.bar, 32u * epoch, s_flag, pk2)) { alive = false; break; }
+        fresh(); PZ_STAMP(8);
 
         // ================= P3: decoder LSTM 1 (tacotron_v2.py:155-161) =================
         seg_mma<MB, 4>(acc1, bc1, xs, a.oCTX + (unsigned)(wave * 4 * MB * 1024), l16);
@@ -565,20 +677,23 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             publish4(hn, a.oY1);
             publish4(h1, a.oH1);
         }
-        hop_arrive(a.bar); ++epoch; fresh();
+        PZ_STAMP(9); hop_arrive(a.bar); ++epoch; fresh();
         // gap: the attention LSTM's recurrent K ranges for the NEXT step: [ctx(t) | h_att(t)]
+        unsigned pk3 = 0u;
         {
             f32x4 b[8];
             wload<8>(b, rA, slabA + (unsigned)((KBX + KBE + wave * 8) * 1024), l16);
             seg_mma<MB, 8>(accA, b, xs, a.oHA + (unsigned)(wave * 8 * MB * 1024), l16);
+            pk3 = hop_peek(a.bar);
             f32x4 bc[4];
             wload<4>(bc, rA, slabA + (unsigned)((KBX + wave * 4) * 1024), l16);
             seg_mma<MB, 4>(accA, bc, xs, a.oCTX + (unsigned)(wave * 4 * MB * 1024), l16);
         }
         f32x4 by[8];
         wload<8>(by, r2, slab2 + (unsigned)(wave * 8 * 1024), l16);
-        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
+        PZ_STAMP(10);
+        if (!hop_wait(a.bar, 32u * epoch, s_flag, pk3)) { alive = false; break; }
+        fresh(); PZ_STAMP(11);
 
         // ================= P4: decoder LSTM 2 =================
         seg_mma<MB, 8>(acc2, by, xs, a.oY1 + (unsigned)(wave * 8 * MB * 1024), l16);
@@ -591,19 +706,27 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             publish4(hn, a.oY2);
             publish4(h2, a.oH2);
         }
-        hop_arrive(a.bar); ++epoch; fresh();
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        PZ_STAMP(12); hop_arrive(a.bar); ++epoch; fresh();
         // gap: LSTM 1's recurrent K range for the next step
+        unsigned pk4 = 0u;
         {
             f32x4 b[8];
             wload<8>(b, r1, slab1 + (unsigned)((KBH + KBE + wave * 8) * 1024), l16);
 #pragma unroll
             for (int rb = 0; rb < MB; ++rb) acc1[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            seg_mma<MB, 8>(acc1, b, xs, a.oH1 + (unsigned)(wave * 8 * MB * 1024), l16);
+            f32x4 blo[4] = {b[0], b[1], b[2], b[3]}, bhi[4] = {b[4], b[5], b[6], b[7]};
+            seg_mma<MB, 4>(acc1, blo, xs, a.oH1 + (unsigned)(wave * 8 * MB * 1024), l16);
+            pk4 = hop_peek(a.bar);
+            seg_mma<MB, 4>(acc1, bhi, xs, a.oH1 + (unsigned)((wave * 8 + 4) * MB * 1024), l16);
         }
         f32x4 bp[8];
-        if (isP) wload<8>(bp, rP, (unsigned)((ptile * KBH + wave * 8) * 1024), l16);
-        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
+        float bias_p = 0.f;
+        if (isP) { wload<8>(bp, rP, (unsigned)((ptile * KBH + wave * 8) * 1024), l16); bias_p = a.bP[ptile * 16 + (tid & 15)]; }
+        PZ_STAMP(13);
+        if (!hop_wait(a.bar, 32u * epoch, s_flag, pk4)) { alive = false; break; }
+        fresh(); PZ_STAMP(14);
 
         // ================= P5: mel / stop projections (rnn_wrappers.py:105-109) + composed first PreNet layer of step t+1 =================
         if (isP) {
@@ -618,7 +741,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
 #pragma unroll
                 for (int w = 0; w < NWAVE; ++w) s += red[w * 64 + sl][reg];
                 const int col = ptile * 16 + c, row = prb * 16 + r16;
-                s += a.bP[col];
+                s += bias_p;
                 if (ptile >= 12) s_tile[r16 * 16 + c] = fmaxf(s, 0.f);
                 else if (row < B) {
                     if (col < a.MR) a.mel[(size_t)row * a.mel_ld + (size_t)t * a.mel_ts + col] = s;
@@ -628,35 +751,27 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
                     }
                 }
             }
-            __syncthreads();
-            if (ptile >= 12 && tid < 64) {
-                const int r16 = tid >> 2, q = tid & 3, row = prb * 16 + r16;
-                if (row < B) st16(xs, a.oX1 + frag_off16(row, (ptile - 12) * 4 + q, MB), *reinterpret_cast<const f32x4*>(s_tile + r16 * 16 + q * 4));
+            if (ptile >= 12) {
+                __syncthreads();
+                if (tid < 64) {
+                    const int r16 = tid >> 2, q = tid & 3, row = prb * 16 + r16;
+                    if (row < B) st16(xs, a.oX1 + frag_off16(row, (ptile - 12) * 4 + q, MB), *reinterpret_cast<const f32x4*>(s_tile + r16 * 16 + q * 4));
+                }
+                // row-block group hop towards the last PreNet layer's tiles of the next step
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(grpx + prb * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        hop_arrive(a.bar); ++epoch; fresh();
-        // gap: LSTM 2's recurrent K range for the next step
-        {
-            f32x4 b[8];
-            wload<8>(b, r2, slab2 + (unsigned)((KBH + wave * 8) * 1024), l16);
-#pragma unroll
-            for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            seg_mma<MB, 8>(acc2, b, xs, a.oH2 + (unsigned)(wave * 8 * MB * 1024), l16);
-        }
-        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
-        // ---- stop rule of StopTokenBasedInferenceHelper (helpers.py:90-94): every row says stop and time > min_iters;
-        //      the finishing step's outputs are kept, so the decode emits t + 1 steps.  Every workgroup evaluates it on the
-        //      same published logits, so all of them leave the loop at the same step.
-        if (tid < 64) {
-            const float v = lane < B ? ld4(xs, a.oSTOP + (unsigned)(lane * 4)) : 1.0f;
-            const bool all_stop = __all(v > 0.f);
-            if (lane == 0) s_flag[1] = (a.stop_en && all_stop && t > a.min_iters) ? 1 : 0;
-        }
-        __syncthreads();
-        if (s_flag[1]) { final_steps = t + 1; break; }
-        __syncthreads();
+        PZ_STAMP(15);
     }
+    // (the last step's stop decision changes nothing: the decode ends at max_steps either way -- dynamic_decode's maximum_iterations)
+#ifdef PZ_STAMPS
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) g_pz_stamps[wg][i] = st_acc[i];
+    }
+#endif
     if (wg == 0 && tid == 0) {
         a.ctl[CTL_FINAL] = final_steps;
         if (!alive) a.ctl[5] = 1;

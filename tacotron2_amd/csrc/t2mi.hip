@@ -101,6 +101,7 @@ struct t2_model {
     ConvLayer proj_plain;               // mel | stop projection in plain layout [D][pad4(M*r + 1)] (deferred, batched projection)
     int opt_tfproj = 1;                 // teacher-forced decode: projections of all steps as one GEMM after the loop
     float *wq = nullptr;                // query layer kernel [A][U], plain
+    Packed wq_pk;                       // the same as a skinny dense operand (persistent decoder)
     float *conv_w = nullptr, *conv_b = nullptr, *wloc = nullptr, *v_a = nullptr, *b_a = nullptr;
     // cached workspaces
     std::vector<t2_state*> states;      // decode states owned by the model (cache)
@@ -468,6 +469,7 @@ extern "C" int t2_model_finalize(t2_model* m) {
     T2_TRY(upload(m, &m->memory_layer.w, w->data));
     T2_TRY(get_w(m, "attention/query_layer/kernel", &w, {A, U}));
     T2_TRY(upload(m, &m->wq, w->data));
+    T2_TRY(pack_skinny(m, &m->wq_pk, w->data.data(), U, {{0, A}}, 0, U, nullptr));
     T2_TRY(get_w(m, "attention/location_features_convolution/kernel", &w, {K, 1, F}));
     T2_TRY(upload(m, &m->conv_w, w->data));
     T2_TRY(get_w(m, "attention/location_features_convolution/bias", &w, {F}));
@@ -922,8 +924,10 @@ static bool persist_dims_ok(const t2_model* m, int B, int T) {
     if (d.enc_units != pz::EW || d.attention_lstm_units != pz::NWG * 4 || d.decoder_lstm_units != pz::NWG * 4) return false;
     if (d.attention_dim != pz::UA || d.attention_filters > 32 || d.attention_kernel > 32) return false;
     if (d.num_mels * d.outputs_per_step != 160) return false;
-    if (m->n_cu < pz::NWG || B < 1 || B > 64 || T < 1 || T > 2048) return false;
-    return true;
+    if (m->n_cu < pz::NWG || B < 1 || B > 64 || T < 1) return false;
+    int c = 16;
+    while (c > 4 && B * c > pz::NWG) c >>= 1;
+    return (T + c - 1) / c <= 64;          // the attention keeps four 16-position tiles per workgroup in registers
 }
 static inline int persist_chunks(int B) { int c = 16; while (c > 4 && B * c > pz::NWG) c >>= 1; return c; }
 static inline size_t persist_lds_bytes(int B, int T) {
@@ -976,12 +980,12 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
         s->pz_off[4] = pcarve((size_t)R * 512 * 4);                               // context
         s->pz_off[5] = pcarve(h); s->pz_off[6] = pcarve(h);                       // y1 raw, h1 state
         s->pz_off[7] = pcarve(h); s->pz_off[8] = pcarve(h);                       // y2 raw, h2 state
-        s->pz_off[9] = pcarve((size_t)pz::NWG * R * pz::UA * 4);                  // partial processed queries
-        s->pz_off[10] = pcarve((size_t)B * T * 4);                                // energies
+        s->pz_off[9] = pcarve((size_t)8 * R * pz::UA * 8);                        // processed query: 8 K-split partials as tagged granules
+        s->pz_off[10] = pcarve((size_t)B * T * 8);                                // energies as tagged 8-byte granules
         s->pz_off[11] = pcarve(2 * (size_t)B * T * 4);                            // attention state, two step parities
         s->pz_off[12] = pcarve(256);                                              // stop logits
         o_pz = carve(pz_total);
-        o_pzbar = carve((size_t)(pz::NSHARD + 64) * 32 * 4);
+        o_pzbar = carve((size_t)(pz::NSHARD + 64 + 4) * 32 * 4);
     }
     s->slab_bytes = off;
     e1 = hipMalloc(&s->slab, off);
@@ -1552,7 +1556,7 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     pz::PArgs a{};
     a.wA = m->att_lstm.w; a.bA = m->att_lstm.bias; a.w1 = m->lstm1.w; a.b1 = m->lstm1.bias; a.w2 = m->lstm2.w; a.b2 = m->lstm2.bias;
     a.wP = m->proj_fused.w; a.bP = m->proj_fused.bias; a.wN = m->prenet[1].w; a.bN = m->prenet[1].bias;
-    a.wq = m->wq; a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
+    a.wQ = m->wq_pk.w; a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
     a.keys = s->keys; a.values = s->values; a.lens = s->lens;
     a.xs = s->pz_xs; a.xs_bytes = s->pz_bytes;
     a.oX1 = s->pz_off[0]; a.oX2 = s->pz_off[1]; a.oHAr = s->pz_off[2]; a.oHA = s->pz_off[3]; a.oCTX = s->pz_off[4];
@@ -1568,7 +1572,7 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
     if (m->att_lstm.n_wg != pz::NWG || m->att_lstm.kbtot != pz::KBX + pz::KBE + pz::KBH || m->lstm1.kbtot != 2 * pz::KBH + pz::KBE ||
         m->lstm2.kbtot != 2 * pz::KBH || m->proj_fused.n_wg != 28 || m->proj_fused.kbtot != pz::KBH || m->prenet[1].n_wg != 16 ||
-        m->prenet[1].kbtot != pz::KBX)
+        m->prenet[1].kbtot != pz::KBX || m->wq_pk.n_wg != 8 || m->wq_pk.kbtot != pz::KBH)
         return fail(T2_ESTATE, "internal: packed operands do not have the persistent decoder's geometry");
     // x1 of step 0 = relu(bias of the first PreNet layer): the go frame is zeros (helpers.py:187-188)
     hipLaunchKernelGGL(pz::init_x1_kernel, dim3(ceil_div(s->B * d.prenet_units[0], 256)), dim3(256), 0, st, s->pz_xs + a.oX1 / 4,
@@ -1709,6 +1713,13 @@ extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* l
     hipHostFree(h_flag);
     return rc;
 }
+
+#ifdef PZ_STAMPS
+extern "C" int t2_debug_stamps(unsigned long long* out) {     // diagnostic builds only: [256][24] tick sums (10 ns)
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(pz::g_pz_stamps), sizeof(unsigned long long) * pz::NWG * 24));
+    return T2_OK;
+}
+#endif
 
 extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
     if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
