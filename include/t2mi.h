@@ -163,6 +163,14 @@ int t2_model_get_stat(t2_model* m, const char* name, double* out);
  * mask [B,T] broadcast over M (priority-frequency blend unused: defaults None / 0). */
 int t2_spec_loss(t2_ctx* ctx, const float* y_hat, const float* y, const float* mask, int B, int T, int M, float* out3);
 
+/* Allocation-free variant of t2_spec_loss.  It has no counterpart in the reference; it exists for callers that cannot
+ * allocate (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): it calls no hipMalloc /
+ * hipFree or allocating routine.  Same arithmetic and results as t2_spec_loss; the per-block partial sums live in a 16 KiB
+ * device array of the library (one copy per GPU, held until the process ends; its address is looked up in t2_ctx_create).
+ * Limit: B*T*M <= 2^28 elements, else T2_EINVAL.  Calls that overlap on one GPU (two streams / two contexts) race on that
+ * array: serialise them. */
+int t2_spec_loss_noalloc(t2_ctx* ctx, const float* y_hat, const float* y, const float* mask, int B, int T, int M, float* out3);
+
 /* binary_loss (tacotron/models.py:146-148): tf.losses.sigmoid_cross_entropy(done, logits, weights = mask),
  * logits / done / mask [B,S]. */
 int t2_binary_loss(t2_ctx* ctx, const float* logits, const float* done, const float* mask, int B, int S, float* out3);

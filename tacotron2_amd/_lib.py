@@ -92,6 +92,7 @@ _SIGS = {
     "t2_trainer_bind_gradient": (C.c_int, [_p, C.c_char_p, C.c_int64]),
     "t2_train_decoder_backward": (C.c_int, [_p, _p, _p, _p, _p, _p, _p]),
     "t2_spec_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
+    "t2_spec_loss_noalloc": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "t2_binary_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "t2_optim_create": (C.c_int, [_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.POINTER(_p)]),
     "t2_optim_destroy": (C.c_int, [_p]),

@@ -297,6 +297,7 @@ static int make_conv(t2_model* m, ConvLayer* L, const std::string& prefix, int k
 // ------------------------------------------------------------------------------------------------
 // ctx / model
 // ------------------------------------------------------------------------------------------------
+static int noalloc_setup(int device);     // train.h
 extern "C" int t2_ctx_create(int device, void* hip_stream, t2_ctx** out) {
     if (!out) return fail(T2_EINVAL, "out is null");
     int n = 0;
@@ -307,6 +308,7 @@ extern "C" int t2_ctx_create(int device, void* hip_stream, t2_ctx** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(T2_EHIP, "device %d is %s; libt2mi is built for gfx950 only", device, prop.gcnArchName);
+    T2_TRY(noalloc_setup(device));        // per-device address of the allocation-free entry point's scratch array (train.h)
     t2_ctx* c = new t2_ctx();
     c->device = device;
     if (hip_stream) {

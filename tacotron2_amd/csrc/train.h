@@ -190,6 +190,41 @@ extern "C" int t2_spec_loss(t2_ctx* ctx, const float* y_hat, const float* y, con
     return T2_OK;
 }
 
+// ---- allocation-free variant of t2_spec_loss (no reference counterpart; for callers that cannot allocate: code under HIP
+// graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same two kernels; the per-block partials go to a
+// file-scope device array instead of the lazily hipMalloc'ed ctx workspace.  Each GPU holds its own copy of the array at its
+// own address, looked up once per device in t2_ctx_create (the library's set-up call), with that device current.
+#define T2_NOALLOC_MAX_ELEMS (1LL << 28)            /* B*T*M accepted by t2_spec_loss_noalloc (1 GiB per tensor) */
+static __device__ __align__(256) float scratch[T2_RED_MAX_BLOCKS * 2];      // 16 KiB per GPU, held until the process ends
+static float* g_scratch_ptr[64] = {nullptr};        // device address of `scratch` on each GPU (host code never uses the name itself)
+
+static int noalloc_setup(int device) {              // called with `device` current
+    if (device < 0 || device >= 64) return fail(T2_EINVAL, "device index %d beyond the per-device table", device);
+    if (g_scratch_ptr[device] != nullptr) return T2_OK;
+    float* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = ptr;
+    return T2_OK;
+}
+
+extern "C" int t2_spec_loss_noalloc(t2_ctx* ctx, const float* y_hat, const float* y, const float* mask, int B, int T, int M, float* out3) {
+    if (!ctx || !y_hat || !y || !mask || !out3) return fail(T2_EINVAL, "null argument");
+    if (B < 1 || T < 1 || M < 1) return fail(T2_EINVAL, "bad shape [%d,%d,%d]", B, T, M);
+    if ((long long)B * T * M > T2_NOALLOC_MAX_ELEMS)
+        return fail(T2_EINVAL, "t2_spec_loss_noalloc: %lld elements exceed the maximum of %lld", (long long)B * T * M, (long long)T2_NOALLOC_MAX_ELEMS);
+    float* ws = (ctx->device >= 0 && ctx->device < 64) ? g_scratch_ptr[ctx->device] : nullptr;
+    if (ws == nullptr) return fail(T2_ESTATE, "t2_spec_loss_noalloc: the scratch array of device %d was not set up", ctx->device);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const long long rows = (long long)B * T;
+    if ((M & 3) == 0 && ((((uintptr_t)y_hat) | ((uintptr_t)y)) & 15) != 0) return fail(T2_EINVAL, "y_hat / y must be 16-byte aligned");
+    const int nb = red_blocks(rows * M / 4 + 1);
+    // every partial the final kernel reads (2 * nb floats) is written by this call's first kernel: nothing has to start at zero
+    hipLaunchKernelGGL(spec_loss_partial_kernel, dim3(nb), dim3(T2_RED_THREADS), 0, ctx->stream, y_hat, y, mask, rows, M, ws);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(T2_RED_THREADS), 0, ctx->stream, ws, nb, out3);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
 extern "C" int t2_binary_loss(t2_ctx* ctx, const float* logits, const float* done, const float* mask, int B, int S, float* out3) {
     if (!ctx || !logits || !done || !mask || !out3) return fail(T2_EINVAL, "null argument");
     if (B < 1 || S < 1) return fail(T2_EINVAL, "bad shape [%d,%d]", B, S);
