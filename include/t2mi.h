@@ -221,6 +221,11 @@ int t2_trainer_load_params(t2_trainer* tr, const float* flat_params);
 /* The UPDATE_OPS of the step (tacotron/models.py:75): moving = momentum*moving + (1-momentum)*batch for the encoder's batch
  * norms (variance with Bessel's correction), in place in the flat parameter buffer; statistics of the last encoder forward. */
 int t2_trainer_update_moving_stats(t2_trainer* tr, float* flat_params, float momentum);
+/* Data-parallel training (no reference counterpart: the reference is single-device).  counts dev [2] = number of
+ * non-zero loss weights of the WHOLE batch over all ranks for {spec_loss, binary_loss} (the caller all-reduces them and keeps the
+ * buffer alive); the next backward passes then differentiate sum_rank / count_total, so that the plain SUM of the ranks' gradients
+ * is the gradient of tf.losses' SUM_BY_NONZERO_WEIGHTS value of the whole batch (models.py:136-148).  NULL: this rank's own counts. */
+int t2_trainer_set_loss_counts(t2_trainer* tr, const float* counts);
 /* Where the gradient of variable `name` (TF layout) goes in the caller's flat gradient buffer (floats, multiple of 4). */
 int t2_trainer_bind_gradient(t2_trainer* tr, const char* name, int64_t offset);
 /* Backward of t2_train_decoder_forward through the losses of model_fn (tacotron/models.py:58-61: spec_loss(mel) +

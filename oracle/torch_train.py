@@ -149,23 +149,25 @@ def decoder_train(d, W, memory, lens, target, seed, prenet_drop_rate):
     return mel, torch.stack(stops, 1), torch.stack(aligns, 0)
 
 
-def weighted_loss(l, w):
-    """tf.losses.compute_weighted_loss, SUM_BY_NONZERO_WEIGHTS."""
+def weighted_loss(l, w, count=None):
+    """tf.losses.compute_weighted_loss, SUM_BY_NONZERO_WEIGHTS.  count: the denominator of a larger (data-parallel) batch
+    this one is a shard of -- then the value is this shard's share of that batch's loss."""
     wb = w.expand_as(l)
-    n = (wb != 0).sum()
-    return (l * wb).sum() / n if int(n) > 0 else (l * wb).sum() * 0.0
+    n = (wb != 0).sum() if count is None else count
+    return (l * wb).sum() / n if float(n) > 0 else (l * wb).sum() * 0.0
 
 
-def losses(mel, stop, labels):
+def losses(mel, stop, labels, counts=None):
     """models.py:58-61, 136-148."""
-    mel_loss = weighted_loss((mel - _t(labels["mel"])).abs(), _t(labels["spec_loss_mask"])[:, :, None])
+    mel_loss = weighted_loss((mel - _t(labels["mel"])).abs(), _t(labels["spec_loss_mask"])[:, :, None], None if counts is None else counts[0])
     x, zt = stop[..., 0], _t(labels["done"])
     ce = torch.clamp(x, min=0) - x * zt + torch.log1p(torch.exp(-x.abs()))
-    done_loss = weighted_loss(ce, _t(labels["binary_loss_mask"]))
+    done_loss = weighted_loss(ce, _t(labels["binary_loss_mask"]), None if counts is None else counts[1])
     return mel_loss, done_loss
 
 
-def train_forward_backward(d, w, ids, lens, labels, seed, prenet_drop_rate=0.5, encoder_drop_rate=0.5, decoder_only_memory=None):
+def train_forward_backward(d, w, ids, lens, labels, seed, prenet_drop_rate=0.5, encoder_drop_rate=0.5, decoder_only_memory=None,
+                           loss_counts=None):
     """One training-mode forward + backward.  Returns dict(loss, mel_loss, done_loss, mel, stop, alignment [S,B,T], memory,
     grads{name: ndarray}, bn_stats).  decoder_only_memory: skip the encoder and treat this memory as a leaf (its gradient is
     returned as grads['memory'])."""
@@ -177,7 +179,7 @@ def train_forward_backward(d, w, ids, lens, labels, seed, prenet_drop_rate=0.5, 
         emb = W["embedding"][torch.as_tensor(np.asarray(ids), dtype=torch.long)]
         memory, bn_stats = encoder_train(d, W, emb, lens, seed, encoder_drop_rate)
     mel, stop, align = decoder_train(d, W, memory, lens, _t(labels["mel"]), seed, prenet_drop_rate)
-    mel_loss, done_loss = losses(mel, stop, labels)
+    mel_loss, done_loss = losses(mel, stop, labels, loss_counts)      # loss_counts: data-parallel shard of a larger batch
     loss = mel_loss + done_loss
     loss.backward()
     grads = {k: (v.grad.numpy().astype(np.float32) if v.grad is not None else np.zeros(tuple(v.shape), np.float32)) for k, v in W.items()}

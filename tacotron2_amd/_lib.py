@@ -88,6 +88,7 @@ _SIGS = {
     "t2_train_encoder_forward": (C.c_int, [_p, _p, _p, C.c_float, C.c_uint32, _p, _p]),
     "t2_train_encoder_backward": (C.c_int, [_p, _p, _p]),
     "t2_trainer_load_params": (C.c_int, [_p, _p]),
+    "t2_trainer_set_loss_counts": (C.c_int, [_p, _p]),
     "t2_trainer_update_moving_stats": (C.c_int, [_p, _p, C.c_float]),
     "t2_trainer_bind_gradient": (C.c_int, [_p, C.c_char_p, C.c_int64]),
     "t2_train_decoder_backward": (C.c_int, [_p, _p, _p, _p, _p, _p, _p]),

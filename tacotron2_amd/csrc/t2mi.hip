@@ -110,6 +110,8 @@ struct t2_model {
     void* enc_ws = nullptr; size_t enc_ws_bytes = 0;
     void* post_ws = nullptr; size_t post_ws_bytes = 0;
     int* h_ctl = nullptr;               // pinned host mirror of a ctl block
+    int* h_flag = nullptr;              // pinned mirrors of the ctl block, two chunks in flight (t2_decode_free)
+    hipEvent_t flag_ev[2] = {nullptr, nullptr};
     int opt_graph = 1;                  // use hipGraph chunks for decode loops
     int opt_chunk = 16;                 // steps per graph
     int opt_splitk = 0;                 // batches > 16 rows: split-K LSTM step with in-launch reduction
@@ -120,6 +122,8 @@ struct t2_model {
     int n_cu = 256;                     // compute units of the device (rider capacity of a launch)
     int opt_lstm_only = 0;              // measurement: decode steps launch only the three LSTM kernels
     int opt_time_lstm = 0;              // record HIP events around decoder LSTM launches (eager mode)
+    unsigned long long param_gen = 0;   // bumped by t2_trainer_load_params; trainers compare it with their own generation
+    const float* last_flat = nullptr;   // flat parameter buffer of the last refresh (owned by the caller)
     long long n_persist = 0;            // persistent decodes launched (stat "persist_launches")
     int opt_persist = 1;                // free-running decodes of the paper-size dimension class run as ONE persistent launch (persist.h)
 };
@@ -570,6 +574,8 @@ extern "C" int t2_model_finalize(t2_model* m) {
     T2_TRY(upload(m, &m->post_proj.w, w->data));
     T2_TRY(upload(m, &m->post_proj.shift, b->data));
     HIP_TRY(hipHostMalloc((void**)&m->h_ctl, 8 * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&m->h_flag, 2 * 8 * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&m->flag_ev[i], hipEventDisableTiming));
     if (d.attention_filters > 64 || U > 256) return fail(T2_EINVAL, "attention_filters <= 64 and attention_dim <= 256 supported");
     T2_TRY(set_attention_func_attributes());
     {
@@ -592,6 +598,8 @@ extern "C" int t2_model_destroy(t2_model* m) {
     if (m->enc_ws) hipFree(m->enc_ws);
     if (m->post_ws) hipFree(m->post_ws);
     if (m->h_ctl) hipHostFree(m->h_ctl);
+    if (m->h_flag) hipHostFree(m->h_flag);
+    for (int i = 0; i < 2; ++i) if (m->flag_ev[i]) hipEventDestroy(m->flag_ev[i]);
     delete m;
     return T2_OK;
 }
@@ -1408,6 +1416,7 @@ static int get_loop_state(t2_model* m, int B, int T, int cap, t2_state** out) {
     if (attn_lds_bytes(m->d, T) > 120 * 1024) return fail(T2_EINVAL, "T_in %d too long for the attention kernel's LDS", T);
     // keep the cache small: drop everything when it grows
     if (m->states.size() >= 4) {
+        if (m->pending) return fail(T2_ESTATE, "a free-running decode is in flight; call t2_decode_free_finish first");
         HIP_TRY(hipStreamSynchronize(m->ctx->stream));
         for (t2_state* s : m->states) state_free(s);
         m->states.clear();
@@ -1598,6 +1607,9 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     const t2_dims& d = m->d;
     const int M = d.num_mels, r = d.outputs_per_step;
     if (T_out < r || T_out % r != 0) return fail(T2_EINVAL, "T_out must be a positive multiple of outputs_per_step");
+    // the loop states are shared with t2_decode_free_launch: zeroing or evicting the state of a decode in flight would corrupt
+    // its step count (t2_decode_free_finish reads the state's control block)
+    if (m->pending) return fail(T2_ESTATE, "a free-running decode is in flight; call t2_decode_free_finish first");
     HIP_TRY(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
     const int S = T_out / r;
@@ -1692,10 +1704,8 @@ extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* l
     hipStream_t st = m->ctx->stream;
     // chunks are enqueued two ahead of the host's view of the finished flag: chunks after the stop
     // step are no-ops on the device, so over-enqueueing is harmless and the host never stalls the GPU.
-    hipEvent_t ev[2];
-    int* h_flag = nullptr;
-    HIP_TRY(hipHostMalloc((void**)&h_flag, 2 * 8 * sizeof(int), hipHostMallocDefault));
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    hipEvent_t* ev = m->flag_ev;          // created once per model (t2_model_finalize), as is the pinned mirror
+    int* h_flag = m->h_flag;
     int rc = decode_prologue(s, 1), n = 0;
     bool finished = false;
     for (int done = 0; rc == T2_OK && done < max_iters && !finished; done += m->opt_chunk, ++n) {
@@ -1711,8 +1721,6 @@ extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* l
     if (rc == T2_OK) rc = free_copy_out(s, mel, stop, align);
     if (rc == T2_OK) rc = read_steps(s, steps_out);
     hipStreamSynchronize(st);
-    for (int i = 0; i < 2; ++i) hipEventDestroy(ev[i]);
-    hipHostFree(h_flag);
     return rc;
 }
 

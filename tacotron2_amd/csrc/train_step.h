@@ -609,6 +609,8 @@ struct t2_trainer {
     double* bn_part = nullptr; int bn_cols = 0;    // batch-norm reduction partials [T2_BN_CHUNKS][2][bn_cols]
     float* wg_part = nullptr;                      // split-K partials of the weight-gradient GEMMs [splits][rows][cols]
     std::map<std::string, long long> offsets;      // flat-gradient layout given by the caller
+    const float* glob_counts = nullptr;            // dev [2]: non-zero loss weights of the whole data-parallel batch (null: this rank's own)
+    unsigned long long gen = 0;                    // parameter generation (t2_model::param_gen) the trainer-owned operands were built from
 };
 
 static int trainer_pack_T(t2_trainer* tr, Packed* out, const std::string& name, int rows, int cols, int col0, int ncols) {
@@ -719,6 +721,7 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
 }
 
 // ---- backward pass -------------------------------------------------------------------------------------------------------
+static int trainer_sync_params(t2_trainer* tr);
 static int trainer_setup_backward(t2_trainer* tr) {
     t2_model* m = tr->m;
     const t2_dims& d = m->d;
@@ -915,6 +918,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     t2_model* m = tr->m;
     HIP_TRY(hipSetDevice(m->ctx->device));
     if (!tr->bslab) T2_TRY(trainer_setup_backward(tr));
+    T2_TRY(trainer_sync_params(tr));
     const t2_dims& d = m->d;
     hipStream_t st = m->ctx->stream;
     t2_state* s = tr->state;
@@ -934,7 +938,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     T2_TRY(t2_spec_loss(m->ctx, s->o_mel, s->i_targets, spec_mask, B, S * r, M, l3));
     T2_TRY(t2_binary_loss(m->ctx, s->o_stop, done, bin_mask, B, S, l3 + 4));
     hipLaunchKernelGGL(loss_grad_kernel, dim3(std::min<long long>(2048, (SB * N + 255) / 256)), dim3(256), 0, st, s->o_mel, s->i_targets,
-                       spec_mask, s->o_stop, done, bin_mask, l3 + 1, l3 + 5, tr->dY, tr->dYf, (long long)MB * 16 * pad16(N), MB, B, S, M, r);
+                       spec_mask, s->o_stop, done, bin_mask, tr->glob_counts ? tr->glob_counts : l3 + 1, tr->glob_counts ? tr->glob_counts + 1 : l3 + 5, tr->dY, tr->dYf, (long long)MB * 16 * pad16(N), MB, B, S, M, r);
     auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (n + 255) / 256))); };
     const size_t lds = (size_t)attn_bwd_lds_floats(U, E, F, K) * 4;
     const int NJ = tr->NJ;
@@ -1471,6 +1475,7 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
     EncTape* et = enc_tape_of(tr);
     if (!et->have_forward) return fail(T2_ESTATE, "t2_train_encoder_forward has not run");
     if (!et->have_bwd) T2_TRY(enc_setup_backward(tr, et));
+    T2_TRY(trainer_sync_params(tr));
     const t2_dims& d = m->d;
     hipStream_t st = m->ctx->stream;
     const int B = tr->B, T = tr->T, MB = mb_for(B), R = MB * 16, E = d.enc_units, He = E / 2, emb = d.embedding_dim, L = d.enc_conv_layers;
@@ -1651,8 +1656,10 @@ static void repack(hipStream_t st, const Packed& p, const float* src, long long 
 // Rebuild every device copy of the weights from the flat parameter buffer (layout = the offsets bound with
 // t2_trainer_bind_gradient; TF layouts).  Called after the optimizer step; inference entry points of the same model see the
 // new weights too.
-extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
-    if (!tr || !flat) return fail(T2_EINVAL, "null argument");
+// model_part: the copies every entry point of the model reads; trainer_part: the transposed / flipped operands of THIS trainer's
+// backward pass.  A model can have several trainers (one per batch shape); each refreshes its own operands when it lags behind
+// the model's parameter generation (trainer_sync_params).
+static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, bool trainer_part) {
     t2_model* m = tr->m;
     HIP_TRY(hipSetDevice(m->ctx->device));
     if (!tr->bslab) T2_TRY(trainer_setup_backward(tr));
@@ -1667,21 +1674,21 @@ extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
     auto copy = [&](float* dst, const float* src, size_t n) -> int { HIP_TRY(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st)); return T2_OK; };
     auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
     T2_TRY(flat_src(tr, flat, "embedding", &w));
-    T2_TRY(copy(m->embedding, w, (size_t)d.num_symbols * emb));
+    if (model_part) T2_TRY(copy(m->embedding, w, (size_t)d.num_symbols * emb));
     int cin = emb;
     for (int i = 0; i < L; ++i) {
         const std::string pn = "encoder/conv1d_" + std::to_string(i);
         const float *g, *be, *mu, *var;
         T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
-        T2_TRY(copy(m->enc_convs[i].w, w, (size_t)d.enc_kernel * cin * E));
-        hipLaunchKernelGGL(conv_flip_kernel, grid1((long long)d.enc_kernel * cin * E), dim3(256), 0, st, et->convT[i].w, w, d.enc_kernel, cin, E);
+        if (model_part) T2_TRY(copy(m->enc_convs[i].w, w, (size_t)d.enc_kernel * cin * E));
+        if (trainer_part) hipLaunchKernelGGL(conv_flip_kernel, grid1((long long)d.enc_kernel * cin * E), dim3(256), 0, st, et->convT[i].w, w, d.enc_kernel, cin, E);
         T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/gamma", &g));
         T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/beta", &be));
         T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_mean", &mu));
         T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_variance", &var));
-        T2_TRY(copy(m->enc_bn_gamma[i], g, E));
-        T2_TRY(copy(m->enc_bn_beta[i], be, E));
-        hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, st, g, be, mu, var, d.bn_eps, m->enc_convs[i].scale, m->enc_convs[i].shift, E);
+        if (model_part) T2_TRY(copy(m->enc_bn_gamma[i], g, E));
+        if (model_part) T2_TRY(copy(m->enc_bn_beta[i], be, E));
+        if (model_part) hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, st, g, be, mu, var, d.bn_eps, m->enc_convs[i].scale, m->enc_convs[i].shift, E);
         cin = E;
     }
     const char* dirs[2] = {"fw", "bw"};
@@ -1689,31 +1696,37 @@ extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
         const std::string pn = std::string("encoder/bidirectional_rnn/") + dirs[dir] + "/lstm_cell";
         T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
         T2_TRY(flat_src(tr, flat, pn + "/bias", &b));
-        repack(st, m->enc_lstm[dir], w, 4 * He, 1, 0);
-        hipLaunchKernelGGL(lstm_bias_pack_kernel, grid1(m->enc_lstm[dir].n_wg * 16), dim3(256), 0, st, m->enc_lstm[dir].bias, b, m->enc_lstm[dir].n_wg, He);
-        repack(st, et->lstmT[dir], w, 1, 4 * He, cin + He);
+        if (model_part) {
+            repack(st, m->enc_lstm[dir], w, 4 * He, 1, 0);
+            hipLaunchKernelGGL(lstm_bias_pack_kernel, grid1(m->enc_lstm[dir].n_wg * 16), dim3(256), 0, st, m->enc_lstm[dir].bias, b, m->enc_lstm[dir].n_wg, He);
+        }
+        if (trainer_part) repack(st, et->lstmT[dir], w, 1, 4 * He, cin + He);
     }
     T2_TRY(flat_src(tr, flat, "attention/memory_layer/kernel", &w));
-    T2_TRY(copy(m->memory_layer.w, w, (size_t)E * U));
-    hipLaunchKernelGGL(transpose_kernel, grid1((long long)U * E), dim3(256), 0, st, tr->wmemT, E, w, U, U, E);
+    if (model_part) T2_TRY(copy(m->memory_layer.w, w, (size_t)E * U));
+    if (trainer_part) hipLaunchKernelGGL(transpose_kernel, grid1((long long)U * E), dim3(256), 0, st, tr->wmemT, E, w, U, U, E);
     T2_TRY(flat_src(tr, flat, "attention/query_layer/kernel", &w));
-    T2_TRY(copy(m->wq, w, (size_t)A * U));
-    repack(st, tr->wqT, w, 1, U, A);
-    T2_TRY(flat_src(tr, flat, "attention/location_features_convolution/kernel", &w)); T2_TRY(copy(m->conv_w, w, (size_t)K * F));
-    T2_TRY(flat_src(tr, flat, "attention/location_features_convolution/bias", &w)); T2_TRY(copy(m->conv_b, w, F));
-    T2_TRY(flat_src(tr, flat, "attention/location_features_layer/kernel", &w)); T2_TRY(copy(m->wloc, w, (size_t)F * U));
-    T2_TRY(flat_src(tr, flat, "attention/attention_variable", &w)); T2_TRY(copy(m->v_a, w, U));
-    T2_TRY(flat_src(tr, flat, "attention/attention_bias", &w)); T2_TRY(copy(m->b_a, w, U));
+    if (model_part) { T2_TRY(copy(m->wq, w, (size_t)A * U)); repack(st, m->wq_pk, w, U, 1, U); }
+    if (trainer_part) repack(st, tr->wqT, w, 1, U, A);
+    if (model_part) {
+        T2_TRY(flat_src(tr, flat, "attention/location_features_convolution/kernel", &w)); T2_TRY(copy(m->conv_w, w, (size_t)K * F));
+        T2_TRY(flat_src(tr, flat, "attention/location_features_convolution/bias", &w)); T2_TRY(copy(m->conv_b, w, F));
+        T2_TRY(flat_src(tr, flat, "attention/location_features_layer/kernel", &w)); T2_TRY(copy(m->wloc, w, (size_t)F * U));
+        T2_TRY(flat_src(tr, flat, "attention/attention_variable", &w)); T2_TRY(copy(m->v_a, w, U));
+        T2_TRY(flat_src(tr, flat, "attention/attention_bias", &w)); T2_TRY(copy(m->b_a, w, U));
+    }
     int pin = M * d.n_feed_frame;
     for (int i = 0; i < np; ++i) {
         const std::string pn = "decoder/prenet_" + std::to_string(i) + "/dense";
         T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
         T2_TRY(flat_src(tr, flat, pn + "/bias", &b));
-        repack(st, m->prenet[i], w, d.prenet_units[i], 1, d.prenet_units[i]);
-        T2_TRY(copy(m->prenet[i].bias, b, d.prenet_units[i]));
-        T2_TRY(copy(m->prenet_plain[i].w, w, (size_t)m->prenet_plain[i].cin * d.prenet_units[i]));
-        T2_TRY(copy(m->prenet_plain[i].shift, b, d.prenet_units[i]));
-        if (i > 0) repack(st, tr->prenetT[i], w, 1, d.prenet_units[i], d.prenet_units[i - 1]);
+        if (model_part) {
+            repack(st, m->prenet[i], w, d.prenet_units[i], 1, d.prenet_units[i]);
+            T2_TRY(copy(m->prenet[i].bias, b, d.prenet_units[i]));
+            T2_TRY(copy(m->prenet_plain[i].w, w, (size_t)m->prenet_plain[i].cin * d.prenet_units[i]));
+            T2_TRY(copy(m->prenet_plain[i].shift, b, d.prenet_units[i]));
+        }
+        if (trainer_part && i > 0) repack(st, tr->prenetT[i], w, 1, d.prenet_units[i], d.prenet_units[i - 1]);
         pin = d.prenet_units[i];
     }
     const char* lname[3] = {"decoder/attention_lstm", "decoder/lstm_1", "decoder/lstm_2"};
@@ -1723,9 +1736,11 @@ extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
     for (int l = 0; l < 3; ++l) {
         T2_TRY(flat_src(tr, flat, std::string(lname[l]) + "/kernel", &w));
         T2_TRY(flat_src(tr, flat, std::string(lname[l]) + "/bias", &b));
-        repack(st, *lp[l], w, 4 * Hh[l], 1, 0);
-        hipLaunchKernelGGL(lstm_bias_pack_kernel, grid1(lp[l]->n_wg * 16), dim3(256), 0, st, lp[l]->bias, b, lp[l]->n_wg, Hh[l]);
-        repack(st, tr->lstmT[l], w, 1, 4 * Hh[l], KXs[l]);
+        if (model_part) {
+            repack(st, *lp[l], w, 4 * Hh[l], 1, 0);
+            hipLaunchKernelGGL(lstm_bias_pack_kernel, grid1(lp[l]->n_wg * 16), dim3(256), 0, st, lp[l]->bias, b, lp[l]->n_wg, Hh[l]);
+        }
+        if (trainer_part) repack(st, tr->lstmT[l], w, 1, 4 * Hh[l], KXs[l]);
     }
     {   // projections: concatenated [D][M*r + 1] operand and its transpose
         const int N = M * r + 1;
@@ -1737,38 +1752,74 @@ extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
         float* wc = tr->tmp;                                      // [D][N]
         HIP_TRY(hipMemcpy2DAsync(wc, (size_t)N * 4, wm, (size_t)M * r * 4, (size_t)M * r * 4, D, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpy2DAsync(wc + M * r, (size_t)N * 4, ws, 4, 4, D, hipMemcpyDeviceToDevice, st));
-        repack(st, m->proj, wc, N, 1, N);
-        HIP_TRY(hipMemcpy2DAsync(m->proj_plain.w, (size_t)m->proj_plain.cout * 4, wc, (size_t)N * 4, (size_t)N * 4, D, hipMemcpyDeviceToDevice, st));
-        T2_TRY(copy(m->proj_plain.shift, bm, (size_t)M * r));
-        T2_TRY(copy(m->proj_plain.shift + M * r, bs, 1));
-        if (m->proj_fused_ok) {        // the composed projection + PreNet-0 operand is built on the host (t2_model_finalize):
-            m->proj_fused_ok = false;  // decode falls back to the separate PreNet-0 launch; cached step graphs are stale
-            for (t2_state* s2 : m->states) for (int i = 0; i < 2; ++i) if (s2->gexec[i]) { (void)hipGraphExecDestroy(s2->gexec[i]); s2->gexec[i] = nullptr; }
+        if (model_part) {
+            repack(st, m->proj, wc, N, 1, N);
+            HIP_TRY(hipMemcpy2DAsync(m->proj_plain.w, (size_t)m->proj_plain.cout * 4, wc, (size_t)N * 4, (size_t)N * 4, D, hipMemcpyDeviceToDevice, st));
+            T2_TRY(copy(m->proj_plain.shift, bm, (size_t)M * r));
+            T2_TRY(copy(m->proj_plain.shift + M * r, bs, 1));
+            if (m->proj_fused_ok) {        // the composed projection + PreNet-0 operand is built on the host (t2_model_finalize):
+                m->proj_fused_ok = false;  // decode falls back to the separate PreNet-0 launch; cached step graphs are stale
+                for (t2_state* s2 : m->states) for (int i = 0; i < 2; ++i) if (s2->gexec[i]) { (void)hipGraphExecDestroy(s2->gexec[i]); s2->gexec[i] = nullptr; }
+            }
+            T2_TRY(copy(m->proj.bias, bm, (size_t)M * r));
+            T2_TRY(copy(m->proj.bias + M * r, bs, 1));
         }
-        repack(st, tr->projT, wc, 1, N, D);
-        T2_TRY(copy(m->proj.bias, bm, (size_t)M * r));
-        T2_TRY(copy(m->proj.bias + M * r, bs, 1));
+        if (trainer_part) repack(st, tr->projT, wc, 1, N, D);
     }
-    cin = M;
-    for (int i = 1; i <= d.postnet_layers; ++i) {
-        const std::string pn = "postnet/conv1d_" + std::to_string(i);
-        const float *g, *be, *mu, *var;
-        ConvLayer& Lc = m->post_convs[i - 1];
-        T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
-        T2_TRY(copy(Lc.w, w, (size_t)d.postnet_kernel * cin * d.postnet_channels));
-        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/gamma", &g));
-        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/beta", &be));
-        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_mean", &mu));
-        T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_variance", &var));
-        hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(d.postnet_channels, 256)), dim3(256), 0, st, g, be, mu, var, d.bn_eps, Lc.scale, Lc.shift, d.postnet_channels);
-        cin = d.postnet_channels;
+    if (model_part) {
+        cin = M;
+        for (int i = 1; i <= d.postnet_layers; ++i) {
+            const std::string pn = "postnet/conv1d_" + std::to_string(i);
+            const float *g, *be, *mu, *var;
+            ConvLayer& Lc = m->post_convs[i - 1];
+            T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
+            T2_TRY(copy(Lc.w, w, (size_t)d.postnet_kernel * cin * d.postnet_channels));
+            T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/gamma", &g));
+            T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/beta", &be));
+            T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_mean", &mu));
+            T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_variance", &var));
+            hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(d.postnet_channels, 256)), dim3(256), 0, st, g, be, mu, var, d.bn_eps, Lc.scale, Lc.shift, d.postnet_channels);
+            cin = d.postnet_channels;
+        }
+        T2_TRY(flat_src(tr, flat, "postnet/projection/kernel", &w));
+        T2_TRY(copy(m->post_proj.w, w, (size_t)d.postnet_channels * M));
+        T2_TRY(flat_src(tr, flat, "postnet/projection/bias", &b));
+        T2_TRY(copy(m->post_proj.shift, b, M));
     }
-    T2_TRY(flat_src(tr, flat, "postnet/projection/kernel", &w));
-    T2_TRY(copy(m->post_proj.w, w, (size_t)d.postnet_channels * M));
-    T2_TRY(flat_src(tr, flat, "postnet/projection/bias", &b));
-    T2_TRY(copy(m->post_proj.shift, b, M));
     // cached decode graphs hold no weight pointers that moved: buffers are updated in place
     HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+// Data-parallel exactness: SUM_BY_NONZERO_WEIGHTS divides by the number of non-zero weights of the WHOLE batch.
+// With counts = {spec, stop} totals over all ranks (dev [2], kept alive by the caller), the backward pass differentiates
+// num_rank / count_total, so the SUM of the ranks' gradients is the gradient of the single-device loss of the whole batch.
+// counts == NULL restores the single-device normalisation.
+extern "C" int t2_trainer_set_loss_counts(t2_trainer* tr, const float* counts) {
+    if (!tr) return fail(T2_EINVAL, "null argument");
+    tr->glob_counts = counts;
+    return T2_OK;
+}
+
+extern "C" int t2_trainer_load_params(t2_trainer* tr, const float* flat) {
+    if (!tr || !flat) return fail(T2_EINVAL, "null argument");
+    T2_TRY(load_params_impl(tr, flat, true, true));
+    tr->m->param_gen += 1;
+    tr->m->last_flat = flat;
+    tr->gen = tr->m->param_gen;
+    return T2_OK;
+}
+
+// A trainer whose own operands were built from an older parameter generation (another trainer of the same model loaded newer
+// parameters, or this trainer was created after a refresh: trainer_setup_backward packs from the INITIAL host weights) rebuilds
+// them from the flat buffer of the last t2_trainer_load_params, which the caller keeps alive and unchanged between the refresh
+// and the next backward pass (training.Trainer.train_step does).
+static int trainer_sync_params(t2_trainer* tr) {
+    t2_model* m = tr->m;
+    if (tr->gen == m->param_gen) return T2_OK;
+    if (m->last_flat == nullptr) return fail(T2_ESTATE, "internal: parameters were refreshed without a flat buffer");
+    T2_TRY(load_params_impl(tr, m->last_flat, false, true));
+    tr->gen = m->param_gen;
     return T2_OK;
 }
 

@@ -4,8 +4,11 @@ the two losses, the learning-rate schedule (T3) and t
 data-parallel gradient exchange of section 8e.  No arithmetic happens in Python or torch here:
 torch provides device memory and the RCCL all-reduce (``torch.distributed`` backend "nccl").
 
-The backward pass that produces the gradients is not built yet; ``AdamOptimizer.apply_gradients``
-takes the flat gradient buffer from its caller."""
+``Trainer`` runs the whole step on the device (training-mode forward with a tape, hand-written backward, clip + Adam, weight
+refresh); ``AdamOptimizer.apply_gradients`` takes the flat gradient buffer it fills.  Difference from the reference worth
+knowing: ``dynamic_decode`` caps the training decode at ``maximum_iterations=max_iters`` too (tacotron_v1.py:150) while a
+``Trainer`` runs exactly the S steps of its targets -- under the reference, targets longer than max_iters * r never reach the
+model (the dataset filters them, datasets/dataset.py:172-177), and ``datasets.py`` here applies the same filter."""
 from __future__ import annotations
 
 import ctypes as C
@@ -114,6 +117,30 @@ def flatten(weights: Dict[str, np.ndarray], spec=None) -> np.ndarray:
 def unflatten(flat, spec) -> Dict[str, np.ndarray]:
     flat = flat.detach().cpu().numpy() if isinstance(flat, torch.Tensor) else np.asarray(flat)
     return {name: flat[off:off + size].reshape(shape).copy() for name, shape, off, size in spec}
+
+
+def _world(group=None) -> int:
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def global_loss_counts(spec_loss_mask, binary_loss_mask, num_mels: int, group=None) -> torch.Tensor:
+    """[count_nonzero(spec weights broadcast over num_mels), count_nonzero(stop weights)] of the WHOLE data-parallel batch
+    (sum all-reduce over ranks): the denominators of tf.losses' SUM_BY_NONZERO_WEIGHTS for a single-device batch of all
+    ranks' rows (models.py:136-148).  Works on CPU (gloo) and device (RCCL) tensors."""
+    import torch.distributed as dist
+    m1, m2 = torch.as_tensor(spec_loss_mask), torch.as_tensor(binary_loss_mask)
+    cnt = torch.stack([(m1 != 0).sum().to(torch.float32) * float(num_mels), (m2 != 0).sum().to(torch.float32)])
+    if _world(group) > 1:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    return cnt
+
+
+def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    import torch.distributed as dist
+    if _world(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
 
 
 def allreduce_gradients(flat_grads: torch.Tensor, group=None) -> float:
@@ -271,21 +298,61 @@ class Trainer:
         with self.engine._ordered():
             _lib.check(self.engine.lib.t2_trainer_update_moving_stats(self._h, flat_params.data_ptr(), float(momentum)))
 
+    def set_loss_counts(self, counts: Optional[torch.Tensor]):
+        """counts dev [2] from ``global_loss_counts`` (or None: this rank's own): normalisation of the next backward passes."""
+        self._counts = None if counts is None else self.engine._f32(counts)            # kept alive: the library holds the pointer
+        with self.engine._ordered():
+            _lib.check(self.engine.lib.t2_trainer_set_loss_counts(self._h, None if self._counts is None else self._counts.data_ptr()))
+
     def train_step(self, optimizer, flat_params, flat_grads, features, labels, global_step=0, seed=0, prenet_drop_rate=0.5,
                    encoder_drop_rate=0.5, clip_norm=1.0, group=None):
         """model_fn(mode=TRAIN) of the reference (models.py:44-76) for the V2 blocks: training-mode forward, loss = spec_loss +
         binary_loss, backward, gradient all-reduce over the data-parallel group (RCCL), clip_by_global_norm + Adam, moving
-        statistics, weights refreshed on the device.  Returns (global_step + 1, losses dev [3] = mel, done, total)."""
+        statistics, weights refreshed on the device.  Returns (global_step + 1, losses dev [3] = mel, done, total).
+
+        Data parallel (world > 1): the ranks first sum their non-zero loss-weight counts; every rank's backward then
+        differentiates sum_rank / count_total, the gradients are SUMMED (one all-reduce of the flat buffer, no 1/world) and the
+        reported losses are sum of numerators / sum of counts -- N ranks x B rows give the gradient and the loss of one batch
+        of N x B rows under SUM_BY_NONZERO_WEIGHTS.  What stays per replica, as SURVEY.md 8e says: batch-norm batch statistics;
+        the moving statistics are averaged over ranks so that every rank keeps identical parameters."""
+        d = self.engine.dims
+        world = _world(group)
         flat_grads.zero_()
+        counts = None
+        if world > 1:
+            counts = global_loss_counts(self.engine._f32(labels["spec_loss_mask"]), self.engine._f32(labels["binary_loss_mask"]), d.num_mels, group)
+        self.set_loss_counts(counts)
         memory, _ = self.encoder_forward(features["source"], features["source_length"], drop_rate=encoder_drop_rate, seed=seed)
         self.decoder_forward(memory, features["source_length"], labels["mel"], prenet_drop_rate=prenet_drop_rate, seed=seed)
         dmem, losses = self.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat_grads)
         self.encoder_backward(dmem, flat_grads)
-        scale = allreduce_gradients(flat_grads, group)
-        step = optimizer.apply_gradients(flat_grads, flat_params, global_step=global_step, clip_norm=clip_norm, grad_scale=scale)
+        if world > 1:
+            allreduce_sum(flat_grads, group)                                     # gradients of sum_rank / count_total: plain sum
+            m1, m2 = self.engine._f32(labels["spec_loss_mask"]), self.engine._f32(labels["binary_loss_mask"])
+            own = torch.stack([(m1 != 0).sum().to(torch.float32) * float(d.num_mels), (m2 != 0).sum().to(torch.float32)])
+            num = allreduce_sum(losses[:2] * own, group)                         # numerators: local ratio x local count
+            mel_loss, done_loss = num[0] / counts[0].clamp(min=1), num[1] / counts[1].clamp(min=1)
+            losses = torch.stack([mel_loss, done_loss, mel_loss + done_loss])
+        step = optimizer.apply_gradients(flat_grads, flat_params, global_step=global_step, clip_norm=clip_norm, grad_scale=1.0)
         self.update_moving_stats(flat_params)
+        if world > 1:
+            self._average_moving_stats(flat_params, group, world)
         self.load_params(flat_params)
         return step, losses
+
+    def _average_moving_stats(self, flat_params, group, world):
+        """Every rank updated the batch-norm moving statistics with its own batch statistics: average them so that the
+        parameter buffers stay identical on all ranks (one small all-reduce)."""
+        sl = [(off, size) for name, shape, off, size in self._spec if name.endswith("/moving_mean") or name.endswith("/moving_variance")]
+        if not sl:
+            return
+        packed = torch.cat([flat_params[o:o + n] for o, n in sl])
+        allreduce_sum(packed, group)
+        packed /= float(world)
+        pos = 0
+        for o, n in sl:
+            flat_params[o:o + n] = packed[pos:pos + n]
+            pos += n
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self.engine, "_model", None):

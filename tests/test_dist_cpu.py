@@ -91,3 +91,66 @@ def test_two_rank_gradient_and_loss_exchange():
     m_all = np.concatenate([res[0][5], res[1][5]])
     num, cnt = O.loss_parts(l_all, m_all[:, :, None])
     assert abs(res[0][3] - num / cnt) < 1e-6 and res[0][3] == res[1][3]
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import torch_train as TT
+    from tacotron2_amd import training as TR
+    d, w, ids, lens, labels = _dp_case()
+    rows = np.arange(3 * rank, 3 * rank + 3)
+    lab = {k: v[rows] for k, v in labels.items()}
+    counts = TR.global_loss_counts(lab["spec_loss_mask"], lab["binary_loss_mask"], d.num_mels)      # sum all-reduce over the ranks
+    ref = TT.train_forward_backward(d, w, ids[rows], lens[rows], lab, seed=5, prenet_drop_rate=0.0, encoder_drop_rate=0.0,
+                                    loss_counts=(float(counts[0]), float(counts[1])))
+    names = sorted(ref["grads"])
+    g = torch.tensor(np.concatenate([ref["grads"][k].reshape(-1) for k in names]))
+    TR.allreduce_sum(g)                                                    # the step's one gradient all-reduce: plain SUM
+    loss = TR.allreduce_sum(torch.tensor([ref["loss"]], dtype=torch.float64))
+    q.put((rank, g.numpy(), float(loss[0]), counts.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dp_case():
+    from tacotron2_amd.hparams import PROFILE_TINY
+    from tacotron2_amd.weights import init_weights
+    d = PROFILE_TINY.replace(enc_conv_layers=0, embedding_dim=10, zoneout_cell=0.0, zoneout_output=0.0)     # nothing but the loss couples the rows
+    w = init_weights(d, 2, perturb=True)
+    rng = np.random.default_rng(9)
+    B, T, S, r = 6, 7, 4, d.outputs_per_step
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    lens = np.array([T, 4, 6, T, 3, 5], np.int64)
+    tl = np.array([S * r, 3, 5, S * r, 2, 7])
+    sl = (tl + r - 1) // r
+    labels = {"mel": rng.uniform(0, 1, (B, S * r, d.num_mels)).astype(np.float32),
+              "done": (np.arange(S)[None, :] >= (sl[:, None] - 1)).astype(np.float32),
+              "spec_loss_mask": (np.arange(S * r)[None, :] < tl[:, None]).astype(np.float32),
+              "binary_loss_mask": (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)}
+    return d, w, ids, lens, labels
+
+
+def test_two_rank_training_step_is_loss_exact():
+    """two ranks x 3 rows = one batch of 6 rows under SUM_BY_NONZERO_WEIGHTS (models.py:136-148): the ranks sum
+    their non-zero weight counts, each differentiates sum_rank / count_total, and the plain SUM of the gradients (and of the
+    loss shares) equals the single-process gradient (loss) of the whole batch -- on the oracle, over gloo."""
+    from oracle import torch_train as TT
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d, w, ids, lens, labels = _dp_case()
+    full = TT.train_forward_backward(d, w, ids, lens, labels, seed=5, prenet_drop_rate=0.0, encoder_drop_rate=0.0)
+    names = sorted(full["grads"])
+    g_full = np.concatenate([full["grads"][k].reshape(-1) for k in names])
+    for r in res:
+        np.testing.assert_allclose(r[1], g_full, atol=1e-6 * float(np.abs(g_full).max()) + 1e-9)
+        assert abs(r[2] - full["loss"]) < 1e-6
+        assert r[3][0] == float((labels["spec_loss_mask"] != 0).sum() * d.num_mels) and r[3][1] == float((labels["binary_loss_mask"] != 0).sum())

@@ -337,3 +337,120 @@ def test_training_step_on_a_pipeline_batch():
     for o in (tr, eng):
         o.close()
     opt.close()
+
+
+def test_two_trainers_of_one_model_share_refreshed_parameters():
+    """A model trains on batches of changing shape through several trainers (one per (B, T_in, S)).  Each trainer owns the
+    transposed operands of its backward pass: a trainer that did not run the last parameter refresh, or that was created
+    after one, must rebuild them before its next backward.  The parameters are moved by a LARGE step between the passes, so
+    stale operands would show in every gradient."""
+    import torch
+    from oracle import torch_train as TT
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    d = MID
+    w = init_weights(d, 19, perturb=True)
+    eng = Engine(d, w)
+    rng = np.random.default_rng(8)
+    shapes = [(4, 11, 5), (3, 9, 4)]
+    data = []
+    for (B, T, S) in shapes:
+        ids = rng.integers(0, d.num_symbols, (B, T))
+        lens = rng.integers(T // 2, T + 1, size=B).astype(np.int64)
+        lens[0] = T
+        labels = _labels(rng, B, S, d.outputs_per_step)
+        labels["mel"] = rng.uniform(0, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+        data.append((ids, lens, labels))
+    spec = TR.flatten_spec(w)
+    flat = torch.tensor(TR.flatten(w, spec), device="cuda")
+    trainers = {}
+
+    def check(which, seed):
+        ids, lens, labels = data[which]
+        B, T, S = shapes[which]
+        if which not in trainers:
+            trainers[which] = TR.Trainer(eng, B, T, S)
+            trainers[which].bind_gradients(spec)
+        tr = trainers[which]
+        w_now = TR.unflatten(flat, spec)
+        ref = TT.train_forward_backward(d, w_now, ids, lens, labels, seed=seed, prenet_drop_rate=0.5, encoder_drop_rate=0.5)
+        g = torch.zeros_like(flat)
+        memory, _ = tr.encoder_forward(ids, lens, drop_rate=0.5, seed=seed)
+        tr.decoder_forward(memory, lens, labels["mel"], prenet_drop_rate=0.5, seed=seed)
+        dmem, losses = tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], g)
+        tr.encoder_backward(dmem, g)
+        assert abs(float(losses[2]) - ref["loss"]) < 2e-4 * max(1.0, abs(ref["loss"]))
+        got = TR.unflatten(g, spec)
+        bad = []
+        for name, g_ref in sorted(ref["grads"].items()):
+            scale = float(np.abs(g_ref).max())
+            err = float(np.abs(got[name] - g_ref).max())
+            if err > 1e-3 * scale + 1e-6:
+                bad.append((name, err, scale))
+        assert not bad, (which, bad)
+        return tr
+
+    def move(tr, seed):                                  # a big parameter step, refreshed through ONE trainer
+        noise = torch.tensor(np.random.default_rng(seed).standard_normal(flat.numel()).astype(np.float32), device="cuda")
+        keep = torch.ones_like(flat)
+        for name, shape, off, size in spec:              # keep the moving variances positive
+            if name.endswith("moving_variance"):
+                keep[off:off + size] = 0
+        flat.add_(0.05 * noise * keep)
+        tr.load_params(flat)
+
+    t0 = check(0, 60)
+    move(t0, 1)
+    t1 = check(1, 61)                                    # created AFTER a refresh: its operands must not come from the initial weights
+    move(t1, 2)
+    check(0, 62)                                         # lags one refresh behind: must rebuild before its backward
+    check(1, 63)
+    for tr in trainers.values():
+        tr.close()
+    eng.close()
+
+
+def test_data_parallel_loss_normalisation_is_exact():
+    """with the loss counts of the WHOLE batch (t2_trainer_set_loss_counts) the SUM of two half-batch gradients is
+    the gradient of the full batch under SUM_BY_NONZERO_WEIGHTS -- checked where nothing else couples rows (no batch norm, no
+    sampled masks: they are keyed by the local row index)."""
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    d = MID.replace(enc_conv_layers=0, zoneout_cell=0.0, zoneout_output=0.0)
+    w = init_weights(d, 23, perturb=True)
+    eng = Engine(d, w)
+    rng = np.random.default_rng(12)
+    B, T, S = 6, 10, 5
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    lens = np.array([T, 6, 9, T, 5, 7], np.int64)           # both halves contain a full-length row: same padded width
+    labels = _labels(rng, B, S, d.outputs_per_step)
+    labels["mel"] = rng.uniform(0, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+    spec = TR.flatten_spec(w)
+    n = TR.flat_size(spec)
+
+    def grad_of(rows, counts):
+        tr = TR.Trainer(eng, len(rows), T, S)
+        tr.bind_gradients(spec)
+        tr.set_loss_counts(counts)
+        g = torch.zeros(n, dtype=torch.float32, device="cuda")
+        lab = {k: v[rows] for k, v in labels.items()}
+        memory, _ = tr.encoder_forward(ids[rows], lens[rows], drop_rate=0.0, seed=1)
+        tr.decoder_forward(memory, lens[rows], lab["mel"], prenet_drop_rate=0.0, seed=1)
+        dmem, losses = tr.decoder_backward(lab["done"], lab["spec_loss_mask"], lab["binary_loss_mask"], g)
+        tr.encoder_backward(dmem, g)
+        out = g.clone(), _np(losses).copy()
+        tr.close()
+        return out
+
+    full, loss_full = grad_of(np.arange(B), None)
+    counts = TR.global_loss_counts(labels["spec_loss_mask"], labels["binary_loss_mask"], d.num_mels)       # world 1: the whole batch
+    ga, la = grad_of(np.arange(0, 3), counts)
+    gb, lb = grad_of(np.arange(3, 6), counts)
+    scale = float(full.abs().max())
+    assert float((ga + gb - full).abs().max()) <= 2e-5 * scale
+    # and the plain mean of the two half-batch gradients (the old exchange) is NOT that gradient when the masks are ragged
+    ha, _ = grad_of(np.arange(0, 3), None)
+    hb, _ = grad_of(np.arange(3, 6), None)
+    assert float((0.5 * (ha + hb) - full).abs().max()) > 1e-3 * scale
+    eng.close()
