@@ -44,7 +44,7 @@ def make_inputs(B, t_lo, t_hi, seed):
     return ids, lens.astype(np.int64)
 
 
-def lstm_algorithmic(d, B):
+def _unused_lstm_algorithmic(d, B):
     """Algorithmic FLOPs / bytes of ONE decoder-LSTM launch, averaged over the three launches of a
     decoder step (attention LSTM, LSTM 1, LSTM 2) -- DESIGN.md "Roofline accounting"."""
     P2, E, A, D = d.prenet_units[-1], d.enc_units, d.attention_lstm_units, d.decoder_lstm_units
@@ -151,71 +151,60 @@ def main():
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
         }
 
-    # ---- roofline of the dominant kernel (decoder LSTM step): live HIP-event timing on the library's
-    # stream of a graph-replayed decode that launches ONLY the three LSTM kernels of every step
-    # (same operands, same launch geometry, back to back; outputs are not used) ----
+    # ---- roofline of the dominant kernel: pz::decode_kernel<4> (csrc/persist.h), ONE launch = the whole free-running decode
+    # of the batch (all S decoder steps).  Live HIP-event timing on the library's stream around the decode (the events also
+    # bracket the per-utterance set-up -- memory mask, keys GEMM, state memset: < 1 % at S = 400).  Algorithmic work per launch
+    # = S x the per-step figures of SURVEY.md 8d (Fd, Bd), both stated in DESIGN.md. ----
     if rank == 0:
         memory = eng.encode(ids, lens)
-        n_steps = 96
-        lb = eng.decode_free_buffers(B, T_in, n_steps)
-        eng.set_option("lstm_only", 1)
-        eng.set_option("hoist", 0)            # whole-K launches: one kernel = one LSTM layer's gate GEMM + cell
-        eng.decode_free_launch(memory, lens, n_steps, d.min_iters, lb)       # warm-up + graph capture
-        eng.decode_free_finish()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        eng.decode_free_launch(memory, lens, n_steps, d.min_iters, lb, events=(e0, e1))
-        eng.decode_free_finish()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        n_l = 3 * n_steps
-        # the production split of the same GEMMs (recurrent halves as jobs of their own)
-        eng.set_option("hoist", 1)
-        eng.decode_free_launch(memory, lens, n_steps, d.min_iters, lb)
-        eng.decode_free_finish()
-        eng.decode_free_launch(memory, lens, n_steps, d.min_iters, lb, events=(e0, e1))
-        eng.decode_free_finish()
-        torch.cuda.synchronize()
-        ms_split = e0.elapsed_time(e1)
-        eng.set_option("lstm_only", 0)
-        for kv in args.opt:
-            k, v = kv.split("=")
-            eng.set_option(k, int(v))
-        # the whole production decoder step (all launches, riders included), same HIP-event timing
-        eng.decode_free_launch(memory, lens, S, d.min_iters, bufs, events=(e0, e1))       # the bench's own decode: S steps
-        eng.decode_free_finish()
-        torch.cuda.synchronize()
-        ms_step = e0.elapsed_time(e1) / S          # includes the per-utterance set-up (memory mask, keys): < 1 % at S = 400
+        reps, ms_list = 5, []
+        for _ in range(reps):
+            eng.decode_free_launch(memory, lens, S, d.min_iters, bufs, events=(e0, e1))
+            n_dec = eng.decode_free_finish()
+            torch.cuda.synchronize()
+            ms_list.append(e0.elapsed_time(e1))
+        ms_dec = float(np.mean(ms_list))
+        persist_ran = eng.get_stat("persist_launches") > 0
         P2_, E_, A_, D_, U_ = d.prenet_units[-1], d.enc_units, d.attention_lstm_units, d.decoder_lstm_units, d.attention_dim
         wd = (M * d.n_feed_frame * d.prenet_units[0] + d.prenet_units[0] * P2_ + (P2_ + E_ + A_) * 4 * A_ + A_ * U_ +
               (A_ + E_ + D_) * 4 * D_ + 2 * D_ * 4 * D_ + D_ * (M * r + 1))
         step_flops = B * (2.0 * wd + T_in * (2 * d.attention_kernel * d.attention_filters + 2 * d.attention_filters * U_ + 6 * U_ + 2 * E_ + 8))
-        flops, byts = lstm_algorithmic(d, B)
-        avg_s = ms * 1e-3 / max(n_l, 1)
-        achieved = flops / avg_s / 1e12
-        traffic = step_traffic = None
+        step_bytes = 4.0 * (wd + d.attention_kernel * d.attention_filters + d.attention_filters * U_) + \
+            B * 4.0 * (T_in * (U_ + E_) + 3 * T_in + 2 * 2 * (A_ + 2 * D_) + M * d.n_feed_frame + M * r + 1)
+        flops_launch, bytes_launch = step_flops * n_dec, step_bytes * n_dec
+        achieved = flops_launch / (ms_dec * 1e-3) / 1e12
+        traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("lstm_step_hbm_bytes_per_launch")
-                step_traffic = tj.get("decoder_step_production", {}).get("hbm_bytes_per_step")
+                traffic = json.load(open(tpath)).get("r02_persistent_decode_b64", {}).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = step_traffic = None
-        out["roofline"] = {"kernel": "lstm_step_kernel<4,false> (decoder LSTM step, B=64)", "bound": "mfma",
-                           "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                traffic = None
+        # the launch-per-phase schedule of round 1 (6 launches per step, hipGraph chunks), same decode, for comparison
+        eng.set_option("persist", 0)
+        eng.decode_free_launch(memory, lens, S, d.min_iters, bufs)
+        eng.decode_free_finish()
+        eng.decode_free_launch(memory, lens, S, d.min_iters, bufs, events=(e0, e1))
+        eng.decode_free_finish()
+        torch.cuda.synchronize()
+        ms_launches = e0.elapsed_time(e1)
+        eng.set_option("persist", 1)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            eng.set_option(k, int(v))
+        out["roofline"] = {"kernel": "pz::decode_kernel<4> (persistent free-running decoder: one launch = %d decoder steps of the B=%d batch)" % (n_dec, B)
+                                     if persist_ran else "launch-per-phase schedule (persistent decoder not eligible)",
+                           "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                           "avg_launch_us": avg_s * 1e6, "launches_timed": int(n_l),
-                           "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
-                           "lstm_gemm_us_per_decoder_step": {"whole_k_3_launches": ms * 1e3 / n_steps,
-                                                             "split_6_launches_standalone": ms_split * 1e3 / n_steps},
-                           "whole_decoder_step": {"us_per_step": ms_step * 1e3, "algorithmic_flops_per_step": step_flops,
-                                                  "achieved_TFLOPs": step_flops / (ms_step * 1e-3) / 1e12,
-                                                  "frac_of_fp32_mfma_peak": step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                                  "traffic_bytes_per_step": step_traffic,
-                                                  "note": "all launches of the production schedule (hoisted products riding in the "
-                                                          "PreNet / attention / projection launches), SURVEY.md 8d formula Fd"},
-                           "hbm_side": {"achieved_GBs": byts / avg_s / 1e9, "peak_GBs": HBM_PEAK_GBS,
-                                        "frac": byts / avg_s / 1e9 / HBM_PEAK_GBS}}
+                           "avg_launch_ms": ms_dec, "launches_timed": reps, "us_per_decoder_step": ms_dec * 1e3 / n_dec,
+                           "algorithmic_flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": bytes_launch,
+                           "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,
+                           "hbm_side": {"achieved_GBs": bytes_launch / (ms_dec * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                                        "frac": bytes_launch / (ms_dec * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                           "launch_schedule_round1": {"us_per_decoder_step": ms_launches * 1e3 / n_dec,
+                                                      "frac_of_fp32_mfma_peak": step_flops / (ms_launches * 1e-3 / n_dec) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                                      "note": "same decode with option persist=0: 6 launches per step replayed from hipGraph chunks"}}
 
     # ---- batch-1 latency / RTF (BASELINE.json configs[1]) ----
     if rank == 0 and not args.no_batch1:
@@ -254,7 +243,7 @@ def main():
                          "decode_only_us_per_step": us_step,
                          "hbm_roofline": {"algorithmic_bytes_per_step": bytes_step, "achieved_GBs": bytes_step / us_step / 1e3,
                                           "peak_GBs": HBM_PEAK_GBS, "frac": bytes_step / us_step / 1e3 / HBM_PEAK_GBS,
-                                          "note": "latency-bound: 6 dependent launches per step, not the weight stream"}}
+                                          "note": "persistent decoder: latency-bound by its 5 all-to-all hops + 3 group hops per step, not by the weight stream"}}
 
     # ---- teacher-forced decoder forward, B = 1, 100 characters / 800 frames (BASELINE.json configs[0], the reference's own
     # CPU-runnable case): encoder + teacher-forced decode + PostNetV2 on the GPU, the NumPy port on the host beside it ----
@@ -278,13 +267,30 @@ def main():
                                                     "T_in=100, %d frames" % (S * r), "ms": dt0 * 1e3, "frames_per_s": S * r / dt0}
             if world == 1 and not args.no_cpu_baseline:
                 from oracle import t2_oracle as O
-                tc = time.perf_counter()
-                mem_o = O.encoder_v2(d, w, O.embedding_lookup(ids0, w["embedding"]), lens0)
-                mel_o, _, _ = O.decoder_v2(d, w, mem_o, is_validation=True, teacher_forcing=True, memory_sequence_length=lens0,
-                                           target=tgt0.cpu().numpy(), max_iters=S)
-                O.postnet_v2(d, w, mel_o)
-                dtc = time.perf_counter() - tc
-                out["teacher_forced_b1"]["cpu_port"] = {"ms": dtc * 1e3, "frames_per_s": S * r / dtc, "kind": "port",
+
+                def cpu_once(steps):
+                    tc = time.perf_counter()
+                    mem_o = O.encoder_v2(d, w, O.embedding_lookup(ids0, w["embedding"]), lens0)
+                    mel_o, _, _ = O.decoder_v2(d, w, mem_o, is_validation=True, teacher_forcing=True, memory_sequence_length=lens0,
+                                               target=tgt0.cpu().numpy()[:, :steps * r], max_iters=steps)
+                    O.postnet_v2(d, w, mel_o)
+                    return time.perf_counter() - tc, mel_o
+                # protocol of SURVEY.md 8d: warm-up, then the median of 3 runs on all host threads; the 1-thread figure on a
+                # quarter of the steps (scaled), also the median of 3
+                cpu_once(S // 8)
+                runs = [cpu_once(S) for _ in range(3)]
+                dtc = float(np.median([t_ for t_, _ in runs]))
+                mel_o = runs[-1][1]
+                one = None
+                try:
+                    from threadpoolctl import threadpool_limits
+                    with threadpool_limits(limits=1):
+                        one = float(np.median([cpu_once(S // 4)[0] for _ in range(3)])) * 4.0
+                except Exception:
+                    one = None
+                out["teacher_forced_b1"]["cpu_port"] = {"ms": dtc * 1e3, "frames_per_s": S * r / dtc, "kind": "port", "runs": 3, "statistic": "median",
+                                                        "one_thread_ms_scaled_from_quarter": None if one is None else one * 1e3,
+                                                        "one_thread_frames_per_s": None if one is None else S * r / one,
                                                         "max_abs_mel_diff": float(np.abs(mel_t.cpu().numpy() - mel_o).max())}
         except Exception as ex:
             out["teacher_forced_b1"] = {"error": repr(ex)}
@@ -346,18 +352,32 @@ def main():
         t_b = time.perf_counter()
         mel_o, _, _ = O.decoder_v2(d, w, mem_o, memory_sequence_length=lens, max_iters=sample_steps)
         t_c = time.perf_counter()
-        O.postnet_v2(d, w, mel_o)
+        post_cpu = O.postnet_v2(d, w, mel_o)
         t_d = time.perf_counter()
         scale = S / sample_steps
         cpu_total = (t_b - t_a) + ((t_c - t_b) + (t_d - t_c)) * scale
+        cpu_model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except Exception:
+            pass
         out["cpu_baseline"] = {"value": B * S * r / cpu_total, "unit": "mel frames/s", "cores": int(cores),
-                               "kind": "port",
+                               "kind": "port", "cpu_model": cpu_model, "os_cpu_count": os.cpu_count(),
                                "sample": "NumPy oracle (CPU restatement, not TensorFlow), the same B=%d batch once: encoder "
                                          "(%.2fs) + %d of %d decoder steps (%.2fs) + PostNetV2 on those %d frames/utt "
                                          "(%.2fs); scale x%.0f" % (B, t_b - t_a, sample_steps, S, t_c - t_b, sample_steps * r, t_d - t_c, scale)}
         # parity spot check of the timed configuration: first sample_steps steps of the GPU decode
         got = bufs[0][:, :sample_steps * r].cpu().numpy()
-        out["parity_check"] = {"max_abs_mel_diff_first_20_steps": float(np.abs(got[:, :20 * r] - mel_o[:, :20 * r]).max()),
+        memory_g = eng.encode(ids, lens)
+        eng.decode_free_launch(memory_g, lens, S, d.min_iters, bufs)
+        n_g = eng.decode_free_finish()
+        got = bufs[0][:, :sample_steps * r].cpu().numpy()
+        post_g = eng.postnet(bufs[0][:, :n_g * r]).cpu().numpy()
+        out["parity_check"] = {"max_abs_mel_postnet_diff_B64x%d_frames" % (n_g * r): float(np.abs(post_g - post_cpu).max()),
+                               "max_abs_mel_diff_first_20_steps": float(np.abs(got[:, :20 * r] - mel_o[:, :20 * r]).max()),
                                "max_abs_mel_diff_all_%d_free_running_steps" % sample_steps: float(np.abs(got - mel_o).max())}
 
     if rank == 0:
