@@ -127,3 +127,65 @@ def test_edge_single_position_and_limits(paper):
         eng.decode_free(_np(mem), np.array([0]), max_iters=2)
     with pytest.raises(T2Error):                                         # T_out not a multiple of r
         eng.decode_teacher(mem, np.array([1]), np.zeros((1, 3, d.num_mels), np.float32))
+
+
+def test_postnet_at_bench_shape_against_oracle(paper):
+    """PostNetV2 (tacotron_v2.py:181-204) at the shape bench.py times: B = 64 x 800 frames at profile P, where launch_conv picks
+    the 128-row tiles of conv_gemm_fast_kernel<2> (smaller inputs land on the 64-row variant)."""
+    d, w, eng, ids, lens = paper
+    rng = np.random.default_rng(11)
+    mel = rng.uniform(-0.2, 1.2, (64, 800, d.num_mels)).astype(np.float32)
+    post = eng.postnet(mel)
+    np.testing.assert_allclose(_np(post), O.postnet_v2(d, w, mel), atol=2e-4)
+    eng.set_option("conv_generic", 1)                    # and the generic conv kernel on the same input
+    try:
+        np.testing.assert_allclose(_np(eng.postnet(mel)), _np(post), atol=1e-5)
+    finally:
+        eng.set_option("conv_generic", 0)
+
+
+def test_training_gradients_at_bench_shape_against_autograd():
+    """The training step at the sizes bench.py times (profile P, B = 32, T_in = 140; 4 decoder steps keep the fp64 autograd
+    reference to ~30 s): the profile-P instantiations of the backward kernels (bwd_dense_kernel<2> with static ring, nine
+    position chunks per row in the attention backward at U = 128, split-K weight-gradient GEMMs) against torch.autograd."""
+    import torch
+    from oracle import torch_train as TT
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    d = PROFILE_P
+    w = init_weights(d, seed=5, perturb=True)
+    rng = np.random.default_rng(1)
+    B, T, S, r = 32, 140, 4, d.outputs_per_step
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    lens = rng.integers(60, T + 1, B).astype(np.int64)
+    lens[0] = T
+    tl = rng.integers(S * r // 2, S * r + 1, B)
+    tl[0] = S * r
+    sl = (tl + r - 1) // r
+    labels = {"mel": rng.uniform(0, 1, (B, S * r, d.num_mels)).astype(np.float32),
+              "done": (np.arange(S)[None, :] >= (sl[:, None] - 1)).astype(np.float32),
+              "spec_loss_mask": (np.arange(S * r)[None, :] < tl[:, None]).astype(np.float32),
+              "binary_loss_mask": (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)}
+    ref = TT.train_forward_backward(d, w, ids, lens, labels, seed=3, prenet_drop_rate=0.5, encoder_drop_rate=0.5)
+    eng = Engine(d, w)
+    tr = TR.Trainer(eng, B, T, S)
+    spec = TR.flatten_spec(w)
+    tr.bind_gradients(spec)
+    memory, _ = tr.encoder_forward(ids, lens, drop_rate=0.5, seed=3)
+    np.testing.assert_allclose(_np(memory), ref["memory"], atol=ATOL)
+    mel, stop, align = tr.decoder_forward(memory, lens, labels["mel"], prenet_drop_rate=0.5, seed=3)
+    np.testing.assert_allclose(_np(mel), ref["mel"], atol=ATOL)
+    flat = torch.zeros(TR.flat_size(spec), dtype=torch.float32, device="cuda")
+    dmem, losses = tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat)
+    tr.encoder_backward(dmem, flat)
+    assert abs(float(losses[2]) - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+    grads = TR.unflatten(flat, spec)
+    bad = []
+    for name, g_ref in sorted(ref["grads"].items()):
+        scale = float(np.abs(g_ref).max())
+        err = float(np.abs(grads[name] - g_ref).max())
+        if err > 1e-3 * scale + 1e-6:
+            bad.append((name, err, scale))
+    assert not bad, bad
+    tr.close()
+    eng.close()
