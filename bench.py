@@ -101,7 +101,17 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     B, S, r, M = args.batch, args.max_iters, d.outputs_per_step, d.num_mels
-    ids, lens = make_inputs(B, 60, 140, seed=1234 + 3 + 1000 * rank)       # each rank its own shard
+    # The job = world x B utterances, T_in ~ U{60..140}; the product's sharding code (tacotron2_amd/sharding.py, used by
+    # synthesize.synthesize_sharded) sorts them by length, cuts "reference batches" of B rows and deals batch b to rank
+    # b % world: every rank gets exactly one batch here, no data-path collective.
+    from tacotron2_amd.sharding import make_batches, shard_batches
+    ids_all, lens_all = make_inputs(B * world, 60, 140, seed=1234 + 3)
+    batches = make_batches(lens_all, B)
+    mine = shard_batches(len(batches), world, rank)
+    assert len(mine) == 1
+    rows = batches[mine[0]]
+    lens = lens_all[rows]
+    ids = np.ascontiguousarray(ids_all[rows][:, :int(lens.max())])
     T_in = ids.shape[1]
     bufs = eng.decode_free_buffers(B, T_in, S)
 
@@ -148,7 +158,8 @@ def main():
                                    "profile P (paper sizes), T_in~U{60..140}, decode to max_iters=%d steps (r=2 -> %d "
                                    "frames/utterance), encoder + decoder + PostNetV2, random-init weights" % (S, S * r),
                        "batch_per_gpu": B, "T_in": int(T_in), "decoder_steps": S,
-                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
+                       "parallelism": "batch-sharded x%d (utterances of the job sorted by length, dealt as batches of %d: "
+                                      "tacotron2_amd/sharding.py), no data-path collective" % (world, B)},
         }
 
     # ---- roofline of the dominant kernel: pz::decode_kernel<4> (csrc/persist.h), ONE launch = the whole free-running decode

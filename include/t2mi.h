@@ -100,6 +100,17 @@ int t2_encode_embedded(t2_model* m, const float* emb, const int64_t* lens, int B
 /* PostNetV2.call (tacotron_v2.py:200-204): mel dev [B,T_out,M] -> mel_post dev [B,T_out,M]. */
 int t2_postnet(t2_model* m, const float* mel, int B, int T_out, float* mel_post);
 
+/* Stand-alone layers / cells of the reference's protocol (API parity: the decode loops never go through these).
+ * t2_dense: tf.layers.Dense as PreNet.call uses it without dropout (modules.py:88-91) -- y[rows][N] = act(x[rows][K] . kernel[K][N]
+ * + bias[N]); activation 0 none, 1 relu, 2 tanh; bias may be NULL.  All pointers dev.
+ * t2_zoneout_lstm_cell: ZoneoutLSTMCell.__call__ with is_training = False (modules.py:261-283 over tf.nn.rnn_cell.LSTMCell,
+ * rnn_impl.py:25-33): xh dev [B][K] = concat(inputs, h_prev), kernel dev [K][4H] (column blocks i | j | f | o), bias dev [4H];
+ * z_ws dev [B][4H] workspace; outputs h_raw (the cell's output), c_new / h_new (the zoned state), dev [B][H]. */
+int t2_dense(t2_ctx* ctx, const float* x, const float* kernel, const float* bias, int rows, int K, int N, int activation, float* y);
+int t2_zoneout_lstm_cell(t2_ctx* ctx, const float* xh, const float* c_prev, const float* h_prev, const float* kernel, const float* bias,
+                         int B, int K, int H, float zoneout_cell, float zoneout_output, float forget_bias, float* z_ws, float* h_raw,
+                         float* c_new, float* h_new);
+
 /* Decoder state = OutputAndStopTokenWrapper.zero_state (rnn_wrappers.py:99-100) of the cell stack
  * OutputAndStopTokenWrapper(DecoderRNNV2(AttentionRNN(ZoneoutLSTMCell, prenets,
  * LocationSensitiveAttention))) plus the attention mechanism's constructor side effects
@@ -112,6 +123,9 @@ int t2_state_destroy(t2_state* s);
  * "lstm1_c", "lstm1_h", "lstm2_c", "lstm2_h" ([B,units]), "attention" ([B,enc_units]),
  * "alignments", "attention_state" ([B,T_in]), "keys" ([B,T_in,U]). */
 int t2_state_get(t2_state* s, const char* name, float* out);
+/* further names: "attention_output" ([B,A]), "lstm1_output", "decoder_output" ([B,D]): the raw cell outputs of the LAST step, i.e.
+ * what DecoderPreNetWrapper.call (rnn_wrappers.py:51-53), the first ZoneoutLSTM of DecoderRNNV2 and DecoderRNNV2.call
+ * (tacotron_v2.py:177-178) return. */
 
 /* RNNCell.call parity: one OutputAndStopTokenWrapper.call (rnn_wrappers.py:105-109) =
  * prenets (rnn_wrappers.py:51-53) -> AttentionWrapper step with LocationSensitiveAttention.__call__
@@ -138,6 +152,11 @@ int t2_decode_teacher(t2_model* m, const float* memory, const int64_t* lens, con
  * *steps_out steps are written.  steps_out: host int. */
 int t2_decode_free(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
                    int max_iters, int min_iters, float* mel, float* stop, float* align, int* steps_out);
+
+/* final_state of dynamic_decode as DecoderV1.call returns it (tacotron_v1.py:149-153; models.py:53 reads
+ * final_state[0].alignment_history): one tensor of the cell stack's state after the LAST decode loop of this model
+ * (t2_decode_teacher / t2_decode_free).  Names and shapes as t2_state_get. */
+int t2_decode_final_state(t2_model* m, const char* name, float* out);
 
 /* Same decode, split for callers that time or overlap it: _launch enqueues everything on the
  * ctx stream without synchronising, _finish waits and returns the step count. */
@@ -210,6 +229,11 @@ int t2_train_decoder_forward(t2_trainer* tr, const float* memory, const int64_t*
  * each -- the moving-statistics update of the step (models.py:75) is moving = 0.99*moving + 0.01*batch on the caller's side. */
 int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, const int64_t* lens, float drop_rate, uint32_t seed,
                              float* memory_out, float* bn_stats_out);
+/* EncoderV2.call(is_training = True) alone on a dev fp32 [B,T_in,embedding_dim] input (the Layer the reference defines,
+ * tacotron_v2.py:53-63); same arithmetic and outputs as t2_train_encoder_forward after its embedding lookup.  No backward through
+ * the embedding is defined for this entry point. */
+int t2_train_encoder_forward_embedded(t2_trainer* tr, const float* emb, const int64_t* lens, float drop_rate, uint32_t seed,
+                                      float* memory_out, float* bn_stats_out);
 /* Backward of t2_train_encoder_forward: dmemory dev [B,T_in,enc_units] (from t2_train_decoder_backward) -> gradients of
  * `embedding`, encoder/conv1d_i/{kernel, batch_normalization/gamma, beta} (through the batch statistics) and the BiLSTM
  * kernels / biases into flat_grads at the bound offsets. */

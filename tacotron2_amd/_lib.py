@@ -71,6 +71,7 @@ _SIGS = {
     "t2_decode_free": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]),
     "t2_decode_free_launch": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "t2_decode_free_finish": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "t2_decode_final_state": (C.c_int, [_p, C.c_char_p, _p]),
     "t2v1_model_create": (C.c_int, [_p, C.POINTER(T2V1Dims), C.POINTER(_p)]),
     "t2v1_model_set_weight": (C.c_int, [_p, C.c_char_p, _p, _i64p, C.c_int]),
     "t2v1_model_finalize": (C.c_int, [_p]),
@@ -86,7 +87,10 @@ _SIGS = {
     "t2_trainer_destroy": (C.c_int, [_p]),
     "t2_train_decoder_forward": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_uint32, _p, _p, _p]),
     "t2_train_encoder_forward": (C.c_int, [_p, _p, _p, C.c_float, C.c_uint32, _p, _p]),
+    "t2_train_encoder_forward_embedded": (C.c_int, [_p, _p, _p, C.c_float, C.c_uint32, _p, _p]),
     "t2_train_encoder_backward": (C.c_int, [_p, _p, _p]),
+    "t2_dense": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "t2_zoneout_lstm_cell": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p]),
     "t2_trainer_load_params": (C.c_int, [_p, _p]),
     "t2_trainer_set_loss_counts": (C.c_int, [_p, _p]),
     "t2_trainer_update_moving_stats": (C.c_int, [_p, _p, C.c_float]),

@@ -59,6 +59,7 @@ struct PArgs {
     unsigned* bar;                              // [NSHARD][32] hop counters, [64][32] attention row groups, [4][32] + [4][32] row-block groups (zeroed)
     int* ctl;
     float *mel, *stop, *hist;
+    float *cA_out, *c1_out, *c2_out;            // cell states [rows][1024] stored when the loop ends (final_state of dynamic_decode)
     long long mel_ld, mel_ts;
     int stop_ld;
     int B, T, C, CH, F, KA, MR, max_steps, min_iters, stop_en, cumulative;
@@ -766,6 +767,13 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         PZ_STAMP(15);
     }
     // (the last step's stop decision changes nothing: the decode ends at max_steps either way -- dynamic_decode's maximum_iterations)
+    // final_state: the hidden states are in the exchange slab already (last published values); the cell states live in registers
+    fresh();
+    if (eown) {
+        a.cA_out[(size_t)erow * (NWG * 4) + wg * 4 + euu] = cA;
+        a.c1_out[(size_t)erow * (NWG * 4) + wg * 4 + euu] = c1;
+        a.c2_out[(size_t)erow * (NWG * 4) + wg * 4 + euu] = c2;
+    }
 #ifdef PZ_STAMPS
     if (tid == 0) {
 #pragma unroll

@@ -106,6 +106,8 @@ struct t2_model {
     // cached workspaces
     std::vector<t2_state*> states;      // decode states owned by the model (cache)
     t2_state* pending = nullptr;        // free-run decode in flight
+    t2_state* last_loop = nullptr;      // state of the last decode loop (final_state of dynamic_decode: t2_decode_final_state)
+    bool last_persist = false; int last_steps_cap = 0;
     float* pend_mel = nullptr; float* pend_stop = nullptr; float* pend_align = nullptr;
     void* enc_ws = nullptr; size_t enc_ws_bytes = 0;
     void* post_ws = nullptr; size_t post_ws_bytes = 0;
@@ -629,6 +631,59 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
     return T2_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// stand-alone cells of the reference's RNNCell / Layer protocol (API parity; the decode loops never use these)
+// ------------------------------------------------------------------------------------------------
+// LSTMCell pointwise math + the inference zoneout blend on the gate pre-activations z [B][4H] (i | j | f | o; bias included)
+__global__ __launch_bounds__(256) void lstm_cell_pointwise_kernel(const float* __restrict__ z, const float* __restrict__ c_prev,
+                                                                  const float* __restrict__ h_prev, int B, int H, float zc, float zh, float fb,
+                                                                  float* __restrict__ h_raw, float* __restrict__ c_new, float* __restrict__ h_new) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * H; i += gridDim.x * blockDim.x) {
+        const int b = i / H, u = i - b * H;
+        const float* zr = z + (size_t)b * 4 * H;
+        const float cp = c_prev[i], hp = h_prev[i];
+        const float cn = sigmoidf_(zr[2 * H + u] + fb) * cp + sigmoidf_(zr[u]) * tanhf(zr[H + u]);
+        const float hn = sigmoidf_(zr[3 * H + u]) * tanhf(cn);
+        h_raw[i] = hn;
+        c_new[i] = (1.0f - zc) * cn + zc * cp;
+        h_new[i] = (1.0f - zh) * hn + zh * hp;
+    }
+}
+
+// y = act(x . kernel + bias) on plain operands (tf.layers.Dense: PreNet.call modules.py:88-91 without dropout; any [rows][K] input)
+static int dense_plain(t2_ctx* ctx, const float* x, const float* kernel, const float* bias, int rows, int K, int N, int act, float* y) {
+    ConvArgs a{};
+    a.x = x; a.ldx = K; a.w = kernel; a.scale = nullptr; a.shift = bias; a.res = nullptr; a.ldr = 0; a.y = y; a.ldy = N;
+    a.Mtot = rows; a.T = rows; a.Cin = K; a.N = N; a.ktaps = 1; a.pad_l = 0; a.act = act;
+    a.vec_a = (K % 4 == 0) && (((uintptr_t)x) % 16 == 0);
+    a.vec_b = (N % 4 == 0) && (((uintptr_t)kernel) % 16 == 0);
+    hipLaunchKernelGGL(conv_gemm_kernel, dim3(ceil_div(N, CG_BN), ceil_div(rows, CG_BM)), dim3(256), 0, ctx->stream, a);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+extern "C" int t2_dense(t2_ctx* ctx, const float* x, const float* kernel, const float* bias, int rows, int K, int N, int activation, float* y) {
+    if (!ctx || !x || !kernel || !y) return fail(T2_EINVAL, "null argument");
+    if (rows < 1 || K < 1 || N < 1 || activation < 0 || activation > 2) return fail(T2_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return dense_plain(ctx, x, kernel, bias, rows, K, N, activation, y);
+}
+
+extern "C" int t2_zoneout_lstm_cell(t2_ctx* ctx, const float* xh, const float* c_prev, const float* h_prev, const float* kernel,
+                                    const float* bias, int B, int K, int H, float zoneout_cell, float zoneout_output, float forget_bias,
+                                    float* z_ws, float* h_raw, float* c_new, float* h_new) {
+    if (!ctx || !xh || !c_prev || !h_prev || !kernel || !bias || !z_ws || !h_raw || !c_new || !h_new) return fail(T2_EINVAL, "null argument");
+    if (B < 1 || H < 1 || K <= H) return fail(T2_EINVAL, "bad shape: the kernel has K = inputs + H rows");
+    const float zm = std::min(zoneout_cell, zoneout_output), zs = std::max(zoneout_cell, zoneout_output);
+    if (zm < 0.f || zs > 1.f) return fail(T2_EINVAL, "One/both provided Zoneout factors are not in [0, 1]");
+    HIP_TRY(hipSetDevice(ctx->device));
+    T2_TRY(dense_plain(ctx, xh, kernel, bias, B, K, 4 * H, 0, z_ws));
+    hipLaunchKernelGGL(lstm_cell_pointwise_kernel, dim3(std::max(1, std::min(1024, ceil_div(B * H, 256)))), dim3(256), 0, ctx->stream, z_ws, c_prev, h_prev, B,
+                       H, zoneout_cell, zoneout_output, forget_bias, h_raw, c_new, h_new);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
 static int ensure_ws(void** ws, size_t* have, size_t need) {
     if (*have >= need) return T2_OK;
     if (*ws) HIP_TRY(hipFree(*ws));
@@ -1125,6 +1180,10 @@ extern "C" int t2_state_get(t2_state* s, const char* name, float* out) {
     if (!strcmp(name, "alignments")) return copy_plain(s->alignments, B, T, T);
     if (!strcmp(name, "attention_state")) return copy_plain(s->att_state, B, T, T);
     if (!strcmp(name, "keys")) return copy_plain(s->keys, (size_t)B * T, d.attention_dim, d.attention_dim);
+    // raw cell outputs of the LAST step (what the inner RNNCell wrappers return: rnn_wrappers.py:51-53, 76-78; tacotron_v2.py:177-178)
+    if (!strcmp(name, "attention_output")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->X1 + (size_t)(par ^ 1) * s->X1_sz, d.attention_lstm_units, 0); }
+    if (!strcmp(name, "lstm1_output")) { T2_TRY(current_parity(s, &par)); return copy_frag(s->X2 + (size_t)(par ^ 1) * s->X2_sz, d.decoder_lstm_units, 0); }
+    if (!strcmp(name, "decoder_output")) return copy_frag(s->XY, d.decoder_lstm_units, 0);
     return fail(T2_EINVAL, "unknown state tensor '%s'", name);
 }
 
@@ -1389,6 +1448,56 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     return T2_OK;
 }
 
+static int read_steps_quiet(t2_state* s, int* steps_out) {
+    hipStream_t st = s->m->ctx->stream;
+    int h[8];
+    HIP_TRY(hipMemcpyAsync(h, s->ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *steps_out = h[CTL_FINAL] != 0 ? h[CTL_FINAL] : h[CTL_MAX];
+    return T2_OK;
+}
+
+// final_state of dynamic_decode (tacotron_v1.py:149-153: DecoderV1.call returns it; models.py:53 reads its alignment history):
+// the cell stack's state after the last decode loop of this model (t2_decode_teacher / t2_decode_free*).  Names and shapes as
+// t2_state_get.  The persistent decoder keeps the LSTM states in registers during the loop and stores them when it ends.
+extern "C" int t2_decode_final_state(t2_model* m, const char* name, float* out) {
+    if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
+    t2_state* s = m->last_loop;
+    if (!s) return fail(T2_ESTATE, "no decode loop has run (or its state was evicted)");
+    if (m->pending) return fail(T2_ESTATE, "a free-running decode is in flight; call t2_decode_free_finish first");
+    if (!m->last_persist) return t2_state_get(s, name, out);
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int B = s->B, T = s->T;
+    int steps = 0;
+    T2_TRY(read_steps_quiet(s, &steps));
+    auto frag = [&](unsigned off, int K) -> int {
+        hipLaunchKernelGGL(frag_to_plain_kernel, dim3(ceil_div(B * K, 256)), dim3(256), 0, st, s->pz_xs + off / 4, out, B, K, s->MB, 0);
+        HIP_TRY(hipGetLastError());
+        return T2_OK;
+    };
+    auto plain = [&](const float* src, size_t n) -> int { HIP_TRY(hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToDevice, st)); return T2_OK; };
+    const int A = d.attention_lstm_units, D = d.decoder_lstm_units;
+    if (!strcmp(name, "attention_c")) return plain(s->c_att, (size_t)B * A);
+    if (!strcmp(name, "lstm1_c")) return plain(s->c1, (size_t)B * D);
+    if (!strcmp(name, "lstm2_c")) return plain(s->c2, (size_t)B * D);
+    if (!strcmp(name, "attention_h")) return frag(s->pz_off[3], A);
+    if (!strcmp(name, "lstm1_h")) return frag(s->pz_off[6], D);
+    if (!strcmp(name, "lstm2_h")) return frag(s->pz_off[8], D);
+    if (!strcmp(name, "attention_output")) return frag(s->pz_off[2], A);
+    if (!strcmp(name, "lstm1_output")) return frag(s->pz_off[5], D);
+    if (!strcmp(name, "decoder_output")) return frag(s->pz_off[7], D);
+    if (!strcmp(name, "attention")) return frag(s->pz_off[4], d.enc_units);
+    if (!strcmp(name, "alignments")) { if (steps < 1) return fail(T2_ESTATE, "no step has run"); return plain(s->o_hist + (size_t)(steps - 1) * B * T, (size_t)B * T); }
+    if (!strcmp(name, "attention_state")) {
+        if (steps < 1) return fail(T2_ESTATE, "no step has run");
+        return plain(s->pz_xs + s->pz_off[11] / 4 + (size_t)((steps - 1) & 1) * B * T, (size_t)B * T);
+    }
+    if (!strcmp(name, "keys")) return plain(s->keys, (size_t)B * T * d.attention_dim);
+    return fail(T2_EINVAL, "unknown state tensor '%s'", name);
+}
+
 extern "C" int t2_decode_step(t2_model* m, t2_state* s, const float* prev_frames, float* mel_r, float* stop) {
     if (!m || !s || !prev_frames || !mel_r || !stop) return fail(T2_EINVAL, "null argument");
     if (s->m != m) return fail(T2_EINVAL, "state belongs to another model");
@@ -1421,6 +1530,7 @@ static int get_loop_state(t2_model* m, int B, int T, int cap, t2_state** out) {
         for (t2_state* s : m->states) state_free(s);
         m->states.clear();
         m->pending = nullptr;
+        m->last_loop = nullptr;
     }
     t2_state* s = nullptr;
     T2_TRY(state_alloc(m, B, T, cap, true, &s));
@@ -1574,6 +1684,7 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     a.oY1 = s->pz_off[5]; a.oH1 = s->pz_off[6]; a.oY2 = s->pz_off[7]; a.oH2 = s->pz_off[8]; a.oQP = s->pz_off[9];
     a.oEN = s->pz_off[10]; a.oCUM = s->pz_off[11]; a.oSTOP = s->pz_off[12];
     a.bar = s->pz_bar; a.ctl = s->ctl;
+    a.cA_out = s->c_att; a.c1_out = s->c1; a.c2_out = s->c2;
     const int M = d.num_mels, r = d.outputs_per_step;
     a.mel = s->o_mel; a.mel_ld = (long long)s->cap * r * M; a.mel_ts = (long long)r * M;
     a.stop = s->o_stop; a.stop_ld = s->cap; a.hist = s->o_hist;
@@ -1622,6 +1733,7 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
     if (teacher_forcing && m->opt_tfproj) T2_TRY(teacher_projection_buffers(s, true));
     const bool persist = !teacher_forcing && persist_mode(s);
+    m->last_loop = s; m->last_persist = persist;
     if (persist) T2_TRY(persist_decode(s, S, 0, 0));
     else T2_TRY(decode_prologue(s, mode));
     const bool deferred = !persist && loop_io(s, mode).defer_proj != 0;
@@ -1645,6 +1757,7 @@ static int free_prepare(t2_model* m, const float* memory, const int64_t* lens, i
     T2_TRY(get_loop_state(m, B, T_in, max_iters, &s));
     T2_TRY(state_init(s, memory, lens));
     T2_TRY(state_zero(s, max_iters, min_iters, 1));
+    m->last_loop = s; m->last_persist = persist_mode(s);
     *out = s;
     return T2_OK;
 }

@@ -1342,9 +1342,9 @@ static int enc_tape_alloc(t2_trainer* tr, EncTape* et) {
 // their training branch with sequence lengths.  ids host int64 [B][T_in]; memory_out dev [B][T_in][enc_units].
 // bn_stats_out (dev, may be null): per conv layer [mean | biased variance], 2 * enc_units floats each (the moving-statistics
 // update of the step, models.py:75, is the caller's: moving = 0.99 * moving + 0.01 * batch).
-extern "C" int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, const int64_t* lens, float drop_rate, uint32_t seed,
-                                        float* memory_out, float* bn_stats_out) {
-    if (!tr || !ids || !memory_out) return fail(T2_EINVAL, "null argument");
+static int train_encoder_forward_impl(t2_trainer* tr, const int64_t* ids, const float* emb_in, const int64_t* lens, float drop_rate, uint32_t seed,
+                                      float* memory_out, float* bn_stats_out) {
+    if (!tr || (!ids && !emb_in) || !memory_out) return fail(T2_EINVAL, "null argument");
     if (!(drop_rate >= 0.f && drop_rate < 1.f)) return fail(T2_EINVAL, "drop rate must be in [0, 1)");
     t2_model* m = tr->m;
     HIP_TRY(hipSetDevice(m->ctx->device));
@@ -1360,7 +1360,7 @@ extern "C" int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, cons
         if (l < 0 || l > T) return fail(T2_EINVAL, "sequence length %lld outside 0..%d", (long long)l, T);
         h_lens[b] = (int)l;
     }
-    for (int i = 0; i < Mtot; ++i) {
+    for (int i = 0; ids && i < Mtot; ++i) {
         if (ids[i] < 0 || ids[i] >= d.num_symbols) return fail(T2_ERANGE, "embedding id %lld outside [0, %d) (modules.py:65-66)", (long long)ids[i], d.num_symbols);
         h_ids[i] = (int)ids[i];
     }
@@ -1369,7 +1369,8 @@ extern "C" int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, cons
     HIP_TRY(hipStreamSynchronize(st));
     et->drop_rate = drop_rate; et->seed = seed;
     auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
-    hipLaunchKernelGGL(embedding_kernel, grid1((long long)Mtot * emb), dim3(256), 0, st, et->ids, m->embedding, et->x[0], Mtot, emb);
+    if (ids) hipLaunchKernelGGL(embedding_kernel, grid1((long long)Mtot * emb), dim3(256), 0, st, et->ids, m->embedding, et->x[0], Mtot, emb);
+    else HIP_TRY(hipMemcpyAsync(et->x[0], emb_in, (size_t)Mtot * emb * 4, hipMemcpyDeviceToDevice, st));
     int cin = emb;
     for (int i = 0; i < L; ++i) {
         ConvLayer raw = m->enc_convs[i];
@@ -1416,8 +1417,20 @@ extern "C" int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, cons
             launch_lstm<true>(MB, dim3(m->enc_lstm[dir].n_wg, 1), st, c, e);
         }
     HIP_TRY(hipGetLastError());
-    et->have_forward = true;
+    et->have_forward = ids != nullptr;      // the backward pass needs the ids of the embedding lookup
     return T2_OK;
+}
+
+extern "C" int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, const int64_t* lens, float drop_rate, uint32_t seed,
+                                        float* memory_out, float* bn_stats_out) {
+    if (!ids) return fail(T2_EINVAL, "ids is null");
+    return train_encoder_forward_impl(tr, ids, nullptr, lens, drop_rate, seed, memory_out, bn_stats_out);
+}
+
+extern "C" int t2_train_encoder_forward_embedded(t2_trainer* tr, const float* emb, const int64_t* lens, float drop_rate, uint32_t seed,
+                                                 float* memory_out, float* bn_stats_out) {
+    if (!emb) return fail(T2_EINVAL, "emb is null");
+    return train_encoder_forward_impl(tr, nullptr, emb, lens, drop_rate, seed, memory_out, bn_stats_out);
 }
 
 static int enc_setup_backward(t2_trainer* tr, EncTape* et) {

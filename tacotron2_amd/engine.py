@@ -48,6 +48,14 @@ def _hp(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def state_shapes(d: T2Dims, B: int, T_in: int):
+    """Shapes of the tensors t2_state_get / t2_decode_final_state return (include/t2mi.h)."""
+    A, D = d.attention_lstm_units, d.decoder_lstm_units
+    return {"attention_c": (B, A), "attention_h": (B, A), "lstm1_c": (B, D), "lstm1_h": (B, D), "lstm2_c": (B, D), "lstm2_h": (B, D),
+            "attention": (B, d.enc_units), "alignments": (B, T_in), "attention_state": (B, T_in), "keys": (B, T_in, d.attention_dim),
+            "attention_output": (B, A), "lstm1_output": (B, D), "decoder_output": (B, D)}
+
+
 class DecoderState:
     """Opaque decoder state (t2_state): the zero_state / state of the reference's cell stack."""
 
@@ -56,13 +64,7 @@ class DecoderState:
         engine._states.add(self)
 
     def get(self, name: str) -> torch.Tensor:
-        d = self.engine.dims
-        shapes = {"attention_c": (self.B, d.attention_lstm_units), "attention_h": (self.B, d.attention_lstm_units),
-                  "lstm1_c": (self.B, d.decoder_lstm_units), "lstm1_h": (self.B, d.decoder_lstm_units),
-                  "lstm2_c": (self.B, d.decoder_lstm_units), "lstm2_h": (self.B, d.decoder_lstm_units),
-                  "attention": (self.B, d.enc_units), "alignments": (self.B, self.T_in),
-                  "attention_state": (self.B, self.T_in), "keys": (self.B, self.T_in, d.attention_dim)}
-        out = torch.empty(shapes[name], dtype=torch.float32, device=self.engine.device)
+        out = torch.empty(state_shapes(self.engine.dims, self.B, self.T_in)[name], dtype=torch.float32, device=self.engine.device)
         with self.engine._ordered():
             _lib.check(self.engine.lib.t2_state_get(self._h, name.encode(), out.data_ptr()))
         return out
@@ -274,6 +276,13 @@ class Engine:
                                            mel.data_ptr(), stop.data_ptr(), align.data_ptr(), C.byref(steps)))
         n = steps.value
         return mel[:, :n * d.outputs_per_step], stop[:, :n].unsqueeze(-1), align[:n], n
+
+    def decode_final_state(self, name: str, B: int, T_in: int) -> torch.Tensor:
+        """One tensor of the cell stack's state after the last decode loop (final_state of dynamic_decode)."""
+        out = torch.empty(state_shapes(self.dims, B, T_in)[name], dtype=torch.float32, device=self.device)
+        with self._ordered():
+            _lib.check(self.lib.t2_decode_final_state(self._model, name.encode(), out.data_ptr()))
+        return out
 
     def decode_free_launch(self, memory, lens, max_iters, min_iters, buffers, events=None):
         """events: optional (start, end) torch.cuda.Event pair recorded on the library's stream around the call

@@ -2,7 +2,7 @@
 mel-generation path: Embedding (:46-70), PreNet (:73-98), Conv1d (:133-160), ZoneoutLSTMCell
 (:235-283).  The objects hold sizes and (optionally) weights in TensorFlow layouts; they hold no
 arithmetic: the assemblies in tacotron_v2.py hand everything to the HIP library (engine.Engine).
-HighwayNet / CBHG (:101-232) belong to the Tacotron-1 path and are not built yet."""
+HighwayNet / CBHG (:101-232) belong to the Tacotron-1 path: tacotron_v1.py (t2v1_cbhg)."""
 from __future__ import annotations
 
 import numpy as np
@@ -52,6 +52,31 @@ class PreNet:
     def compute_output_shape(self, input_shape):
         return tuple(input_shape[:-1]) + (self.out_units,)
 
+    def __call__(self, inputs, **kwargs):
+        return self.call(inputs)
+
+    def call(self, inputs, **kwargs):
+        """Dense(out_units, relu) of modules.py:88-91 on the HIP library (t2_dense).  Stand-alone use needs ``weights``; active
+        dropout (is_training or apply_dropout_on_inference with drop_rate > 0) is sampled only inside the training step."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        from .engine import shared_context
+        if self.dropout_enabled and self.drop_rate > 0:
+            raise NotImplementedError("PreNet dropout is sampled inside the training step (training.Trainer); stand-alone calls run "
+                                      "the dropout-free arithmetic: construct the PreNet with drop_rate=0")
+        if self.weights is None:
+            raise ValueError("PreNet called without weights")
+        x = inputs if isinstance(inputs, torch.Tensor) and inputs.is_cuda else None
+        ctx = shared_context(x.device.index if x is not None else torch.cuda.current_device())
+        x = ctx.f32(inputs)
+        k, b = ctx.f32(self.weights["kernel"]), ctx.f32(self.weights["bias"])
+        rows = int(np.prod(x.shape[:-1]))
+        y = torch.empty(tuple(x.shape[:-1]) + (self.out_units,), dtype=torch.float32, device=ctx.device)
+        with ctx.ordered():
+            _lib.check(ctx.lib.t2_dense(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), rows, int(x.shape[-1]), self.out_units, 1, y.data_ptr()))
+        return y
+
 
 class Conv1d:
     """modules.py:133-160: conv1d(SAME, no bias) -> batch norm -> activation -> dropout."""
@@ -98,8 +123,36 @@ class ZoneoutLSTMCell:
     def output_size(self):
         return self._cell.output_size
 
+    def zero_state(self, batch_size, dtype=None, device="cuda"):
+        import torch
+        z = lambda: torch.zeros((batch_size, self.num_units), dtype=torch.float32, device=device)
+        return (z(), z())                       # LSTMStateTuple(c, h)
+
     def __call__(self, inputs, state, scope=None):
+        """modules.py:261-283 on the HIP library (t2_zoneout_lstm_cell): returns (raw output h, (zoned c, zoned h)).  Stand-alone
+        use needs ``weights``; the sampled training branch (:274-276) runs only inside the training step."""
+        import torch
+        from . import _lib
+        from .engine import shared_context
         if not self.state_is_tuple:
             raise NotImplementedError("non-tuple state is not implemented")
-        raise RuntimeError("ZoneoutLSTMCell runs inside a decoder / encoder assembly (see tacotron_v2.py); "
-                           "a stand-alone cell call is not exposed by the HIP library")
+        if self.is_training and (self._zoneout_cell > 0 or self._zoneout_outputs > 0):
+            raise NotImplementedError("zoneout masks are sampled inside the training step (training.Trainer); a stand-alone cell runs "
+                                      "the inference blend: construct it with is_training=False")
+        if self.weights is None:
+            raise ValueError("ZoneoutLSTMCell called without weights")
+        dev = inputs.device.index if isinstance(inputs, torch.Tensor) and inputs.is_cuda else torch.cuda.current_device()
+        ctx = shared_context(dev)
+        x, c, h = ctx.f32(inputs), ctx.f32(state[0]), ctx.f32(state[1])
+        kernel, bias = ctx.f32(self.weights["kernel"]), ctx.f32(self.weights["bias"])
+        B, H = int(x.shape[0]), self.num_units
+        xh = torch.cat([x, h], dim=-1).contiguous()
+        if tuple(kernel.shape) != (xh.shape[1], 4 * H):
+            raise ValueError(f"kernel shape {tuple(kernel.shape)} does not fit inputs + state ({xh.shape[1]}, {4 * H})")
+        z = torch.empty((B, 4 * H), dtype=torch.float32, device=ctx.device)
+        out, c2, h2 = (torch.empty((B, H), dtype=torch.float32, device=ctx.device) for _ in range(3))
+        with ctx.ordered():
+            _lib.check(ctx.lib.t2_zoneout_lstm_cell(ctx.handle, xh.data_ptr(), c.data_ptr(), h.data_ptr(), kernel.data_ptr(), bias.data_ptr(),
+                                                    B, int(xh.shape[1]), H, float(self._zoneout_cell), float(self._zoneout_outputs), 1.0,
+                                                    z.data_ptr(), out.data_ptr(), c2.data_ptr(), h2.data_ptr()))
+        return out, (c2, h2)

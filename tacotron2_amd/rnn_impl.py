@@ -56,12 +56,27 @@ def lstm_cell_factory(lstm_impl, num_units, dtype=None):
     raise ValueError(f"Unknown LSTM cell implementation: {lstm_impl}. Supported: {', '.join(LSTMImpl.all_list())}")
 
 
+class GRUCellSpec:
+    """What gru_cell_factory returns here: the description of one TF GRUCell layer (reset gate applied before the candidate
+    matmul); the arithmetic lives in the HIP library (gru_step_kernel / gru_seq_kernel, csrc/kernels.h)
+    and is reached through tacotron_v1.py's assemblies."""
+
+    def __init__(self, num_units):
+        self.num_units = num_units
+
+    @property
+    def state_size(self):
+        return self.num_units
+
+    @property
+    def output_size(self):
+        return self.num_units
+
+
 def gru_cell_factory(gru_impl, num_units, dtype=None):
-    """rnn_impl.py:36-44.  GRU cells belong to the Tacotron-1 path (BASELINE.json configs[4]),
-    which this build does not cover yet: known names raise NotImplementedError, unknown ones
-    ValueError like the reference."""
+    """rnn_impl.py:36-44: both names select the one HIP implementation; unknown ones raise ValueError like the reference."""
     if isinstance(gru_impl, str):
         gru_impl = next((i for i in GRUImpl if str(i) == gru_impl), gru_impl)
     if gru_impl in (GRUImpl.GRUCell, GRUImpl.GRUBlockCellV2):
-        raise NotImplementedError("GRU cells (Tacotron v1 path) are not built yet")
+        return GRUCellSpec(num_units)
     raise ValueError(f"Unknown GRU cell implementation: {gru_impl}. Supported: {', '.join(GRUImpl.all_list())}")

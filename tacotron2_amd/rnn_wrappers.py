@@ -2,9 +2,13 @@
 decoder step (prenet -> attention-wrapped RNN -> concat context -> mel / stop projections).
 
 Every class keeps the reference's protocol (``state_size``, ``output_size``, ``zero_state``,
-``compute_output_shape``, ``call`` / ``__call__``).  The composition is a *description*: the
-outermost ``OutputAndStopTokenWrapper`` binds the whole stack to the HIP library and one
-``call(inputs, state)`` is one ``t2_decode_step`` (include/t2mi.h).
+``compute_output_shape``, ``call`` / ``__call__``).  The HIP library runs the cell stack as ONE unit
+(``t2_decode_step``, include/t2mi.h), so the composition is a description that the outermost wrapper in
+use binds to the library: ``OutputAndStopTokenWrapper.call`` is one step; ``DecoderRNNV2.call``,
+``AttentionRNN.call`` and the two inner wrappers of an ``AttentionRNN`` run the same step (bound through
+outer layers nobody reads) and return what the reference's cell returns at that level -- the raw output
+of the last decoder LSTM, ``concat(attention cell output, new context)``, the attention cell output.
+State is a ``DecoderState``: ``state.get(name)`` reads any field of the reference's state tuple.
 """
 from __future__ import annotations
 
@@ -17,6 +21,28 @@ import torch
 from .hparams import T2Dims
 from .modules import PreNet, ZoneoutLSTMCell
 from .weights import init_weights
+
+
+class DeferredState:
+    """zero_state of a cell that is used on its own, before the width of its input is known (the reference's zero_state takes
+    only the batch size): becomes a real DecoderState at the first ``call``."""
+
+    def __init__(self, batch_size):
+        self.batch_size, self._real = batch_size, None
+
+    def bind(self, make):
+        if self._real is None:
+            self._real = make()
+        return self._real
+
+    def get(self, name):
+        if self._real is None:
+            raise RuntimeError("the cell has not been called yet: every field of its zero state is zero")
+        return self._real.get(name)
+
+
+def real_state(state):
+    return state._real if isinstance(state, DeferredState) else state
 
 
 class _Delegating:
@@ -67,21 +93,34 @@ class _AttentionWrapperSpec(_Delegating):
         return self._cell_spec.output_size      # output_attention=False
 
     def zero_state(self, batch_size, dtype=None):
-        raise RuntimeError("zero_state is provided by the bound OutputAndStopTokenWrapper")
+        return _owner(self).zero_state(batch_size, dtype)
 
     def call(self, inputs, state):
-        raise RuntimeError("the attention wrapper runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+        raise RuntimeError("tf.contrib.seq2seq.AttentionWrapper takes concat(prenet output, previous context); in this package the "
+                           "PreNets and the attention cell run as one unit: call the owning DecoderPreNetWrapper / AttentionRNN")
+
+
+def _owner(wrapper):
+    owner = getattr(wrapper, "_owner", None)
+    if owner is None:
+        raise RuntimeError("this wrapper is bound through the AttentionRNN that built it (rnn_wrappers.py:118-127); construct an "
+                           "AttentionRNN(cell, prenets, attention_mechanism) and use its inner wrappers")
+    return owner
 
 
 class DecoderPreNetWrapper(_Delegating):
-    """rnn_wrappers.py:30-53."""
+    """rnn_wrappers.py:30-53: ``call`` = PreNets, then the attention-wrapped cell; returns the attention cell's raw output."""
 
     def __init__(self, cell, prenets: Tuple[PreNet, ...]):
         self._cell = cell
         self.prenets = tuple(prenets)
 
+    def zero_state(self, batch_size, dtype=None):
+        return _owner(self).zero_state(batch_size, dtype)
+
     def call(self, inputs, state):
-        raise RuntimeError("runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+        _owner(self)._step(inputs, state)
+        return state.get("attention_output"), state
 
 
 class ConcatOutputAndAttentionWrapper(_Delegating):
@@ -94,8 +133,11 @@ class ConcatOutputAndAttentionWrapper(_Delegating):
     def output_size(self):
         return self._cell.output_size + self._cell.state_size.attention
 
+    def zero_state(self, batch_size, dtype=None):
+        return _owner(self).zero_state(batch_size, dtype)
+
     def call(self, inputs, state):
-        raise RuntimeError("runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+        return _owner(self).call(inputs, state)
 
 
 class AttentionRNN(_Delegating):
@@ -108,14 +150,40 @@ class AttentionRNN(_Delegating):
         concat_cell = ConcatOutputAndAttentionWrapper(prenet_cell)      # prenet -> attention -> concat
         self._cell = concat_cell
         self.lstm, self.prenets, self.mechanism = cell, tuple(prenets), attention_mechanism
+        attention_cell._owner = prenet_cell._owner = concat_cell._owner = self
+        self.input_units = None         # width of the decoder input (num_mels * n_feed_frame), known at the first call
+        self.weights = None             # optional {"decoder/...", "attention/...": array} for a cell used on its own
+        self._decoder = None
+
+    # -- RNNCell protocol on the cell itself (rnn_wrappers.py:143-144) -----------------------------------------------------
+    def _bound_decoder(self):
+        """A bare AttentionRNN is bound through a DecoderRNNV2 with two small LSTM layers nobody reads: the attention cell,
+        its PreNets and the attention mechanism do not depend on them."""
+        if self._decoder is None:
+            from .tacotron_v2 import DecoderRNNV2
+            self._decoder = DecoderRNNV2(4, self, is_training=self.lstm.is_training, zoneout_factor_cell=self.lstm._zoneout_cell,
+                                         zoneout_factor_output=self.lstm._zoneout_outputs)
+            own = ("decoder/prenet_", "decoder/attention_lstm/", "attention/")
+            self._decoder.weights = {k: v for k, v in (self.weights or {}).items() if k.startswith(own)}
+        return self._decoder
+
+    def zero_state(self, batch_size, dtype=None):
+        return self._bound_decoder().zero_state(batch_size, dtype)
+
+    def _step(self, inputs, state):
+        self.input_units = int(inputs.shape[-1])
+        self._bound_decoder().call(inputs, state)
 
     def call(self, inputs, state):
-        raise RuntimeError("runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+        """prenet -> attention-wrapped cell -> concat(cell output, NEW context) (rnn_wrappers.py:76-78): [B, A + E]."""
+        self._step(inputs, state)
+        return torch.cat([state.get("attention_output"), state.get("attention")], dim=-1), state
 
 
 class OutputProjectionWrapper(_Delegating):
-    """rnn_wrappers.py:147-186 (Tacotron-1 only).  The constructor check is kept; the projection
-    itself belongs to the V1 path, which is not built yet."""
+    """rnn_wrappers.py:147-186 (Tacotron-1 only).  The constructor check is kept here; the projection itself runs inside the
+    V1 decoder step of the HIP library (csrc/v1.h, v1_launch_step: a dense launch on [context | attention cell output]), reached
+    through tacotron_v1.DecoderV1."""
 
     def __init__(self, cell, output_size, activation=None, use_bias=True, name=None, dtype=None):
         if output_size < 1:
@@ -130,7 +198,7 @@ class OutputProjectionWrapper(_Delegating):
         return self._output_size
 
     def call(self, inputs, state):
-        raise NotImplementedError("OutputProjectionWrapper belongs to the Tacotron v1 path (not built yet)")
+        raise RuntimeError("OutputProjectionWrapper runs inside the V1 decoder step (tacotron_v1.DecoderV1 -> t2v1_decode_*)")
 
 
 class OutputAndStopTokenWrapper(_Delegating):
@@ -203,5 +271,5 @@ class OutputAndStopTokenWrapper(_Delegating):
     def call(self, inputs, state):
         if inputs.shape[-1] != self._n_feed_units:
             raise ValueError(f"decoder input width {inputs.shape[-1]} != n_feed_units {self._n_feed_units}")
-        mel_output, stop_token = self.engine().decode_step(state, inputs)
+        mel_output, stop_token = self.engine().decode_step(real_state(state), inputs)
         return (mel_output, stop_token), state

@@ -44,17 +44,33 @@ class EncoderV2:
                                     name=f"conv1d_{i}") for i in range(0, num_conv_layers)]
         self._cells = [ZoneoutLSTMCell(out_units // 2, is_training, zoneout_factor_cell, zoneout_factor_output,
                                        lstm_impl=lstm_impl) for _ in range(2)]
-        if is_training:
-            raise NotImplementedError("training-mode encoder (batch-statistics BN, dropout, zoneout sampling) is not built")
+        self.drop_rate = drop_rate
         self._engine = engine
+        self._trainers = {}
+        self.seed = 0                   # seed of the next training-mode call's dropout / zoneout masks; advances per call
+        self.batch_statistics = None    # [layers, 2, out_units] batch mean | variance of the last training-mode call
 
     def __call__(self, inputs, input_lengths=None):
         return self.call(inputs, input_lengths)
 
     def call(self, inputs, input_lengths=None):
+        """Inference arithmetic (moving statistics, no dropout, deterministic zoneout), or with ``is_training`` the training
+        arithmetic of Conv1d.call (modules.py:149-157: batch statistics over all positions, dropout) and the sampled zoneout
+        branch of ZoneoutLSTMCell (modules.py:274-276) -- t2_train_encoder_forward_embedded."""
         if self._engine is None:
             raise RuntimeError("EncoderV2 needs an engine (see TacotronV2Model)")
-        return self._engine.encode_embedded(inputs, input_lengths)
+        if not self.is_training:
+            return self._engine.encode_embedded(inputs, input_lengths)
+        x = self._engine._f32(inputs)
+        key = (int(x.shape[0]), int(x.shape[1]))
+        if key not in self._trainers:
+            if len(self._trainers) >= 2:
+                self._trainers.pop(next(iter(self._trainers))).close()
+            self._trainers[key] = training.Trainer(self._engine, key[0], key[1], 1)
+        memory, stats = self._trainers[key].encoder_forward_embedded(x, input_lengths, drop_rate=self.drop_rate, seed=self.seed)
+        self.seed += 1
+        self.batch_statistics = stats
+        return memory
 
 
 class LocationSensitiveAttention:
@@ -109,14 +125,33 @@ class DecoderRNNV2:
     def output_size(self):
         return self._out_units
 
+    # -- RNNCell protocol on the cell itself (tacotron_v2.py:177-178) -----------------------------------------------
+    def _bound(self, n_feed_units):
+        """The HIP library runs the cell stack as one unit (t2_decode_step); a bare DecoderRNNV2 is bound through an
+        OutputAndStopTokenWrapper whose projections nobody reads."""
+        if getattr(self, "_outer", None) is None or self._outer._n_feed_units != n_feed_units:
+            from .rnn_wrappers import OutputAndStopTokenWrapper
+            unread = ("decoder/out_projection/", "decoder/stop_token_projection/")
+            own = {k: v for k, v in (getattr(self, "weights", None) or {}).items() if not k.startswith(unread)}
+            self._outer = OutputAndStopTokenWrapper(self, n_feed_units, weights=own, n_feed_units=n_feed_units, num_mels=n_feed_units)
+        return self._outer
+
     def zero_state(self, batch_size, dtype=None):
-        raise RuntimeError("zero_state is provided by the bound OutputAndStopTokenWrapper")
+        from .rnn_wrappers import DeferredState
+        return DeferredState(batch_size)            # the library state is created at the first call, when the input width is known
 
     def compute_output_shape(self, input_shape):
         return (input_shape[0], input_shape[1], self.output_size)
 
     def call(self, inputs, state):
-        raise RuntimeError("runs inside OutputAndStopTokenWrapper.call (t2_decode_step)")
+        """MultiRNNCell([attention_cell, ZoneoutLSTM, ZoneoutLSTM]) step: returns (raw output of the last LSTM [B, out_units],
+        state); ``state`` (a DecoderState from zero_state) is advanced in place."""
+        from .rnn_wrappers import DeferredState
+        outer = self._bound(int(inputs.shape[-1]))
+        if isinstance(state, DeferredState):
+            state.bind(lambda: outer.zero_state(state.batch_size))
+        outer.call(inputs, state)
+        return state.get("decoder_output"), state
 
     __call__ = call
 
@@ -249,8 +284,19 @@ class DecoderV2:
         else:
             mel_output, stop, align, _ = eng.decode_free(source, memory_sequence_length, max_iters=self.max_iters,
                                                          min_iters=self.min_iters)
-        final_state = (SimpleNamespace(alignment_history=_AlignmentHistory(align)), None, None)
+        final_state = self._final_state(eng, B, source.shape[1], align, None if not generic_loop else final)
         return mel_output, stop, final_state
+
+    @staticmethod
+    def _final_state(eng, B, T_in, align, state=None):
+        """The state tuple DecoderRNNV2 leaves behind (tacotron_v2.py:155-161 MultiRNNCell, state_is_tuple=True):
+        (AttentionWrapperState(cell_state=LSTMStateTuple(c, h), attention, time, alignments, alignment_history, attention_state),
+        LSTMStateTuple(c, h) of LSTM 1, LSTMStateTuple(c, h) of LSTM 2) -- models.py:53 reads [0].alignment_history.stack()."""
+        get = (lambda n: state.get(n)) if state is not None else (lambda n: eng.decode_final_state(n, B, T_in))
+        lstm = lambda p: SimpleNamespace(c=get(p + "_c"), h=get(p + "_h"))
+        att = SimpleNamespace(cell_state=lstm("attention"), attention=get("attention"), time=int(align.shape[0]), alignments=get("alignments"),
+                              alignment_history=_AlignmentHistory(align), attention_state=get("attention_state"))
+        return (att, lstm("lstm1"), lstm("lstm2"))
 
 
 def spec_loss(y_hat, y, mask, n_priority_freq=None, priority_w=0, engine=None):

@@ -259,6 +259,20 @@ class Trainer:
                                                         int(seed) & 0xFFFFFFFF, memory.data_ptr(), stats.data_ptr()))
         return memory, stats[:d.enc_conv_layers]
 
+    def encoder_forward_embedded(self, emb, lens, drop_rate: float = 0.5, seed: int = 0):
+        """EncoderV2.call(is_training=True) on an embedded input [B, T_in, embedding_dim] (tacotron_v2.py:53-63)."""
+        eng, d = self.engine, self.engine.dims
+        emb = eng._f32(emb)
+        lens = None if lens is None else np.ascontiguousarray(np.asarray(lens), dtype=np.int64)
+        if tuple(emb.shape) != (self.B, self.T_in, d.embedding_dim):
+            raise ValueError("input does not match the trainer's (B, T_in, embedding_dim)")
+        memory = torch.empty((self.B, self.T_in, d.enc_units), dtype=torch.float32, device=eng.device)
+        stats = torch.empty((max(d.enc_conv_layers, 1), 2, d.enc_units), dtype=torch.float32, device=eng.device)
+        with eng._ordered():
+            _lib.check(eng.lib.t2_train_encoder_forward_embedded(self._h, emb.data_ptr(), None if lens is None else lens.ctypes.data_as(C.c_void_p),
+                                                                 float(drop_rate), int(seed) & 0xFFFFFFFF, memory.data_ptr(), stats.data_ptr()))
+        return memory, stats[:d.enc_conv_layers]
+
     def bind_gradients(self, spec):
         """spec: training.flatten_spec(weights) -- where each variable's gradient goes in the flat buffer."""
         self._spec = spec

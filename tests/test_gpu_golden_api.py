@@ -141,3 +141,88 @@ def test_synthesize_driver_and_splitk_option():
     got = synthesize(model, ["HI"])[0]
     np.testing.assert_allclose(got["mel"], ref["mel_postnet"][0], atol=5 * ATOL)
     model.close()
+
+
+def test_inference_helper_drives_the_hip_decoder():
+    """H4, the legacy InferenceHelper (helpers.py:13-49: a row finishes when its whole output is exactly 0.0) through the
+    generic RNNCell / Helper loop on the HIP cell stack, against the oracle's dynamic_decode with the same helper.  A row
+    whose projection kernels and biases are zero... does not exist per row, so the zero output is forced for EVERY row
+    from the start: all-zero projection weights end the decode after one step; non-zero ones run to maximum_iterations."""
+    from tacotron2_amd.helpers import InferenceHelper
+    from tacotron2_amd.modules import PreNet, ZoneoutLSTMCell
+    from tacotron2_amd.rnn_wrappers import AttentionRNN, OutputAndStopTokenWrapper
+    from tacotron2_amd.tacotron_v2 import DecoderRNNV2, LocationSensitiveAttention, dynamic_decode
+    d = PROFILE_TINY
+    rng = np.random.default_rng(4)
+    B, T = 3, 6
+    memory = rng.uniform(-1, 1, (B, T, d.enc_units)).astype(np.float32)
+    lens = np.array([6, 4, 5])
+    for zero_projection, want_steps in ((False, 5), (True, 1)):
+        w = init_weights(d, 9, perturb=True)
+        if zero_projection:
+            for k in ("decoder/out_projection/kernel", "decoder/out_projection/bias"):
+                w[k] = np.zeros_like(w[k])
+        mech = LocationSensitiveAttention(d.attention_dim, memory, lens, d.attention_kernel, d.attention_filters)
+        cell = OutputAndStopTokenWrapper(
+            DecoderRNNV2(d.decoder_lstm_units,
+                         AttentionRNN(ZoneoutLSTMCell(d.attention_lstm_units, False, d.zoneout_cell, d.zoneout_output),
+                                      tuple(PreNet(u, False) for u in d.prenet_units), mech),
+                         False, d.zoneout_cell, d.zoneout_output),
+            d.num_mels * d.outputs_per_step, weights=w, n_feed_units=d.num_mels * d.n_feed_frame, num_mels=d.num_mels)
+        helper = InferenceHelper(B, d.num_mels, d.outputs_per_step, n_feed_frame=d.n_feed_frame)
+        (mel, stop), state, steps = dynamic_decode(cell, helper, cell.zero_state(B), maximum_iterations=5)
+        assert steps == want_steps
+        ocell = O.DecoderCellV2(d, w, memory, lens)
+        (mel_o, stop_o), _, steps_o = O.dynamic_decode(ocell, O.InferenceHelper(B, d.num_mels, d.outputs_per_step, d.n_feed_frame),
+                                                       ocell.zero_state(), 5)
+        assert steps_o == want_steps
+        np.testing.assert_allclose(_np(mel), mel_o, atol=ATOL)
+        np.testing.assert_allclose(_np(stop), stop_o, atol=ATOL)
+        cell.engine().close()
+
+
+def test_imported_checkpoint_runs_on_the_engine(tmp_path):
+    """SURVEY.md 8f rank 2 on the GPU: TF-style variable dict -> import_tf_variables -> save_npz -> load_npz -> Engine, against
+    the oracle on the same dict."""
+    from tacotron2_amd import checkpoint as C
+    from tacotron2_amd.engine import Engine
+    d = PROFILE_TINY
+    w = init_weights(d, 31, perturb=True)
+    names = C.tf_style_names(d)
+    tf_vars = {names[k] + ":0": v for k, v in w.items()}
+    tf_vars["global_step"] = np.array(3, np.int64)
+    tf_vars[names["embedding"] + "/Adam"] = np.zeros_like(w["embedding"])
+    path = str(tmp_path / "ckpt.npz")
+    C.save_npz(path, C.import_tf_variables(tf_vars, d))
+    loaded = C.load_npz(path, d)
+    eng = Engine(d, loaded)
+    rng = np.random.default_rng(2)
+    ids = rng.integers(0, d.num_symbols, (4, 9))
+    lens = np.array([9, 5, 7, 3])
+    ref = O.tacotron2_forward(d, w, ids, lens, mode="predict")
+    memory = eng.encode(ids, lens)
+    mel, stop, align, n = eng.decode_free(memory, lens)
+    assert n == ref["steps"]
+    np.testing.assert_allclose(_np(memory), ref["memory"], atol=ATOL)
+    np.testing.assert_allclose(_np(mel), ref["mel"], atol=ATOL)
+    np.testing.assert_allclose(_np(eng.postnet(mel)), ref["mel_postnet"], atol=ATOL)
+    eng.close()
+
+
+def test_synthesize_sharded_covers_the_job_without_overlap():
+    """SURVEY.md 8e, inference partitioning: two ranks (here: two calls) deal the length-sorted batches round robin; together
+    they cover every utterance exactly once and each result equals the unsharded synthesis of the same batch."""
+    from tacotron2_amd.sharding import make_batches
+    from tacotron2_amd.synthesize import synthesize, synthesize_sharded, text_to_sequence
+    from tacotron2_amd.tacotron_v2 import TacotronV2Model
+    d = PROFILE_TINY.replace(num_symbols=128, max_iters=8)
+    model = TacotronV2Model(d, init_weights(d, 3, perturb=True))
+    texts = ["AB", "HELLO WORLD", "ABC", "TACOTRON", "X", "SPEECH SYNTH", "MI355X"]
+    parts = [synthesize_sharded(model, texts, world_size=2, rank=r, batch_size=2) for r in range(2)]
+    assert not set(parts[0]) & set(parts[1]) and set(parts[0]) | set(parts[1]) == set(range(len(texts)))
+    batches = make_batches([len(text_to_sequence(t)) for t in texts], 2)
+    for b, idx in enumerate(batches):
+        whole = synthesize(model, [texts[i] for i in idx])
+        for i, res in zip(idx, whole):
+            np.testing.assert_array_equal(parts[b % 2][int(i)]["mel"], res["mel"])
+    model.close()
