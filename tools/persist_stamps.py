@@ -26,9 +26,11 @@ assert eng.lib.t2_debug_stamps(out.ctypes.data_as(C.c_void_p)) == 0
 us = out.astype(np.float64) * 0.01 / n          # us per step per interval
 names = ["P5 tail+P6 work", "arr6+gap Z2+attn pre", "WAIT6", "stop+P1 work", "arr1", "WAIT1", "attn hist+ctx", "arr2+gap Z1x", "WAIT2", "P3 work",
          "arr3+gap ZA", "WAIT3", "P4 work", "arr4+gap Z1", "WAIT4", "P5 work", "-", "-", "attn q+energies", "-", "attn exchange+softmax"]
-print("B=%d T=%d steps=%d ; us per step: mean over workgroups / min / max / wg0 / wg255" % (B, T, n))
+MB = 1 if B <= 16 else 2 if B <= 32 else 4
+wn = 255 - 27 * MB - 1          # an owner of a last-PreNet tile
+print("B=%d T=%d steps=%d ; us per step: mean over workgroups / min / max / wg0 / wg%d (PreNet tile) / wg255 (projection tile)" % (B, T, n, wn))
 for i, nm in enumerate(names):
     c = us[:, i]
-    print("%2d %-22s %7.2f %7.2f %7.2f %7.2f %7.2f" % (i, nm, c.mean(), c.min(), c.max(), c[0], c[255]))
+    print("%2d %-22s %7.2f %7.2f %7.2f %7.2f %7.2f %7.2f" % (i, nm, c.mean(), c.min(), c.max(), c[0], c[wn], c[255]))
 print("sum (mean) %.2f" % us[:, :21].sum(axis=1).mean())
 eng.close()
