@@ -10,9 +10,13 @@
 // Structure.  256 workgroups (one per CU) stay resident for the whole decode.  Workgroup g owns hidden units
 // 4g..4g+3 (16 gate columns) of all three ZoneoutLSTM cells: their cell / hidden state lives in registers for
 // the whole decode, the gate GEMM of a layer is [rows x K] . [K x 16] on v_mfma_f32_16x16x4_f32 with K split
-// over the 8 waves.  A decoder step is six all-to-all exchanges ("hops"):
-//   P6 last PreNet layer -> H6 -> P1 attention LSTM -> H1 -> P2 attention -> H2 -> P3 LSTM 1 -> H3 ->
-//   P4 LSTM 2 -> H4 -> P5 mel / stop projection + first PreNet layer of the next step -> H5 -> stop rule.
+// over the 8 waves.  A decoder step is five all-to-all exchanges ("hops") and three group hops:
+//   P6 last PreNet layer -> H6 (+ stop rule) -> P1 attention LSTM -> H1 -> P2a query tiles -> granules -> P2 attention
+//   (energy granules inside) -> H2 -> P3 LSTM 1 -> H3 -> P4 LSTM 2 -> H4 -> P5 mel / stop projection + first PreNet layer
+//   of the next step -> row-block counter -> P6.
+// Teacher-forced decodes (TrainingHelper / ValidationHelper(teacher_forcing=True), helpers.py:131-136,176-184) feed nothing
+// back: the PreNet outputs of all steps are computed beforehand (teacher_prenets), the projections afterwards
+// (teacher_projection), and a step is P1 -> H1 -> P2 -> H2 -> P3 -> H3 -> P4 -> H4.
 // Every K range whose operand is already known (recurrent halves, the attention cell output into LSTM 1) is
 // multiplied in the gaps between "arrive" and "wait" of a hop and accumulates in the per-wave MFMA accumulators
 // that the critical part of the layer continues, so nothing hoisted ever goes through memory.  Weights of the
@@ -60,6 +64,10 @@ struct PArgs {
     int* ctl;
     float *mel, *stop, *hist;
     float *cA_out, *c1_out, *c2_out;            // cell states [rows][1024] stored when the loop ends (final_state of dynamic_decode)
+    const float* x2_all;                        // teacher-forced decode: last PreNet layer's outputs of every step, frag16 per step
+    unsigned x2_bytes, x2_stride;               // size of x2_all, bytes per step
+    float* y_all;                               // teacher-forced decode: LSTM 2's raw outputs [S][rows][1024] for the deferred projection
+    int teacher;
     long long mel_ld, mel_ts;
     int stop_ld;
     int B, T, C, CH, F, KA, MR, max_steps, min_iters, stop_en, cumulative;
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     const rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w2), 0, NWG * (KBH + KBH) * 1024, 0x00020000);
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wP), 0, 28 * KBH * 1024, 0x00020000);
     const rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wN), 0, 16 * KBX * 1024, 0x00020000);
+    const rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.teacher ? a.x2_all : a.wN), 0, a.teacher ? (int)a.x2_bytes : 0, 0x00020000);
     const unsigned slabA = (unsigned)wg * (KBX + KBE + KBH) * 1024u;      // byte offsets of this workgroup's slabs
     const unsigned slab1 = (unsigned)wg * (KBH + KBE + KBH) * 1024u;
     const unsigned slab2 = (unsigned)wg * (KBH + KBH) * 1024u;
@@ -419,9 +428,12 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[r][g] = 0.f;
+    if (a.teacher && isAtt) attention_pre(0);
 
     for (; t < a.max_steps; ++t) {
         fresh();
+        f32x4 bx[2];
+        if (!a.teacher) {
         // gap work of the P5 -> P6 chain: the query-independent part of this step's attention.  The owners of a last-PreNet
         // tile do it BEFORE their tile (they are waiting for the projection tiles anyway), everybody else after arriving.
         auto gap6 = [&]() {
@@ -457,7 +469,6 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         PZ_STAMP(0); hop_arrive(a.bar); ++epoch; fresh();
         if (!isN) { gap6(); fresh(); }
         // critical weights of P1 (the PreNet rows of the attention LSTM kernel) while the hop completes
-        f32x4 bx[2];
         wload<2>(bx, rA, slabA + (unsigned)(wave * 2 * 1024), l16);
         PZ_STAMP(1);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
@@ -476,8 +487,13 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             if (s_flag[1]) { final_steps = t; break; }
         }
 
+        } else {
+            wload<2>(bx, rA, slabA + (unsigned)(wave * 2 * 1024), l16);
+        }
+
         // ================= P1: attention LSTM (AttentionWrapper cell call, App. A6)  =================
-        seg_mma<MB, 2>(accA, bx, xs, a.oX2 + (unsigned)(wave * 2 * MB * 1024), l16);
+        if (!a.teacher) seg_mma<MB, 2>(accA, bx, xs, a.oX2 + (unsigned)(wave * 2 * MB * 1024), l16);
+        else seg_mma<MB, 2>(accA, bx, rX2, (unsigned)t * a.x2_stride + (unsigned)(wave * 2 * MB * 1024), l16);
         put_red(accA);
         __syncthreads();
         if (tid < MB * 64) {
@@ -706,6 +722,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             const float hn = cell(z, s_bias + 32, c2, h2);
             publish4(hn, a.oY2);
             publish4(h2, a.oH2);
+            if (a.teacher && eown) a.y_all[((size_t)t * B + erow) * (NWG * 4) + wg * 4 + euu] = hn;
         }
 #pragma unroll
         for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -722,15 +739,16 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             pk4 = hop_peek(a.bar);
             seg_mma<MB, 4>(acc1, bhi, xs, a.oH1 + (unsigned)((wave * 8 + 4) * MB * 1024), l16);
         }
+        if (a.teacher && isAtt) { attention_pre(t + 1); fresh(); }
         f32x4 bp[8];
         float bias_p = 0.f;
-        if (isP) { wload<8>(bp, rP, (unsigned)((ptile * KBH + wave * 8) * 1024), l16); bias_p = a.bP[ptile * 16 + (tid & 15)]; }
+        if (isP && !a.teacher) { wload<8>(bp, rP, (unsigned)((ptile * KBH + wave * 8) * 1024), l16); bias_p = a.bP[ptile * 16 + (tid & 15)]; }
         PZ_STAMP(13);
         if (!hop_wait(a.bar, 32u * epoch, s_flag, pk4)) { alive = false; break; }
         fresh(); PZ_STAMP(14);
 
         // ================= P5: mel / stop projections (rnn_wrappers.py:105-109) + composed first PreNet layer of step t+1 =================
-        if (isP) {
+        if (isP && !a.teacher) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             tile_mma<8>(acc, bp, xs, a.oY2 + (unsigned)((wave * 8 * MB + prb) * 1024), MB, l16);
             red[wave * 64 + lane] = acc;

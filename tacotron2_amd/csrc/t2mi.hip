@@ -1670,7 +1670,13 @@ static inline bool persist_mode(const t2_state* s) {
     const t2_model* m = s->m;
     return m->opt_persist && s->pz_xs != nullptr && m->proj_fused_ok && m->opt_projfuse && !m->opt_lstm_only;
 }
-static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en) {
+// Teacher-forced decode as one persistent launch: PreNets of all steps before it (teacher_prenets), projections after it
+// (teacher_projection); needs neither the composed projection nor the stop rule.
+static inline bool persist_mode_teacher(const t2_state* s) {
+    const t2_model* m = s->m;
+    return m->opt_persist && m->opt_tfproj && s->pz_xs != nullptr && s->tf_frag != nullptr && s->y_all != nullptr && !m->opt_lstm_only;
+}
+static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en, bool teacher = false) {
     t2_model* m = s->m;
     const t2_dims& d = m->d;
     hipStream_t st = m->ctx->stream;
@@ -1693,12 +1699,19 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     a.max_steps = max_steps; a.min_iters = min_iters; a.stop_en = stop_en; a.cumulative = d.cumulative_weights;
     a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
     if (m->att_lstm.n_wg != pz::NWG || m->att_lstm.kbtot != pz::KBX + pz::KBE + pz::KBH || m->lstm1.kbtot != 2 * pz::KBH + pz::KBE ||
-        m->lstm2.kbtot != 2 * pz::KBH || m->proj_fused.n_wg != 28 || m->proj_fused.kbtot != pz::KBH || m->prenet[1].n_wg != 16 ||
-        m->prenet[1].kbtot != pz::KBX || m->wq_pk.n_wg != 8 || m->wq_pk.kbtot != pz::KBH)
+        m->lstm2.kbtot != 2 * pz::KBH || m->wq_pk.n_wg != 8 || m->wq_pk.kbtot != pz::KBH ||
+        (!teacher && (m->proj_fused.n_wg != 28 || m->proj_fused.kbtot != pz::KBH || m->prenet[1].n_wg != 16 || m->prenet[1].kbtot != pz::KBX)))
         return fail(T2_ESTATE, "internal: packed operands do not have the persistent decoder's geometry");
-    // x1 of step 0 = relu(bias of the first PreNet layer): the go frame is zeros (helpers.py:187-188)
-    hipLaunchKernelGGL(pz::init_x1_kernel, dim3(ceil_div(s->B * d.prenet_units[0], 256)), dim3(256), 0, st, s->pz_xs + a.oX1 / 4,
-                       m->prenet[0].bias, s->B, s->MB, d.prenet_units[0]);
+    if (teacher) {
+        if (s->tf_stride != (long long)s->MB * 16 * pz::KBX * 16 || (long long)max_steps * s->tf_stride * 4 > 0x7fffffffLL)
+            return fail(T2_ESTATE, "internal: teacher-forced PreNet operands do not have the persistent decoder's geometry");
+        a.teacher = 1; a.x2_all = s->tf_frag; a.x2_stride = (unsigned)(s->tf_stride * 4); a.x2_bytes = (unsigned)((long long)max_steps * s->tf_stride * 4);
+        a.y_all = s->y_all;
+    } else {
+        // x1 of step 0 = relu(bias of the first PreNet layer): the go frame is zeros (helpers.py:187-188)
+        hipLaunchKernelGGL(pz::init_x1_kernel, dim3(ceil_div(s->B * d.prenet_units[0], 256)), dim3(256), 0, st, s->pz_xs + a.oX1 / 4,
+                           m->prenet[0].bias, s->B, s->MB, d.prenet_units[0]);
+    }
     const size_t lds = persist_lds_bytes(s->B, s->T);
     const dim3 grid(pz::NWG), blk(pz::NT);
     if (s->MB == 1) hipLaunchKernelGGL(pz::decode_kernel<1>, grid, blk, lds, st, a);
@@ -1732,11 +1745,12 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     const int mode = teacher_forcing ? 0 : 1;
     if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
     if (teacher_forcing && m->opt_tfproj) T2_TRY(teacher_projection_buffers(s, true));
-    const bool persist = !teacher_forcing && persist_mode(s);
+    const bool persist_tf = teacher_forcing && persist_mode_teacher(s);
+    const bool persist = persist_tf || (!teacher_forcing && persist_mode(s));
     m->last_loop = s; m->last_persist = persist;
-    if (persist) T2_TRY(persist_decode(s, S, 0, 0));
+    if (persist) T2_TRY(persist_decode(s, S, 0, 0, persist_tf));
     else T2_TRY(decode_prologue(s, mode));
-    const bool deferred = !persist && loop_io(s, mode).defer_proj != 0;
+    const bool deferred = persist_tf || (!persist && loop_io(s, mode).defer_proj != 0);
     for (int done = 0; !persist && done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
     if (deferred) T2_TRY(teacher_projection(s, s->y_all, s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));

@@ -126,3 +126,32 @@ def test_persistent_validation_free_run(paper):
     np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
     np.testing.assert_allclose(_np(stop), stop_o, atol=2e-4)
     np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
+
+
+@pytest.mark.parametrize("B", [1, 20, 64])
+def test_persistent_teacher_forced_against_oracle_and_launch_schedule(paper, B):
+    """TrainingHelper / ValidationHelper(teacher_forcing=True) (helpers.py:131-136, 176-184) as one launch: PreNets of all steps
+    before it, projections after it; against the oracle, the launch-per-phase schedule, and with the final state."""
+    d, w, eng, memory_o, lens = paper
+    S = 9
+    T = int(lens[:B].max())
+    mem = memory_o[:B, :T]
+    target = np.random.default_rng(3).uniform(-1, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+    mel_o, stop_o, st = O.decoder_v2(d, w, mem, is_training=True, memory_sequence_length=lens[:B], target=target)
+    eng.set_option("persist", 1)
+    before = eng.get_stat("persist_launches")
+    mel, stop, align = eng.decode_teacher(mem, lens[:B], target, teacher_forcing=True)
+    assert eng.get_stat("persist_launches") == before + 1, "the persistent kernel did not run"
+    np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
+    np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
+    np.testing.assert_allclose(_np(stop), stop_o, atol=2e-4)
+    for name, want in (("attention_c", st[0].cell_state[0]), ("attention_h", st[0].cell_state[1]), ("attention", st[0].attention),
+                       ("attention_state", st[0].attention_state), ("lstm1_c", st[1][0]), ("lstm2_h", st[2][1])):
+        np.testing.assert_allclose(_np(eng.decode_final_state(name, B, T)), want, atol=2e-4, err_msg=name)
+    mel1, stop1, align1 = _np(mel).copy(), _np(stop).copy(), _np(align).copy()
+    eng.set_option("persist", 0)
+    mel0, stop0, align0 = eng.decode_teacher(mem, lens[:B], target, teacher_forcing=True)
+    eng.set_option("persist", 1)
+    np.testing.assert_allclose(mel1, _np(mel0), atol=1e-4)
+    np.testing.assert_allclose(stop1, _np(stop0), atol=1e-4)
+    np.testing.assert_allclose(align1, _np(align0), atol=1e-5)
