@@ -49,6 +49,15 @@ constexpr unsigned SPIN_LIMIT_TICKS = 25u * 1000u * 1000u;   // s_memrealtime ti
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
+// Training forward (csrc/train_step.h): sampled zoneout (modules.py:274-276) from the counter-based generator and the tape
+// the backward pass reads, written by the workgroups that own the values.  Layout as TrainTape (plain [S][rows][.]).
+struct PTape {
+    float *z[3], *cprev[3], *cnew[3], *hraw[3], *hstate[3];    // attention LSTM, LSTM 1, LSTM 2
+    float *q, *state_prev, *ctx;
+    unsigned seed;
+    int on;
+};
+
 struct PArgs {
     const float *wA, *bA, *w1, *b1, *w2, *b2;   // packed LSTM slabs [256][kbtot][64][4] (pack_skinny), biases [256][16]
     const float *wP, *bP;                       // projection + composed first PreNet layer: [28][64][64][4], bias [448]
@@ -68,6 +77,7 @@ struct PArgs {
     unsigned x2_bytes, x2_stride;               // size of x2_all, bytes per step
     float* y_all;                               // teacher-forced decode: LSTM 2's raw outputs [S][rows][1024] for the deferred projection
     int teacher;
+    PTape tp;
     long long mel_ld, mel_ts;
     int stop_ld;
     int B, T, C, CH, F, KA, MR, max_steps, min_iters, stop_en, cumulative;
@@ -317,6 +327,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     for (int rb = 0; rb < MB; ++rb) { accA[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rb] = accA[rb]; acc2[rb] = accA[rb]; }
     __syncthreads();
 
+    int t = 0;                 // decoder step
     // gate sums of this thread's (row, unit) from the waves' partial tiles; D layout: col = lane & 15, row = 4 (lane >> 4) + reg
     auto gate4 = [&](float (&z)[4]) {
         const int rb = erow >> 4, rr = erow & 15;
@@ -334,12 +345,26 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
     };
     // LSTMCell + inference zoneout (modules.py:261-283): returns raw output, updates (c, h) state
-    auto cell = [&](const float (&z)[4], const float* bv, float& c, float& h) -> float {
+    auto cell = [&](const float (&z)[4], const float* bv, float& c, float& h, int layer) -> float {
         const float zi = z[0] + bv[euu], zj = z[1] + bv[4 + euu], zf = z[2] + bv[8 + euu], zo = z[3] + bv[12 + euu];
         const float cn = sigmoidf_(zf + a.fb) * c + sigmoidf_(zi) * tanhf(zj);
         const float hn = sigmoidf_(zo) * tanhf(cn);
-        c = (1.0f - a.zc) * cn + a.zc * c;
-        h = (1.0f - a.zh) * hn + a.zh * h;
+        if (!a.tp.on) {
+            c = (1.0f - a.zc) * cn + a.zc * c;
+            h = (1.0f - a.zh) * hn + a.zh * h;
+        } else if (eown) {
+            const int unit = wg * 4 + euu, H = NWG * 4;
+            const unsigned stream = (unsigned)(T2_STREAM_ZONE_ATT + 2 * layer);
+            const float cp = c, hp = h;
+            c = (1.0f - a.zc) * dropout_train(cn - cp, a.zc, t2_u01(a.tp.seed, stream, (unsigned)t, (unsigned)erow, (unsigned)unit)) + cp;
+            h = (1.0f - a.zh) * dropout_train(hn - hp, a.zh, t2_u01(a.tp.seed, stream + 1u, (unsigned)t, (unsigned)erow, (unsigned)unit)) + hp;
+            const size_t ti = (size_t)t * B + erow;
+            float* tz = a.tp.z[layer] + ti * 4 * H;
+            tz[unit] = zi; tz[H + unit] = zj; tz[2 * H + unit] = zf; tz[3 * H + unit] = zo;
+            a.tp.cprev[layer][ti * H + unit] = cp; a.tp.cnew[layer][ti * H + unit] = cn;
+            if (a.tp.hraw[layer] != nullptr) a.tp.hraw[layer][ti * H + unit] = hn;
+            a.tp.hstate[layer][ti * H + unit] = h;
+        }
         return hn;
     };
     // the four units of a row sit in four adjacent lanes: lane uu == 0 stores them as one float4 of the frag16 operand
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     unsigned long long st_prev = __builtin_amdgcn_s_memrealtime();
 #endif
     unsigned epoch = 0;        // hops completed so far (identical in every workgroup)
-    int t = 0, final_steps = 0;
+    int final_steps = 0;
     bool alive = true;
     // attention pre-work of the NEXT step, done in a gap: everything of the energies that does not need the query.
     // pre[r][g] = keys[p][u] + (f . W_loc)[p][u] for this lane's (position 16 r + 4 kg + g of the chunk, unit 16 wave + c16)
@@ -499,7 +524,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         if (tid < MB * 64) {
             float z[4];
             gate4(z);
-            const float hn = cell(z, s_bias, cA, hA);
+            const float hn = cell(z, s_bias, cA, hA, 0);
             publish4(hn, a.oHAr);
             publish4(hA, a.oHA);
         }
@@ -564,6 +589,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
 #pragma unroll
                 for (int k = 0; k < KSQ; ++k) q += __builtin_bit_cast(float, (unsigned)g[k]);
                 s_q[tid] = q;
+                if (a.tp.on && ac == 0) a.tp.q[((size_t)t * B + ab) * UA + tid] = q;
             }
             __syncthreads();
             if (s_flag[0]) { alive = false; break; }
@@ -643,6 +669,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             if (tid < n) {
                 const float p = s_a[p0 + tid];
                 a.hist[((size_t)t * B + ab) * T + p0 + tid] = p;
+                if (a.tp.on) a.tp.state_prev[((size_t)t * B + ab) * T + p0 + tid] = s_cum[tid + pl];
                 st4(xs, a.oCUM + (unsigned)((t & 1) * B * T * 4) + (unsigned)((ab * T + p0 + tid) * 4), a.cumulative ? p + s_cum[tid + pl] : p);
             }
             // (f) context slice = alignments . values[:, slice]   (AttentionWrapper._compute_attention)
@@ -661,6 +688,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
                 for (int g = 0; g < NPG; ++g) s += *reinterpret_cast<const f32x4*>(s_cx + g * ES + tid * 4);
                 st16(xs, a.oCTX + frag_off16(ab, (ac * ES >> 2) + tid, MB), s);
+                if (a.tp.on) *reinterpret_cast<f32x4*>(a.tp.ctx + ((size_t)t * B + ab) * EW + ac * ES + tid * 4) = s;
             }
         }
         PZ_STAMP(6); hop_arrive(a.bar); ++epoch; fresh();
@@ -690,7 +718,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         if (tid < MB * 64) {
             float z[4];
             gate4(z);
-            const float hn = cell(z, s_bias + 16, c1, h1);
+            const float hn = cell(z, s_bias + 16, c1, h1, 1);
             publish4(hn, a.oY1);
             publish4(h1, a.oH1);
         }
@@ -719,10 +747,10 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         if (tid < MB * 64) {
             float z[4];
             gate4(z);
-            const float hn = cell(z, s_bias + 32, c2, h2);
+            const float hn = cell(z, s_bias + 32, c2, h2, 2);
             publish4(hn, a.oY2);
             publish4(h2, a.oH2);
-            if (a.teacher && eown) a.y_all[((size_t)t * B + erow) * (NWG * 4) + wg * 4 + euu] = hn;
+            if (a.y_all != nullptr && eown) a.y_all[((size_t)t * B + erow) * (NWG * 4) + wg * 4 + euu] = hn;
         }
 #pragma unroll
         for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};

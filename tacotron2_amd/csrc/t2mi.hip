@@ -1215,6 +1215,11 @@ struct TrainTape {
     float *q, *state_prev, *ctx;              // attention: q + b_a, state before the step, context
 };
 
+static void persist_fill_tape(pz::PTape& tp, const TrainTape* tape) {
+    for (int l = 0; l < 3; ++l) { tp.z[l] = tape->z[l]; tp.cprev[l] = tape->cprev[l]; tp.cnew[l] = tape->cnew[l]; tp.hraw[l] = tape->hraw[l]; tp.hstate[l] = tape->hstate[l]; }
+    tp.q = tape->q; tp.state_prev = tape->state_prev; tp.ctx = tape->ctx; tp.seed = tape->seed; tp.on = 1;
+}
+
 // which launch schedule a decoder step uses (see launch_step)
 static inline bool spread_mode(const t2_model* m, int MB, int feed_mode, bool train) {
     return m->opt_hoist && m->opt_spread && (MB >= 2 || m->opt_spread >= 2) && !m->opt_lstm_only && feed_mode != 3 &&
@@ -1676,7 +1681,9 @@ static inline bool persist_mode_teacher(const t2_state* s) {
     const t2_model* m = s->m;
     return m->opt_persist && m->opt_tfproj && s->pz_xs != nullptr && s->tf_frag != nullptr && s->y_all != nullptr && !m->opt_lstm_only;
 }
-static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en, bool teacher = false) {
+struct TrainTape;
+static void persist_fill_tape(pz::PTape& tp, const TrainTape* tape);
+static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en, bool teacher = false, const TrainTape* tape = nullptr) {
     t2_model* m = s->m;
     const t2_dims& d = m->d;
     hipStream_t st = m->ctx->stream;
@@ -1706,7 +1713,8 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
         if (s->tf_stride != (long long)s->MB * 16 * pz::KBX * 16 || (long long)max_steps * s->tf_stride * 4 > 0x7fffffffLL)
             return fail(T2_ESTATE, "internal: teacher-forced PreNet operands do not have the persistent decoder's geometry");
         a.teacher = 1; a.x2_all = s->tf_frag; a.x2_stride = (unsigned)(s->tf_stride * 4); a.x2_bytes = (unsigned)((long long)max_steps * s->tf_stride * 4);
-        a.y_all = s->y_all;
+        a.y_all = tape ? nullptr : s->y_all;            // the training tape keeps LSTM 2's raw outputs itself (hraw[2])
+        if (tape) persist_fill_tape(a.tp, tape);
     } else {
         // x1 of step 0 = relu(bias of the first PreNet layer): the go frame is zeros (helpers.py:187-188)
         hipLaunchKernelGGL(pz::init_x1_kernel, dim3(ceil_div(s->B * d.prenet_units[0], 256)), dim3(256), 0, st, s->pz_xs + a.oX1 / 4,

@@ -710,8 +710,12 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     io.train = &tr->tape;
     io.y_all = nullptr;                            // the tape keeps LSTM 2's raw output of every step (hraw[2])
     io.slot_hint = 1;                              // the control block's base stays 0: step t runs as step_off = t
-    for (int t = 0; t < S; ++t) T2_TRY(launch_step(s, t, io));       // eager launches: seed and rates are per-call kernel arguments
-    if (io.defer_proj) T2_TRY(teacher_projection(s, tr->tape.hraw[2], s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
+    // the whole teacher-forced recurrence as ONE persistent launch (persist.h, teacher mode + tape), else one launch per phase
+    const bool persist = m->opt_persist && m->opt_tfproj && s->pz_xs != nullptr && s->tf_frag != nullptr && s->proj_tmp != nullptr &&
+                         !m->opt_lstm_only && tr->tape.hraw[2] != nullptr;
+    if (persist) T2_TRY(persist_decode(s, S, 0, 0, true, &tr->tape));
+    else for (int t = 0; t < S; ++t) T2_TRY(launch_step(s, t, io));       // eager launches: seed and rates are per-call kernel arguments
+    if (persist || io.defer_proj) T2_TRY(teacher_projection(s, tr->tape.hraw[2], s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * S * r * M * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));

@@ -147,7 +147,8 @@ def test_postnet_at_bench_shape_against_oracle(paper):
 def test_training_gradients_at_bench_shape_against_autograd():
     """The training step at the sizes bench.py times (profile P, B = 32, T_in = 140; 4 decoder steps keep the fp64 autograd
     reference to ~30 s): the profile-P instantiations of the backward kernels (bwd_dense_kernel<2> with static ring, nine
-    position chunks per row in the attention backward at U = 128, split-K weight-gradient GEMMs) against torch.autograd."""
+    position chunks per row in the attention backward at U = 128, split-K weight-gradient GEMMs) against torch.autograd.  The
+    forward recurrence is the persistent decoder in teacher mode with the tape and sampled zoneout (csrc/persist.h)."""
     import torch
     from oracle import torch_train as TT
     from tacotron2_amd import training as TR
@@ -173,7 +174,9 @@ def test_training_gradients_at_bench_shape_against_autograd():
     tr.bind_gradients(spec)
     memory, _ = tr.encoder_forward(ids, lens, drop_rate=0.5, seed=3)
     np.testing.assert_allclose(_np(memory), ref["memory"], atol=ATOL)
+    before = eng.get_stat("persist_launches")
     mel, stop, align = tr.decoder_forward(memory, lens, labels["mel"], prenet_drop_rate=0.5, seed=3)
+    assert eng.get_stat("persist_launches") == before + 1, "the training forward did not run as the persistent launch"
     np.testing.assert_allclose(_np(mel), ref["mel"], atol=ATOL)
     flat = torch.zeros(TR.flat_size(spec), dtype=torch.float32, device="cuda")
     dmem, losses = tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat)
