@@ -127,6 +127,7 @@ struct t2_model {
     unsigned long long param_gen = 0;   // bumped by t2_trainer_load_params; trainers compare it with their own generation
     const float* last_flat = nullptr;   // flat parameter buffer of the last refresh (owned by the caller)
     long long n_persist = 0;            // persistent decodes launched (stat "persist_launches")
+    int opt_bwd_splitk = 1;             // training backward: K = 4H data-gradient GEMMs split in two halves over the grid (train_step.h)
     int opt_persist = 1;                // free-running decodes of the paper-size dimension class run as ONE persistent launch (persist.h)
 };
 
@@ -420,6 +421,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
     else if (!strcmp(name, "persist")) m->opt_persist = value;
+    else if (!strcmp(name, "bwd_splitk")) m->opt_bwd_splitk = value;
     else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
     else return fail(T2_EINVAL, "unknown option %s", name);
     return T2_OK;

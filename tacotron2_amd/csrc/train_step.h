@@ -129,22 +129,55 @@ struct BwdEpi {
     const float* pn_y; float pn_inv_keep; float *pn_plain, *pn_frag; int pn_P;
 };
 
-template <int MB>
-__global__ __launch_bounds__(T2_SKINNY_THREADS) void bwd_dense_kernel(SkinnyCore a, BwdEpi e) {
+// NPW > 0: the statically unrolled walk of skinny_core (counted vmcnt waits).
+// SPLIT: the K range is cut in two halves over blockIdx.y so that the K = 4H products of the recurrence (N / 16 = 112..160
+// column tiles) occupy the whole chip: both workgroups of a tile store their partial tile write-through (sc1), drain, and take
+// a ticket (one agent-scope atomic add); the one whose add came last reads the other half with sc1 loads, runs the epilogue
+// on the sum (two addends: order-independent, deterministic) and clears the ticket for the next launch.
+// (MI355X_MICROARCH.md, "Valid forms", sc1 table row 1: one unsharded counter, the last adder told by the returned value.)
+#define T2_SK_MAX_TILES 256
+template <int MB, int NPW = 0, bool SPLIT = false>
+__global__ __launch_bounds__(T2_SKINNY_THREADS) void bwd_dense_kernel(SkinnyCore a, BwdEpi e, float* sk_part, unsigned* sk_ticket) {
     __shared__ f32x4 red[T2_SKINNY_WAVES * MB * 64];
+    __shared__ __attribute__((aligned(16))) float s_tile[SPLIT ? MB * 256 : 4];
+    __shared__ unsigned s_old;
     f32x4 acc[MB];
     const int wg = blockIdx.x;
-    const int t = skinny_core<MB, 0>(a, 0, wg, acc, [](int) {});
+    if constexpr (SPLIT) {
+        const int hk = a.kbtot / 2, half = (int)blockIdx.y;
+        a.kbtot = hk; a.kb_w0 += half * hk; a.seg[0][1].koff += half * hk * 16;
+    }
+    const int t = skinny_core<MB, NPW>(a, 0, wg, acc, [](int) {});
     if (t < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
     __syncthreads();
+    if constexpr (SPLIT) {
+        const int half = (int)blockIdx.y;
+        for (int idx = threadIdx.x; idx < MB * 256; idx += T2_SKINNY_THREADS) s_tile[idx] = red_sum<MB>(red, idx >> 4, idx & 15);
+        __syncthreads();
+        const pz::rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(sk_part + (size_t)wg * 2 * MB * 256, 0, 2 * MB * 256 * 4, 0x00020000);
+        if (threadIdx.x < MB * 64) pz::st16(rp, (unsigned)((half * MB * 256 + threadIdx.x * 4) * 4), *reinterpret_cast<const f32x4*>(s_tile + threadIdx.x * 4));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_old = __hip_atomic_fetch_add(sk_ticket + wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_old == 0u) return;                           // the other half has not arrived yet: it will finish the tile
+        if (threadIdx.x == 0) __hip_atomic_store(sk_ticket + wg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < MB * 64) {
+            const f32x4 o = pz::ld16(rp, (unsigned)(((half ^ 1) * MB * 256 + threadIdx.x * 4) * 4));
+            f32x4* mine = reinterpret_cast<f32x4*>(s_tile + threadIdx.x * 4);
+            *mine = *mine + o;
+        }
+        __syncthreads();
+    }
     for (int idx = threadIdx.x; idx < MB * 16 * 16; idx += T2_SKINNY_THREADS) {
         const int row = idx >> 4, c = idx & 15;
         const int col = wg * 16 + c;
         if (row >= a.B || col >= e.N) continue;
-        const float v = red_sum<MB>(red, row, c);
+        float v;
+        if constexpr (SPLIT) v = s_tile[idx]; else v = red_sum<MB>(red, row, c);
         if (e.out_plain != nullptr) e.out_plain[(size_t)row * e.plain_ld + col] = v;
         if (e.mode == 1) {
             if (col < e.lb.H) lstm_bwd_elem(e.lb, row, col, v);
@@ -608,6 +641,7 @@ struct t2_trainer {
     float* cs_part = nullptr;                      // column-sum partials [chunks][N], T2_CS_PART_FLOATS
     double* bn_part = nullptr; int bn_cols = 0;    // batch-norm reduction partials [T2_BN_CHUNKS][2][bn_cols]
     float* wg_part = nullptr;                      // split-K partials of the weight-gradient GEMMs [splits][rows][cols]
+    float* sk_part = nullptr; unsigned* sk_ticket = nullptr;   // split-K halves of the recurrence's data-gradient GEMMs (bwd_dense_kernel SPLIT)
     std::map<std::string, long long> offsets;      // flat-gradient layout given by the caller
     const float* glob_counts = nullptr;            // dev [2]: non-zero loss weights of the whole data-parallel batch (null: this rank's own)
     unsigned long long gen = 0;                    // parameter generation (t2_model::param_gen) the trainer-owned operands were built from
@@ -792,6 +826,14 @@ static int trainer_setup_backward(t2_trainer* tr) {
     const size_t o_tmp = carve((size_t)std::max(D * N, 4096)), o_loss = carve(16);
     tr->bslab_bytes = off;
     HIP_TRY(hipMalloc(&tr->bslab, off));
+    {
+        const size_t part_bytes = (size_t)T2_SK_MAX_TILES * 2 * MB * 256 * 4;
+        char* q = nullptr;
+        HIP_TRY(hipMalloc((void**)&q, part_bytes + T2_SK_MAX_TILES * 4));
+        tr->allocs.push_back(q);
+        HIP_TRY(hipMemset(q, 0, part_bytes + T2_SK_MAX_TILES * 4));
+        tr->sk_part = (float*)q; tr->sk_ticket = (unsigned*)(q + part_bytes);
+    }
     char* p = (char*)tr->bslab;
     tr->dY = (float*)(p + o_dY); tr->dYf = (float*)(p + o_dYf);
     for (int l = 0; l < 3; ++l) {
@@ -854,10 +896,41 @@ static void bwd_dense_epi(t2_trainer* tr, const Packed& wT, float* x_frag, BwdEp
     c.kb0 = 0; c.kbtot = wT.kbtot; c.kb_w0 = 0; c.kb_full = wT.kbtot; c.ctl = nullptr; c.step_off = 0; c.t_hint = 0; c.B = tr->B;
     c.seg[0][1] = FragBuf{x_frag, 0, 1, 0, 0};
     hipStream_t st = tr->m->ctx->stream;
+    const int G = MB >= 4 ? T2_G4 : 4;
+    const bool split = tr->sk_part != nullptr && wT.kbtot >= 128 && wT.kbtot % (2 * G) == 0 && wT.n_wg <= T2_SK_MAX_TILES && tr->m->opt_bwd_splitk;
+    const int per_wave = ((split ? wT.kbtot / 2 : wT.kbtot) / G) / T2_SKINNY_WAVES;
+    const dim3 grid(wT.n_wg, split ? 2 : 1), blk(T2_SKINNY_THREADS);
+    float* sp = tr->sk_part; unsigned* tk = tr->sk_ticket;
+    if (split) {
+        switch (MB) {
+            case 1:
+                if (per_wave == 4) hipLaunchKernelGGL((bwd_dense_kernel<1, 4, true>), grid, blk, 0, st, c, e, sp, tk);
+                else hipLaunchKernelGGL((bwd_dense_kernel<1, 0, true>), grid, blk, 0, st, c, e, sp, tk);
+                break;
+            case 2:
+                if (per_wave == 4) hipLaunchKernelGGL((bwd_dense_kernel<2, 4, true>), grid, blk, 0, st, c, e, sp, tk);
+                else hipLaunchKernelGGL((bwd_dense_kernel<2, 0, true>), grid, blk, 0, st, c, e, sp, tk);
+                break;
+            default:
+                if (per_wave == 8) hipLaunchKernelGGL((bwd_dense_kernel<4, 8, true>), grid, blk, 0, st, c, e, sp, tk);
+                else hipLaunchKernelGGL((bwd_dense_kernel<4, 0, true>), grid, blk, 0, st, c, e, sp, tk);
+                break;
+        }
+        return;
+    }
     switch (MB) {
-        case 1: hipLaunchKernelGGL(bwd_dense_kernel<1>, dim3(wT.n_wg), dim3(T2_SKINNY_THREADS), 0, st, c, e); break;
-        case 2: hipLaunchKernelGGL(bwd_dense_kernel<2>, dim3(wT.n_wg), dim3(T2_SKINNY_THREADS), 0, st, c, e); break;
-        default: hipLaunchKernelGGL(bwd_dense_kernel<4>, dim3(wT.n_wg), dim3(T2_SKINNY_THREADS), 0, st, c, e); break;
+        case 1:
+            if (per_wave == 8) hipLaunchKernelGGL((bwd_dense_kernel<1, 8>), grid, blk, 0, st, c, e, sp, tk);
+            else hipLaunchKernelGGL((bwd_dense_kernel<1, 0>), grid, blk, 0, st, c, e, sp, tk);
+            break;
+        case 2:
+            if (per_wave == 8) hipLaunchKernelGGL((bwd_dense_kernel<2, 8>), grid, blk, 0, st, c, e, sp, tk);
+            else hipLaunchKernelGGL((bwd_dense_kernel<2, 0>), grid, blk, 0, st, c, e, sp, tk);
+            break;
+        default:
+            if (per_wave == 16) hipLaunchKernelGGL((bwd_dense_kernel<4, 16>), grid, blk, 0, st, c, e, sp, tk);
+            else hipLaunchKernelGGL((bwd_dense_kernel<4, 0>), grid, blk, 0, st, c, e, sp, tk);
+            break;
     }
 }
 
