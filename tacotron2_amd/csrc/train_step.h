@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void prenet_bwd_kernel(const float* __restrict
         const int row = i / N, c = i - row * N;
         const float v = y[i] != 0.f ? g0[(size_t)row * ld0 + c] * inv_keep : 0.f;
         d_plain[i] = v;
-        d_frag[frag_idx(row, c, MB)] = v;
+        if (d_frag != nullptr) d_frag[frag_idx(row, c, MB)] = v;
     }
 }
 
@@ -627,6 +627,8 @@ struct t2_trainer {
     std::vector<void*> allocs;
     Packed projT, lstmT[3], wqT, prenetT[T2_MAX_PRENET_LAYERS];
     float* wmemT = nullptr;             // [U][E] memory layer transposed (plain)
+    float* prenetTp[T2_MAX_PRENET_LAYERS] = {};    // PreNet layer i >= 1 transposed (plain [P_i][P_{i-1}]): its data gradient runs once, after the loop
+    float* dpre_tmp = nullptr;          // [S*B][max PreNet width]
     void* bslab = nullptr; size_t bslab_bytes = 0;
     float *dY = nullptr, *dYf = nullptr, *dz[3] = {}, *dzf[3] = {}, *dq = nullptr, *dqf = nullptr;
     float *dpre[T2_MAX_PRENET_LAYERS] = {}, *dpref[T2_MAX_PRENET_LAYERS] = {}, *xin = nullptr;
@@ -798,6 +800,16 @@ static int trainer_setup_backward(t2_trainer* tr) {
         tr->allocs.push_back(tr->wmemT);
         HIP_TRY(hipMemcpy(tr->wmemT, t.data(), t.size() * 4, hipMemcpyHostToDevice));
     }
+    for (int i = 1; i < np; ++i) {
+        const HostWeight* w;
+        const int Pi = d.prenet_units[i], Pp = d.prenet_units[i - 1];
+        T2_TRY(get_w(m, "decoder/prenet_" + std::to_string(i) + "/dense/kernel", &w, {Pp, Pi}));
+        std::vector<float> t((size_t)Pi * Pp);
+        for (int k = 0; k < Pp; ++k) for (int c = 0; c < Pi; ++c) t[(size_t)c * Pp + k] = w->data[(size_t)k * Pi + c];
+        HIP_TRY(hipMalloc((void**)&tr->prenetTp[i], t.size() * 4));
+        tr->allocs.push_back(tr->prenetTp[i]);
+        HIP_TRY(hipMemcpy(tr->prenetTp[i], t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
     // workspaces
     const int H[3] = {A, D, D};
     const int KX[3] = {P_last + E + A, A + E + D, D + D};
@@ -823,7 +835,7 @@ static int trainer_setup_backward(t2_trainer* tr) {
                  o_img = carve((size_t)ab_image_floats(U, d.attention_filters, d.attention_kernel));
     if (T2_AB_J + d.attention_kernel - 1 > T2_AB_THREADS || U > 256)
         return fail(T2_EINVAL, "attention kernel size / attention_dim too large for the attention backward kernels");
-    const size_t o_tmp = carve((size_t)std::max(D * N, 4096)), o_loss = carve(16);
+    const size_t o_tmp = carve((size_t)std::max(D * N, 4096)), o_loss = carve(16), o_dpt = carve(SB * pmax);
     tr->bslab_bytes = off;
     HIP_TRY(hipMalloc(&tr->bslab, off));
     {
@@ -845,7 +857,7 @@ static int trainer_setup_backward(t2_trainer* tr) {
     tr->xin = (float*)(p + o_xin); tr->dy2 = (float*)(p + o_dy2); tr->dhq = (float*)(p + o_dhq); tr->dxp = (float*)(p + o_dxp);
     tr->g_state = (float*)(p + o_gs); tr->dkeys = (float*)(p + o_dk); tr->dvalues = (float*)(p + o_dv);
     tr->p_va = (float*)(p + o_pva); tr->part_dva = (float*)(p + o_pdva);
-    tr->tmp = (float*)(p + o_tmp); tr->loss3 = (float*)(p + o_loss);
+    tr->tmp = (float*)(p + o_tmp); tr->loss3 = (float*)(p + o_loss); tr->dpre_tmp = (float*)(p + o_dpt);
     tr->de_all = (float*)(p + o_de); tr->dctx_all = (float*)(p + o_dctx); tr->part_dq = (float*)(p + o_pdq); tr->part_ds = (float*)(p + o_pds);
     tr->ab_image = (float*)(p + o_img);
     {   // tape-wide du / f / df of the attention backward: written row by row every call, so outside the zero-filled slab
@@ -1089,14 +1101,18 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
             prenet_epi(e, np - 1);
             bwd_dense_epi(tr, tr->lstmT[0], tr->dzf[0], e);
         }
-        for (int i = np - 1; i >= 1; --i) {
-            BwdEpi e{};
-            e.N = d.prenet_units[i - 1]; e.out_plain = nullptr;
-            prenet_epi(e, i - 1);
-            bwd_dense_epi(tr, tr->prenetT[i], tr->dpref[i], e);
-        }
     }
     HIP_TRY(hipGetLastError());
+    // the PreNet layers below the last one do not feed the recurrence: their data gradients are one GEMM over all S*B tape rows
+    // each, d x_{i-1} = dropout'(relu'( d pre_i . W_i^T )) (modules.py:88-91 backward)
+    for (int i = np - 1; i >= 1; --i) {
+        const int Pi = d.prenet_units[i], Pp = d.prenet_units[i - 1];
+        ConvLayer L;
+        L.w = tr->prenetTp[i]; L.k = 1; L.cin = Pi; L.cout = Pp;
+        T2_TRY(launch_conv(m, L, tr->dpre[i], Pi, tr->dpre_tmp, Pp, (int)SB, (int)SB, 0, nullptr, 0));
+        hipLaunchKernelGGL(prenet_bwd_kernel, grid1((long long)SB * Pp), dim3(256), 0, st, tr->dpre_tmp, Pp, tp.xp[i - 1], 1.0f / (1.0f - tp.prenet_drop_rate),
+                           tr->dpre[i - 1], (float*)nullptr, (int)SB, Pp, MB);
+    }
     // ---- weight gradients: one GEMM per K segment over all S*B rows of the tape
     float* g = nullptr;
     const long long rows1 = (long long)(S - 1) * B;
@@ -1817,6 +1833,9 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
             T2_TRY(copy(m->prenet_plain[i].shift, b, d.prenet_units[i]));
         }
         if (trainer_part && i > 0) repack(st, tr->prenetT[i], w, 1, d.prenet_units[i], d.prenet_units[i - 1]);
+        if (trainer_part && i > 0 && tr->prenetTp[i])
+            hipLaunchKernelGGL(transpose_kernel, grid1((long long)d.prenet_units[i] * d.prenet_units[i - 1]), dim3(256), 0, st, tr->prenetTp[i],
+                               d.prenet_units[i - 1], w, d.prenet_units[i], d.prenet_units[i], d.prenet_units[i - 1]);
         pin = d.prenet_units[i];
     }
     const char* lname[3] = {"decoder/attention_lstm", "decoder/lstm_1", "decoder/lstm_2"};
