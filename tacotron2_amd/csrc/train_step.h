@@ -126,6 +126,8 @@ struct BwdEpi {
     float* out_plain; int plain_ld;          // y itself, may be null
     int mode, col0;
     LstmBwdArgs lb;
+    int mode_b, col0_b;                      // mode_b == 3: a second fused cell backward, of the layer whose state gradient the
+    LstmBwdArgs lb2;                         // columns [col0_b, col0_b + lb2.H) are (decoder LSTM 2's previous step)
     const float* pn_y; float pn_inv_keep; float *pn_plain, *pn_frag; int pn_P;
 };
 
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(T2_SKINNY_THREADS) void bwd_dense_kernel(SkinnyCore
         float v;
         if constexpr (SPLIT) v = s_tile[idx]; else v = red_sum<MB>(red, row, c);
         if (e.out_plain != nullptr) e.out_plain[(size_t)row * e.plain_ld + col] = v;
+        if (e.mode_b == 3 && col >= e.col0_b && col < e.col0_b + e.lb2.H) lstm_bwd_elem(e.lb2, row, col - e.col0_b, v, true);
         if (e.mode == 1) {
             if (col < e.lb.H) lstm_bwd_elem(e.lb, row, col, v);
         } else if (e.mode == 3) {
@@ -426,6 +429,10 @@ struct AttnBwdArgs {
     float *part_dq, *part_dva, *part_ds;      // [B][NJ][U], [B][NJ][U], [B][NJ][J + K - 1]
     float *du_out, *f_out, *df_out;           // this step's slices of the tape-wide du [B][T][U], f [B][T][F], df [B][T][F]
     int B, T, U, E, F, K, NJ, first;
+    // the row's last chunk to arrive sums the partials (what attention_bwd_finish_kernel did as a launch of its own)
+    unsigned* ticket;                         // [B], zero between launches
+    float *dq_plain, *dq_frag, *g_state_out, *p_va;
+    int MB, cumulative;
 };
 
 __host__ __device__ inline int attn_bwd_lds_floats(int U, int E, int F, int K) {
@@ -557,8 +564,8 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArg
         for (int j = 0; j < J; ++j) s += L.du[j * U + u];
 #pragma unroll
         for (int jq = 0; jq < J / 4; ++jq) sv += s_dva[jq * U + u];
-        a.part_dq[((size_t)b * a.NJ + ch) * U + u] = s;
-        a.part_dva[((size_t)b * a.NJ + ch) * U + u] = sv;
+        __hip_atomic_store(a.part_dq + ((size_t)b * a.NJ + ch) * U + u, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1):
+        __hip_atomic_store(a.part_dva + ((size_t)b * a.NJ + ch) * U + u, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // read inside this launch
     }
     for (int i = tid; i < jt * U; i += T2_AB_THREADS) a.du_out[((size_t)b * T + j0) * U + i] = L.du[i];
     ab_df(L, U, F, tid);
@@ -581,7 +588,37 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArg
         }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
-        if (i < NI && cg == 0) a.part_ds[((size_t)b * a.NJ + ch) * NI + i] = acc;
+        if (i < NI && cg == 0) __hip_atomic_store(a.part_ds + ((size_t)b * a.NJ + ch) * NI + i, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- in-launch hand-off to the row's last chunk (MI355X_MICROARCH.md "Valid forms", sc1 table row 1: sc1 partial stores,
+    //      every wave drains, barrier, one agent-scope atomic add on ONE counter per row; the workgroup whose add came last reads
+    //      all partials with sc1 loads).  Chunks past the row's length never run this far and are not counted.
+    __shared__ unsigned s_old;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_old = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned n_active = (unsigned)max(1, (min(len, T) + J - 1) / J);
+    if (s_old != n_active - 1u) return;
+    if (tid == 0) __hip_atomic_store(a.ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int u = tid; u < U; u += T2_AB_THREADS) {
+        float s = 0.f;
+        float sv = a.first ? 0.f : a.p_va[(size_t)b * U + u];
+        for (int c2 = 0; c2 < a.NJ; ++c2) {
+            s += __hip_atomic_load(a.part_dq + ((size_t)b * a.NJ + c2) * U + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sv += __hip_atomic_load(a.part_dva + ((size_t)b * a.NJ + c2) * U + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a.dq_plain[(size_t)b * U + u] = s;
+        a.dq_frag[frag_idx(b, u, a.MB)] = s;
+        a.p_va[(size_t)b * U + u] = sv;
+    }
+    for (int p = tid; p < T; p += T2_AB_THREADS) {
+        float s = (a.cumulative && !a.first) ? a.g_state[(size_t)b * T + p] : 0.f;    // state_t = state_{t-1} + a_t
+        for (int c2 = 0; c2 < a.NJ; ++c2) {
+            const int i = p - (c2 * J - pad_l);
+            if (i >= 0 && i < NI) s += __hip_atomic_load(a.part_ds + ((size_t)b * a.NJ + c2) * NI + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a.g_state_out[(size_t)b * T + p] = s;
     }
 }
 
@@ -629,6 +666,9 @@ struct t2_trainer {
     float* wmemT = nullptr;             // [U][E] memory layer transposed (plain)
     float* prenetTp[T2_MAX_PRENET_LAYERS] = {};    // PreNet layer i >= 1 transposed (plain [P_i][P_{i-1}]): its data gradient runs once, after the loop
     float* dpre_tmp = nullptr;          // [S*B][max PreNet width]
+    float* projTp = nullptr;            // [M*r + 1][D] projections transposed (plain): d y2 of all steps is one GEMM before the loop
+    float* dy2_all = nullptr;           // [S*B][D]
+    float* dzf2b = nullptr;             // second frag16 operand of LSTM 2's dz (ping-pong with dzf[2] by step parity)
     void* bslab = nullptr; size_t bslab_bytes = 0;
     float *dY = nullptr, *dYf = nullptr, *dz[3] = {}, *dzf[3] = {}, *dq = nullptr, *dqf = nullptr;
     float *dpre[T2_MAX_PRENET_LAYERS] = {}, *dpref[T2_MAX_PRENET_LAYERS] = {}, *xin = nullptr;
@@ -779,6 +819,9 @@ static int trainer_setup_backward(t2_trainer* tr) {
             for (int c = 0; c < M * r; ++c) t[(size_t)c * D + k] = wm->data[(size_t)k * M * r + c];
             t[(size_t)(M * r) * D + k] = ws->data[k];
         }
+        HIP_TRY(hipMalloc((void**)&tr->projTp, t.size() * 4));
+        tr->allocs.push_back(tr->projTp);
+        HIP_TRY(hipMemcpy(tr->projTp, t.data(), t.size() * 4, hipMemcpyHostToDevice));
         const size_t before = m->allocs.size();
         T2_TRY(pack_skinny(m, &tr->projT, t.data(), D, {{0, N}}, 0, D, nullptr));
         for (size_t i = before; i < m->allocs.size(); ++i) tr->allocs.push_back(m->allocs[i]);
@@ -835,15 +878,16 @@ static int trainer_setup_backward(t2_trainer* tr) {
                  o_img = carve((size_t)ab_image_floats(U, d.attention_filters, d.attention_kernel));
     if (T2_AB_J + d.attention_kernel - 1 > T2_AB_THREADS || U > 256)
         return fail(T2_EINVAL, "attention kernel size / attention_dim too large for the attention backward kernels");
-    const size_t o_tmp = carve((size_t)std::max(D * N, 4096)), o_loss = carve(16), o_dpt = carve(SB * pmax);
+    const size_t o_tmp = carve((size_t)std::max(D * N, 4096)), o_loss = carve(16), o_dpt = carve(SB * pmax), o_dy2a = carve(SB * D),
+                 o_dzf2b = carve((size_t)R * pad16(4 * D));
     tr->bslab_bytes = off;
     HIP_TRY(hipMalloc(&tr->bslab, off));
     {
         const size_t part_bytes = (size_t)T2_SK_MAX_TILES * 2 * MB * 256 * 4;
         char* q = nullptr;
-        HIP_TRY(hipMalloc((void**)&q, part_bytes + T2_SK_MAX_TILES * 4));
+        HIP_TRY(hipMalloc((void**)&q, part_bytes + (T2_SK_MAX_TILES + 64) * 4));      // + one ticket per batch row (attention_bwd_kernel)
         tr->allocs.push_back(q);
-        HIP_TRY(hipMemset(q, 0, part_bytes + T2_SK_MAX_TILES * 4));
+        HIP_TRY(hipMemset(q, 0, part_bytes + (T2_SK_MAX_TILES + 64) * 4));
         tr->sk_part = (float*)q; tr->sk_ticket = (unsigned*)(q + part_bytes);
     }
     char* p = (char*)tr->bslab;
@@ -858,6 +902,7 @@ static int trainer_setup_backward(t2_trainer* tr) {
     tr->g_state = (float*)(p + o_gs); tr->dkeys = (float*)(p + o_dk); tr->dvalues = (float*)(p + o_dv);
     tr->p_va = (float*)(p + o_pva); tr->part_dva = (float*)(p + o_pdva);
     tr->tmp = (float*)(p + o_tmp); tr->loss3 = (float*)(p + o_loss); tr->dpre_tmp = (float*)(p + o_dpt);
+    tr->dy2_all = (float*)(p + o_dy2a); tr->dzf2b = (float*)(p + o_dzf2b);
     tr->de_all = (float*)(p + o_de); tr->dctx_all = (float*)(p + o_dctx); tr->part_dq = (float*)(p + o_pdq); tr->part_ds = (float*)(p + o_pds);
     tr->ab_image = (float*)(p + o_img);
     {   // tape-wide du / f / df of the attention backward: written row by row every call, so outside the zero-filled slab
@@ -1032,33 +1077,44 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     const size_t lds = (size_t)attn_bwd_lds_floats(U, E, F, K) * 4;
     const int NJ = tr->NJ;
     hipLaunchKernelGGL(attention_image_kernel, dim3(1), dim3(256), 0, st, m->conv_w, m->conv_b, m->wloc, m->v_a, tr->ab_image, U, F, K);
+    // Nothing of the loss gradient depends on the recurrence: d y2 (projection part) of all steps is one GEMM
+    // (rnn_wrappers.py:105-109 backward), and LSTM 2's cell backward of step t - 1 rides in the epilogue of step t's
+    // d [y1 | h2_prev] product (its columns [D, 2D) are the state gradient it waits for); the last step's runs on its own.
+    {
+        ConvLayer L;
+        L.w = tr->projTp; L.k = 1; L.cin = N; L.cout = D;
+        T2_TRY(launch_conv(m, L, tr->dY, N, tr->dy2_all, D, (int)SB, (int)SB, 0, nullptr, 0));
+    }
+    float* const dzf2[2] = {tr->dzf[2], tr->dzf2b};
+    auto lstm_args_at = [&](int l, int tt, int first_, const float* go0, int ld0, const float* gh1, int ldh1, float* dz_frag) {
+        LstmBwdArgs a{};
+        a.z = tp.z[l] + (size_t)tt * B * 4 * H[l]; a.cprev = tp.cprev[l] + (size_t)tt * B * H[l]; a.cnew = tp.cnew[l] + (size_t)tt * B * H[l];
+        a.g_out0 = go0; a.ld_out0 = ld0; a.g_out1 = nullptr; a.ld_out1 = 0;
+        a.g_hs0 = tr->g_hp[l]; a.ld_hs0 = H[l]; a.g_hs1 = gh1; a.ld_hs1 = ldh1;
+        a.g_c = tr->g_c[l]; a.g_hp = tr->g_hp[l];
+        a.dz_plain = tr->dz[l] + (size_t)tt * B * 4 * H[l]; a.dz_frag = dz_frag;
+        a.B = B; a.H = H[l]; a.MB = MB; a.t = tt; a.stream = stream_of[l]; a.seed = tp.seed;
+        a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias; a.first = first_;
+        return a;
+    };
+    hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * D), dim3(256), 0, st,
+                       lstm_args_at(2, S - 1, 1, tr->dy2_all + (size_t)(S - 1) * B * D, D, nullptr, 0, dzf2[(S - 1) & 1]));
     for (int t = S - 1; t >= 0; --t) {
         const int first = (t == S - 1) ? 1 : 0;
         auto lstm_args = [&](int l, const float* go0, int ld0, const float* gh1, int ldh1) {
-            LstmBwdArgs a{};
-            a.z = tp.z[l] + (size_t)t * B * 4 * H[l]; a.cprev = tp.cprev[l] + (size_t)t * B * H[l]; a.cnew = tp.cnew[l] + (size_t)t * B * H[l];
-            a.g_out0 = go0; a.ld_out0 = ld0; a.g_out1 = nullptr; a.ld_out1 = 0;
-            a.g_hs0 = tr->g_hp[l]; a.ld_hs0 = H[l]; a.g_hs1 = gh1; a.ld_hs1 = ldh1;
-            a.g_c = tr->g_c[l]; a.g_hp = tr->g_hp[l];
-            a.dz_plain = tr->dz[l] + (size_t)t * B * 4 * H[l]; a.dz_frag = tr->dzf[l];
-            a.B = B; a.H = H[l]; a.MB = MB; a.t = t; a.stream = stream_of[l]; a.seed = tp.seed;
-            a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias; a.first = first;
-            return a;
+            return lstm_args_at(l, t, first, go0, ld0, gh1, ldh1, tr->dzf[l]);
         };
         // Every elementwise stage rides in the epilogue of the GEMM that produces its input gradient.
-        // projections -> d y2, LSTM 2 backward (input [y1 | h2_prev])
-        {
-            BwdEpi e{};
-            e.N = D; e.out_plain = nullptr; e.mode = 1;
-            e.lb = lstm_args(2, nullptr, 0, tr->dX[2] + D, KX[2]);
-            bwd_dense_epi(tr, tr->projT, tr->dYf + (size_t)t * MB * 16 * pad16(N), e);
-        }
-        // d [y1 | h2_prev], LSTM 1 backward (input [h_att | ctx | h1_prev])
+        // d [y1 | h2_prev] -> LSTM 1 backward (input [h_att | ctx | h1_prev]) and LSTM 2 backward of step t - 1
         {
             BwdEpi e{};
             e.N = KX[2]; e.out_plain = tr->dX[2]; e.plain_ld = KX[2]; e.mode = 1;
             e.lb = lstm_args(1, nullptr, 0, tr->dX[1] + A + E, KX[1]);
-            bwd_dense_epi(tr, tr->lstmT[2], tr->dzf[2], e);
+            if (t > 0) {
+                e.mode_b = 3; e.col0_b = D;
+                e.lb2 = lstm_args_at(2, t - 1, 0, tr->dy2_all + (size_t)(t - 1) * B * D, D, nullptr, 0, dzf2[(t - 1) & 1]);
+            }
+            bwd_dense_epi(tr, tr->lstmT[2], dzf2[t & 1], e);
         }
         bwd_dense(tr, tr->lstmT[1], tr->dzf[1], tr->dX[1], KX[1]);
         // attention
@@ -1074,11 +1130,9 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
             a.part_dq = tr->part_dq; a.part_dva = tr->part_dva; a.part_ds = tr->part_ds;
             a.du_out = tr->du_all + (size_t)t * B * T * U; a.f_out = tr->f_all + (size_t)t * B * T * F; a.df_out = tr->df_all + (size_t)t * B * T * F;
             a.B = B; a.T = T; a.U = U; a.E = E; a.F = F; a.K = K; a.NJ = NJ; a.first = first;
+            a.ticket = tr->sk_ticket + T2_SK_MAX_TILES; a.dq_plain = tr->dq + (size_t)t * B * U; a.dq_frag = tr->dqf; a.g_state_out = tr->g_state;
+            a.p_va = tr->p_va; a.MB = MB; a.cumulative = d.cumulative_weights;
             hipLaunchKernelGGL(attention_bwd_kernel, dim3(NJ, B), dim3(T2_AB_THREADS), lds, st, a);
-            AttnBwdFinishArgs f{};
-            f.part_dq = tr->part_dq; f.part_dva = tr->part_dva; f.part_ds = tr->part_ds; f.p_va = tr->p_va; f.dq_plain = tr->dq + (size_t)t * B * U; f.dq_frag = tr->dqf; f.g_state = tr->g_state;
-            f.B = B; f.T = T; f.U = U; f.K = K; f.NJ = NJ; f.MB = MB; f.cumulative = d.cumulative_weights; f.first = first;
-            hipLaunchKernelGGL(attention_bwd_finish_kernel, dim3(B), dim3(256), 0, st, f);
         }
         // query layer -> d h_att (second source), attention LSTM backward (input [prenet out | ctx_prev | h_att_prev]; its raw
         // output feeds LSTM 1 and the query layer)
@@ -1874,6 +1928,7 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
             T2_TRY(copy(m->proj.bias + M * r, bs, 1));
         }
         if (trainer_part) repack(st, tr->projT, wc, 1, N, D);
+        if (trainer_part && tr->projTp) hipLaunchKernelGGL(transpose_kernel, grid1((long long)N * D), dim3(256), 0, st, tr->projTp, D, wc, N, N, D);
     }
     if (model_part) {
         cin = M;
