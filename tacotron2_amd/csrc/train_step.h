@@ -1391,24 +1391,46 @@ __global__ __launch_bounds__(256) void enc_dx_scatter_kernel(const float* __rest
     }
 }
 
-// d embedding[sym][:] = sum over the rows m with ids[m] == sym of dx[m][:]: one block per symbol, rows in order (deterministic)
+// d embedding[sym][:] = sum over the rows m with ids[m] == sym of dx[m][:]: one block per symbol.  The block first compacts the
+// matching row numbers into LDS in row order (ballot + prefix counts per 256 rows), then every thread sums its columns over
+// that list: the rows are added in increasing order whatever the block's scheduling (deterministic).
 __global__ __launch_bounds__(256) void embedding_grad_kernel(const int* __restrict__ ids, const float* __restrict__ dx, int M, int C, float* __restrict__ demb) {
-    __shared__ int s_ids[1024];
-    const int sym = blockIdx.x;
-    for (int c0 = 0; c0 < C; c0 += blockDim.x) {
-        const int c = c0 + threadIdx.x;
-        float acc = 0.f;
-        for (int m0 = 0; m0 < M; m0 += 1024) {          // the row ids go through LDS: every thread scans them
-            __syncthreads();
-            for (int i = threadIdx.x; i < 1024 && m0 + i < M; i += blockDim.x) s_ids[i] = ids[m0 + i];
-            __syncthreads();
-            const int n = min(1024, M - m0);
-            if (c < C)
-                for (int i = 0; i < n; ++i)
-                    if (s_ids[i] == sym) acc += dx[(size_t)(m0 + i) * C + c];
+    constexpr int CAP = 2048;
+    __shared__ int s_list[CAP + 256];
+    __shared__ int s_wave[4];
+    __shared__ int s_n;
+    const int sym = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int CMAX = 8;                              // columns per thread: C <= 2048
+    float acc[CMAX];
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) acc[k] = 0.f;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    auto flush = [&]() {
+        const int n = s_n;
+        for (int i = 0; i < n; ++i) {
+            const float* row = dx + (size_t)s_list[i] * C;
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k) { const int c = tid + k * 256; if (c < C) acc[k] += row[c]; }
         }
-        if (c < C) demb[(size_t)sym * C + c] = acc;
+    };
+    for (int m0 = 0; m0 < M; m0 += 256) {
+        const int m = m0 + tid;
+        const bool hit = m < M && ids[m] == sym;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int base = s_n;
+        for (int w = 0; w < wave; ++w) base += s_wave[w];
+        if (hit) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = m;
+        __syncthreads();
+        if (tid == 0) s_n += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+        if (s_n >= CAP) { flush(); __syncthreads(); if (tid == 0) s_n = 0; __syncthreads(); }
     }
+    flush();
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) { const int c = tid + k * 256; if (c < C) demb[(size_t)sym * C + c] = acc[k]; }
 }
 
 struct EncTape {
@@ -1716,6 +1738,7 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
         // d_out now holds d x_i ([M][cin]); `other` is free again
     }
     T2_TRY(grad_dst(tr, flat_grads, "embedding", &g));
+    if (emb > 2048) return fail(T2_EINVAL, "embedding_dim > 2048 is not supported by the embedding gradient kernel");
     hipLaunchKernelGGL(embedding_grad_kernel, dim3(d.num_symbols), dim3(256), 0, st, et->ids, d_out, Mtot, emb, g);
     HIP_TRY(hipGetLastError());
     return T2_OK;
