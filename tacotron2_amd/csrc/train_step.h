@@ -1067,6 +1067,9 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
     const int stream_of[3] = {T2_STREAM_ZONE_ATT, T2_STREAM_ZONE_L1, T2_STREAM_ZONE_L2};
     const size_t SB = (size_t)S * B;
     HIP_TRY(hipMemsetAsync(tr->bslab, 0, tr->bslab_bytes, st));
+    // arrival tickets of the in-launch combines (bwd_dense_kernel SPLIT, attention_bwd_kernel): the last arriver clears its own,
+    // this clears whatever a failed launch may have left
+    HIP_TRY(hipMemsetAsync(tr->sk_ticket, 0, (T2_SK_MAX_TILES + 64) * 4, st));
     // losses (T1, T2) and their gradients
     float* l3 = tr->loss3;
     T2_TRY(t2_spec_loss(m->ctx, s->o_mel, s->i_targets, spec_mask, B, S * r, M, l3));
