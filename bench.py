@@ -162,7 +162,7 @@ def main():
                                       "tacotron2_amd/sharding.py), no data-path collective" % (world, B)},
         }
 
-    # ---- roofline of the dominant kernel: pz::decode_kernel<4> (csrc/persist.h), ONE launch = the whole free-running decode
+    # ---- roofline of the dominant kernel: pz::decode_kernel<4, 0> (csrc/persist.h), ONE launch = the whole free-running decode
     # of the batch (all S decoder steps).  Live HIP-event timing on the library's stream around the decode (the events also
     # bracket the per-utterance set-up -- memory mask, keys GEMM, state memset: < 1 % at S = 400).  Algorithmic work per launch
     # = S x the per-step figures of SURVEY.md 8d (Fd, Bd), both stated in DESIGN.md. ----
@@ -204,7 +204,7 @@ def main():
         for kv in args.opt:
             k, v = kv.split("=")
             eng.set_option(k, int(v))
-        out["roofline"] = {"kernel": "pz::decode_kernel<4> (persistent free-running decoder: one launch = %d decoder steps of the B=%d batch)" % (n_dec, B)
+        out["roofline"] = {"kernel": "pz::decode_kernel<4, 0> (persistent free-running decoder: one launch = %d decoder steps of the B=%d batch)" % (n_dec, B)
                                      if persist_ran else "launch-per-phase schedule (persistent decoder not eligible)",
                            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,

@@ -73,15 +73,19 @@ struct PArgs {
     int* ctl;
     float *mel, *stop, *hist;
     float *cA_out, *c1_out, *c2_out;            // cell states [rows][1024] stored when the loop ends (final_state of dynamic_decode)
-    const float* x2_all;                        // teacher-forced decode: last PreNet layer's outputs of every step, frag16 per step
-    unsigned x2_bytes, x2_stride;               // size of x2_all, bytes per step
-    float* y_all;                               // teacher-forced decode: LSTM 2's raw outputs [S][rows][1024] for the deferred projection
-    int teacher;
-    PTape tp;
     long long mel_ld, mel_ts;
     int stop_ld;
     int B, T, C, CH, F, KA, MR, max_steps, min_iters, stop_en, cumulative;
     float zc, zh, fb;
+};
+
+// What only the teacher-forced modes read: a second kernel argument, so that the free-running instantiation's argument block
+// (and its scalar-register budget) stays what it was.
+struct PExtra {
+    const float* x2_all;                        // last PreNet layer's outputs of every step, frag16 per step
+    unsigned x2_bytes, x2_stride;               // size of x2_all, bytes per step
+    float* y_all;                               // LSTM 2's raw outputs [S][rows][1024] for the deferred projection (null: the tape has them)
+    PTape tp;
 };
 
 __host__ __device__ inline int lds_floats(int MB, int T, int CH) {
@@ -234,8 +238,12 @@ __device__ unsigned long long g_pz_stamps[NWG][24];
 #define PZ_STAMP(i) do { } while (0)
 #endif
 
-template <int MB>
-__global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
+// MODE 0: free-running decode (feeds its own output back, stop rule); 1: teacher-forced decode; 2: teacher-forced training
+// forward (sampled zoneout + tape).  A template parameter, not a runtime switch: the free-running instantiation carries none
+// of the other modes' code (a runtime switch cost it 2.4 us per step at B = 1).
+template <int MB, int MODE>
+__global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
+    constexpr bool TEACH = MODE >= 1, TAPE = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Thread coordinates are re-derived from an opaque copy of the thread index at the start of every phase (fresh()):
     // otherwise hipcc hoists every step-invariant address computation of every phase out of the step loop and spills them.
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     const rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w2), 0, NWG * (KBH + KBH) * 1024, 0x00020000);
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wP), 0, 28 * KBH * 1024, 0x00020000);
     const rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wN), 0, 16 * KBX * 1024, 0x00020000);
-    const rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.teacher ? a.x2_all : a.wN), 0, a.teacher ? (int)a.x2_bytes : 0, 0x00020000);
+    const rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(TEACH ? x.x2_all : a.wN), 0, TEACH ? (int)x.x2_bytes : 0, 0x00020000);
     const unsigned slabA = (unsigned)wg * (KBX + KBE + KBH) * 1024u;      // byte offsets of this workgroup's slabs
     const unsigned slab1 = (unsigned)wg * (KBH + KBE + KBH) * 1024u;
     const unsigned slab2 = (unsigned)wg * (KBH + KBH) * 1024u;
@@ -349,21 +357,21 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         const float zi = z[0] + bv[euu], zj = z[1] + bv[4 + euu], zf = z[2] + bv[8 + euu], zo = z[3] + bv[12 + euu];
         const float cn = sigmoidf_(zf + a.fb) * c + sigmoidf_(zi) * tanhf(zj);
         const float hn = sigmoidf_(zo) * tanhf(cn);
-        if (!a.tp.on) {
+        if constexpr (!TAPE) {
             c = (1.0f - a.zc) * cn + a.zc * c;
             h = (1.0f - a.zh) * hn + a.zh * h;
         } else if (eown) {
             const int unit = wg * 4 + euu, H = NWG * 4;
             const unsigned stream = (unsigned)(T2_STREAM_ZONE_ATT + 2 * layer);
             const float cp = c, hp = h;
-            c = (1.0f - a.zc) * dropout_train(cn - cp, a.zc, t2_u01(a.tp.seed, stream, (unsigned)t, (unsigned)erow, (unsigned)unit)) + cp;
-            h = (1.0f - a.zh) * dropout_train(hn - hp, a.zh, t2_u01(a.tp.seed, stream + 1u, (unsigned)t, (unsigned)erow, (unsigned)unit)) + hp;
+            c = (1.0f - a.zc) * dropout_train(cn - cp, a.zc, t2_u01(x.tp.seed, stream, (unsigned)t, (unsigned)erow, (unsigned)unit)) + cp;
+            h = (1.0f - a.zh) * dropout_train(hn - hp, a.zh, t2_u01(x.tp.seed, stream + 1u, (unsigned)t, (unsigned)erow, (unsigned)unit)) + hp;
             const size_t ti = (size_t)t * B + erow;
-            float* tz = a.tp.z[layer] + ti * 4 * H;
+            float* tz = x.tp.z[layer] + ti * 4 * H;
             tz[unit] = zi; tz[H + unit] = zj; tz[2 * H + unit] = zf; tz[3 * H + unit] = zo;
-            a.tp.cprev[layer][ti * H + unit] = cp; a.tp.cnew[layer][ti * H + unit] = cn;
-            if (a.tp.hraw[layer] != nullptr) a.tp.hraw[layer][ti * H + unit] = hn;
-            a.tp.hstate[layer][ti * H + unit] = h;
+            x.tp.cprev[layer][ti * H + unit] = cp; x.tp.cnew[layer][ti * H + unit] = cn;
+            if (x.tp.hraw[layer] != nullptr) x.tp.hraw[layer][ti * H + unit] = hn;
+            x.tp.hstate[layer][ti * H + unit] = h;
         }
         return hn;
     };
@@ -453,12 +461,11 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[r][g] = 0.f;
-    if (a.teacher && isAtt) attention_pre(0);
+    if (TEACH && isAtt) attention_pre(0);
 
     for (; t < a.max_steps; ++t) {
         fresh();
-        f32x4 bx[2];
-        if (!a.teacher) {
+        if constexpr (!TEACH) {
         // gap work of the P5 -> P6 chain: the query-independent part of this step's attention.  The owners of a last-PreNet
         // tile do it BEFORE their tile (they are waiting for the projection tiles anyway), everybody else after arriving.
         auto gap6 = [&]() {
@@ -493,8 +500,11 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
         }
         PZ_STAMP(0); hop_arrive(a.bar); ++epoch; fresh();
         if (!isN) { gap6(); fresh(); }
+        }
         // critical weights of P1 (the PreNet rows of the attention LSTM kernel) while the hop completes
+        f32x4 bx[2];
         wload<2>(bx, rA, slabA + (unsigned)(wave * 2 * 1024), l16);
+        if constexpr (!TEACH) {
         PZ_STAMP(1);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
         fresh(); PZ_STAMP(2);
@@ -512,13 +522,11 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             if (s_flag[1]) { final_steps = t; break; }
         }
 
-        } else {
-            wload<2>(bx, rA, slabA + (unsigned)(wave * 2 * 1024), l16);
         }
 
         // ================= P1: attention LSTM (AttentionWrapper cell call, App. A6)  =================
-        if (!a.teacher) seg_mma<MB, 2>(accA, bx, xs, a.oX2 + (unsigned)(wave * 2 * MB * 1024), l16);
-        else seg_mma<MB, 2>(accA, bx, rX2, (unsigned)t * a.x2_stride + (unsigned)(wave * 2 * MB * 1024), l16);
+        if constexpr (!TEACH) seg_mma<MB, 2>(accA, bx, xs, a.oX2 + (unsigned)(wave * 2 * MB * 1024), l16);
+        else seg_mma<MB, 2>(accA, bx, rX2, (unsigned)t * x.x2_stride + (unsigned)(wave * 2 * MB * 1024), l16);
         put_red(accA);
         __syncthreads();
         if (tid < MB * 64) {
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
 #pragma unroll
                 for (int k = 0; k < KSQ; ++k) q += __builtin_bit_cast(float, (unsigned)g[k]);
                 s_q[tid] = q;
-                if (a.tp.on && ac == 0) a.tp.q[((size_t)t * B + ab) * UA + tid] = q;
+                if (TAPE && ac == 0) x.tp.q[((size_t)t * B + ab) * UA + tid] = q;
             }
             __syncthreads();
             if (s_flag[0]) { alive = false; break; }
@@ -669,7 +677,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             if (tid < n) {
                 const float p = s_a[p0 + tid];
                 a.hist[((size_t)t * B + ab) * T + p0 + tid] = p;
-                if (a.tp.on) a.tp.state_prev[((size_t)t * B + ab) * T + p0 + tid] = s_cum[tid + pl];
+                if constexpr (TAPE) x.tp.state_prev[((size_t)t * B + ab) * T + p0 + tid] = s_cum[tid + pl];
                 st4(xs, a.oCUM + (unsigned)((t & 1) * B * T * 4) + (unsigned)((ab * T + p0 + tid) * 4), a.cumulative ? p + s_cum[tid + pl] : p);
             }
             // (f) context slice = alignments . values[:, slice]   (AttentionWrapper._compute_attention)
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
                 for (int g = 0; g < NPG; ++g) s += *reinterpret_cast<const f32x4*>(s_cx + g * ES + tid * 4);
                 st16(xs, a.oCTX + frag_off16(ab, (ac * ES >> 2) + tid, MB), s);
-                if (a.tp.on) *reinterpret_cast<f32x4*>(a.tp.ctx + ((size_t)t * B + ab) * EW + ac * ES + tid * 4) = s;
+                if constexpr (TAPE) *reinterpret_cast<f32x4*>(x.tp.ctx + ((size_t)t * B + ab) * EW + ac * ES + tid * 4) = s;
             }
         }
         PZ_STAMP(6); hop_arrive(a.bar); ++epoch; fresh();
@@ -750,7 +758,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             const float hn = cell(z, s_bias + 32, c2, h2, 2);
             publish4(hn, a.oY2);
             publish4(h2, a.oH2);
-            if (a.y_all != nullptr && eown) a.y_all[((size_t)t * B + erow) * (NWG * 4) + wg * 4 + euu] = hn;
+            if (TEACH && x.y_all != nullptr && eown) x.y_all[((size_t)t * B + erow) * (NWG * 4) + wg * 4 + euu] = hn;
         }
 #pragma unroll
         for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -767,16 +775,16 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a) {
             pk4 = hop_peek(a.bar);
             seg_mma<MB, 4>(acc1, bhi, xs, a.oH1 + (unsigned)((wave * 8 + 4) * MB * 1024), l16);
         }
-        if (a.teacher && isAtt) { attention_pre(t + 1); fresh(); }
+        if (TEACH && isAtt) { attention_pre(t + 1); fresh(); }
         f32x4 bp[8];
         float bias_p = 0.f;
-        if (isP && !a.teacher) { wload<8>(bp, rP, (unsigned)((ptile * KBH + wave * 8) * 1024), l16); bias_p = a.bP[ptile * 16 + (tid & 15)]; }
+        if (isP && !TEACH) { wload<8>(bp, rP, (unsigned)((ptile * KBH + wave * 8) * 1024), l16); bias_p = a.bP[ptile * 16 + (tid & 15)]; }
         PZ_STAMP(13);
         if (!hop_wait(a.bar, 32u * epoch, s_flag, pk4)) { alive = false; break; }
         fresh(); PZ_STAMP(14);
 
         // ================= P5: mel / stop projections (rnn_wrappers.py:105-109) + composed first PreNet layer of step t+1 =================
-        if (isP && !a.teacher) {
+        if (isP && !TEACH) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             tile_mma<8>(acc, bp, xs, a.oY2 + (unsigned)((wave * 8 * MB + prb) * 1024), MB, l16);
             red[wave * 64 + lane] = acc;

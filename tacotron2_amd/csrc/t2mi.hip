@@ -583,7 +583,9 @@ extern "C" int t2_model_finalize(t2_model* m) {
     if (d.attention_filters > 64 || U > 256) return fail(T2_EINVAL, "attention_filters <= 64 and attention_dim <= 256 supported");
     T2_TRY(set_attention_func_attributes());
     {
-        const void* pk[] = {(const void*)pz::decode_kernel<1>, (const void*)pz::decode_kernel<2>, (const void*)pz::decode_kernel<4>};
+        const void* pk[] = {(const void*)pz::decode_kernel<1, 0>, (const void*)pz::decode_kernel<2, 0>, (const void*)pz::decode_kernel<4, 0>,
+                            (const void*)pz::decode_kernel<1, 1>, (const void*)pz::decode_kernel<2, 1>, (const void*)pz::decode_kernel<4, 1>,
+                            (const void*)pz::decode_kernel<1, 2>, (const void*)pz::decode_kernel<2, 2>, (const void*)pz::decode_kernel<4, 2>};
         for (const void* f : pk) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     }
     // the host copies stay: a trainer packs the transposed operands of the backward pass from them
@@ -1690,6 +1692,7 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     const t2_dims& d = m->d;
     hipStream_t st = m->ctx->stream;
     pz::PArgs a{};
+    pz::PExtra x{};
     a.wA = m->att_lstm.w; a.bA = m->att_lstm.bias; a.w1 = m->lstm1.w; a.b1 = m->lstm1.bias; a.w2 = m->lstm2.w; a.b2 = m->lstm2.bias;
     a.wP = m->proj_fused.w; a.bP = m->proj_fused.bias; a.wN = m->prenet[1].w; a.bN = m->prenet[1].bias;
     a.wQ = m->wq_pk.w; a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a; a.b_a = m->b_a;
@@ -1714,9 +1717,9 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     if (teacher) {
         if (s->tf_stride != (long long)s->MB * 16 * pz::KBX * 16 || (long long)max_steps * s->tf_stride * 4 > 0x7fffffffLL)
             return fail(T2_ESTATE, "internal: teacher-forced PreNet operands do not have the persistent decoder's geometry");
-        a.teacher = 1; a.x2_all = s->tf_frag; a.x2_stride = (unsigned)(s->tf_stride * 4); a.x2_bytes = (unsigned)((long long)max_steps * s->tf_stride * 4);
-        a.y_all = tape ? nullptr : s->y_all;            // the training tape keeps LSTM 2's raw outputs itself (hraw[2])
-        if (tape) persist_fill_tape(a.tp, tape);
+        x.x2_all = s->tf_frag; x.x2_stride = (unsigned)(s->tf_stride * 4); x.x2_bytes = (unsigned)((long long)max_steps * s->tf_stride * 4);
+        x.y_all = tape ? nullptr : s->y_all;            // the training tape keeps LSTM 2's raw outputs itself (hraw[2])
+        if (tape) persist_fill_tape(x.tp, tape);
     } else {
         // x1 of step 0 = relu(bias of the first PreNet layer): the go frame is zeros (helpers.py:187-188)
         hipLaunchKernelGGL(pz::init_x1_kernel, dim3(ceil_div(s->B * d.prenet_units[0], 256)), dim3(256), 0, st, s->pz_xs + a.oX1 / 4,
@@ -1724,9 +1727,15 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     }
     const size_t lds = persist_lds_bytes(s->B, s->T);
     const dim3 grid(pz::NWG), blk(pz::NT);
-    if (s->MB == 1) hipLaunchKernelGGL(pz::decode_kernel<1>, grid, blk, lds, st, a);
-    else if (s->MB == 2) hipLaunchKernelGGL(pz::decode_kernel<2>, grid, blk, lds, st, a);
-    else hipLaunchKernelGGL(pz::decode_kernel<4>, grid, blk, lds, st, a);
+    const int mode = teacher ? (tape ? 2 : 1) : 0;        // pz::decode_kernel's MODE
+#define T2_PZ_LAUNCH(MBv) do { \
+        if (mode == 0) hipLaunchKernelGGL((pz::decode_kernel<MBv, 0>), grid, blk, lds, st, a, x); \
+        else if (mode == 1) hipLaunchKernelGGL((pz::decode_kernel<MBv, 1>), grid, blk, lds, st, a, x); \
+        else hipLaunchKernelGGL((pz::decode_kernel<MBv, 2>), grid, blk, lds, st, a, x); } while (0)
+    if (s->MB == 1) T2_PZ_LAUNCH(1);
+    else if (s->MB == 2) T2_PZ_LAUNCH(2);
+    else T2_PZ_LAUNCH(4);
+#undef T2_PZ_LAUNCH
     HIP_TRY(hipGetLastError());
     ++m->n_persist;
     return T2_OK;

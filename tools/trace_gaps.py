@@ -2,7 +2,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # find decode kernels, take the window between the 2nd and 3rd persistent decode launch (one full bench step)
-idx = [i for i, r in enumerate(rows) if 'decode_kernel<4>' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'decode_kernel<4, 0>' in r['Kernel_Name']]
 print('decode launches', len(idx))
 a, b = idx[1], idx[2]
 t0 = int(rows[a]['End_Timestamp'])
