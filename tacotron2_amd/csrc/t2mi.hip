@@ -95,7 +95,7 @@ struct t2_model {
     ConvLayer prenet_plain[T2_MAX_PRENET_LAYERS];     // the same layers in plain layout (batched teacher-forced PreNets)
     Packed att_lstm, lstm1, lstm2, proj;
     Packed proj_fused;                  // proj + the first PreNet layer of the next step composed into it (free-running decode)
-    bool proj_fused_ok = false;         // false after a device-side parameter refresh (the composition is made on the host)
+    bool proj_fused_ok = false;         // built at t2_model_finalize (host, in double), rebuilt by compose_proj_kernel after a device-side parameter refresh
     int opt_projfuse = 1;
     int opt_conv_generic = 0;           // tuning / tests: 1 forces the generic conv_gemm_kernel
     ConvLayer proj_plain;               // mel | stop projection in plain layout [D][pad4(M*r + 1)] (deferred, batched projection)

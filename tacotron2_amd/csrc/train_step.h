@@ -666,6 +666,7 @@ struct t2_trainer {
     float* wmemT = nullptr;             // [U][E] memory layer transposed (plain)
     float* prenetTp[T2_MAX_PRENET_LAYERS] = {};    // PreNet layer i >= 1 transposed (plain [P_i][P_{i-1}]): its data gradient runs once, after the loop
     float* dpre_tmp = nullptr;          // [S*B][max PreNet width]
+    float* compose_tmp = nullptr;       // [D + 1][N2] composed projection operand before packing (parameter refresh)
     float* projTp = nullptr;            // [M*r + 1][D] projections transposed (plain): d y2 of all steps is one GEMM before the loop
     float* dy2_all = nullptr;           // [S*B][D]
     float* dzf2b = nullptr;             // second frag16 operand of LSTM 2's dz (ping-pong with dzf[2] by step parity)
@@ -1831,6 +1832,31 @@ static int flat_src(t2_trainer* tr, const float* flat, const std::string& name, 
     return T2_OK;
 }
 
+// The composed projection operand of the free-running decode (t2_model_finalize builds it on the host), rebuilt on the
+// device after a parameter refresh: out [D + 1][N2], row D = bias.  Columns [0, N) = [W_mel | w_stop], [N, N0) zero,
+// [N0, N0 + P0) = W_mel[:, fed frames] . W_prenet0 (+ b_mel[fed] . W_prenet0 + b_prenet0 in the bias row), summed in double
+// and rounded once, like the host version.
+__global__ __launch_bounds__(256) void compose_proj_kernel(const float* __restrict__ wm, const float* __restrict__ ws, const float* __restrict__ bm,
+                                                           const float* __restrict__ bs, const float* __restrict__ wp0, const float* __restrict__ bp0,
+                                                           float* __restrict__ out, int D, int MR, int c0, int nfm, int P0, int N0, int N2) {
+    const long long n = (long long)(D + 1) * N2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / N2), c = (int)(i - (long long)k * N2);
+        const bool bias = k == D;
+        float v = 0.f;
+        if (c < MR) v = bias ? bm[c] : wm[(size_t)k * MR + c];
+        else if (c == MR) v = bias ? bs[0] : ws[k];
+        else if (c >= N0 && c < N0 + P0) {
+            const int q = c - N0;
+            double acc = bias ? (double)bp0[q] : 0.0;
+            const float* row = bias ? bm : wm + (size_t)k * MR;
+            for (int j = 0; j < nfm; ++j) acc += (double)row[c0 + j] * (double)wp0[(size_t)j * P0 + q];
+            v = (float)acc;
+        }
+        out[i] = v;
+    }
+}
+
 static void repack(hipStream_t st, const Packed& p, const float* src, long long sk, long long sc, int ncols) {
     PackDesc d{};
     d.src = src; d.sk = sk; d.sc = sc; d.nseg = p.nseg; d.kbtot = p.kbtot; d.n_wg = p.n_wg; d.lstm_units = p.lstm_units; d.ncols = ncols;
@@ -1946,9 +1972,19 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
             HIP_TRY(hipMemcpy2DAsync(m->proj_plain.w, (size_t)m->proj_plain.cout * 4, wc, (size_t)N * 4, (size_t)N * 4, D, hipMemcpyDeviceToDevice, st));
             T2_TRY(copy(m->proj_plain.shift, bm, (size_t)M * r));
             T2_TRY(copy(m->proj_plain.shift + M * r, bs, 1));
-            if (m->proj_fused_ok) {        // the composed projection + PreNet-0 operand is built on the host (t2_model_finalize):
-                m->proj_fused_ok = false;  // decode falls back to the separate PreNet-0 launch; cached step graphs are stale
-                for (t2_state* s2 : m->states) for (int i = 0; i < 2; ++i) if (s2->gexec[i]) { (void)hipGraphExecDestroy(s2->gexec[i]); s2->gexec[i] = nullptr; }
+            if (m->proj_fused_ok) {        // the composed projection + PreNet-0 operand (free-running decode): recomposed here
+                const int nfm = M * d.n_feed_frame, c0 = M * (r - d.n_feed_frame), P0 = d.prenet_units[0], N0 = pad16(N), N2 = N0 + P0;
+                if (!tr->compose_tmp) {
+                    HIP_TRY(hipMalloc((void**)&tr->compose_tmp, (size_t)(D + 1) * N2 * 4));
+                    tr->allocs.push_back(tr->compose_tmp);
+                }
+                const float *wp0, *bp0;
+                T2_TRY(flat_src(tr, flat, "decoder/prenet_0/dense/kernel", &wp0));
+                T2_TRY(flat_src(tr, flat, "decoder/prenet_0/dense/bias", &bp0));
+                hipLaunchKernelGGL(compose_proj_kernel, grid1((long long)(D + 1) * N2), dim3(256), 0, st, wm, ws, bm, bs, wp0, bp0, tr->compose_tmp,
+                                   D, M * r, c0, nfm, P0, N0, N2);
+                repack(st, m->proj_fused, tr->compose_tmp, N2, 1, N2);
+                T2_TRY(copy(m->proj_fused.bias, tr->compose_tmp + (size_t)D * N2, (size_t)N2));
             }
             T2_TRY(copy(m->proj.bias, bm, (size_t)M * r));
             T2_TRY(copy(m->proj.bias + M * r, bs, 1));

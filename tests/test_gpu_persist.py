@@ -155,3 +155,40 @@ def test_persistent_teacher_forced_against_oracle_and_launch_schedule(paper, B):
     np.testing.assert_allclose(mel1, _np(mel0), atol=1e-4)
     np.testing.assert_allclose(stop1, _np(stop0), atol=1e-4)
     np.testing.assert_allclose(align1, _np(align0), atol=1e-5)
+
+
+def test_persistent_decode_after_a_device_side_parameter_refresh():
+    """t2_trainer_load_params rebuilds every kernel-native operand on the device, the composed projection + first-PreNet columns of
+    the free-running decode included (compose_proj_kernel): the refreshed engine still decodes as ONE launch and equals an engine
+    built from the new parameters on the host."""
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    d = PROFILE_P
+    w = init_weights(d, seed=17, perturb=True)
+    eng = Engine(d, w)
+    tr = TR.Trainer(eng, 2, 12, 2)
+    spec = TR.flatten_spec(w)
+    tr.bind_gradients(spec)
+    rng = np.random.default_rng(4)
+    w2 = {}
+    for k, v in w.items():
+        moved = not k.endswith("moving_variance")
+        w2[k] = (v + (0.02 * rng.standard_normal(v.shape).astype(np.float32) if moved else 0.0)).astype(np.float32)
+    tr.load_params(torch.tensor(TR.flatten(w2, spec), device="cuda"))
+    B, T, S = 3, 30, 12
+    lens = np.array([30, 17, 25])
+    memory = rng.uniform(-1, 1, (B, T, d.enc_units)).astype(np.float32)
+    before = eng.get_stat("persist_launches")
+    mel, stop, align, n = eng.decode_free(memory, lens, max_iters=S, min_iters=100)
+    assert eng.get_stat("persist_launches") == before + 1, "decode fell back to the launch schedule after the refresh"
+    eng2 = Engine(d, w2)
+    mel2, stop2, align2, n2 = eng2.decode_free(memory, lens, max_iters=S, min_iters=100)
+    assert n == n2 == S
+    np.testing.assert_allclose(_np(mel), _np(mel2), atol=1e-5)
+    np.testing.assert_allclose(_np(stop), _np(stop2), atol=1e-5)
+    np.testing.assert_allclose(_np(align), _np(align2), atol=1e-6)
+    mel_o, stop_o, _ = O.decoder_v2(d.replace(min_iters=100), w2, memory, memory_sequence_length=lens, max_iters=S)
+    np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
+    for o in (tr, eng2, eng):
+        o.close()
