@@ -465,6 +465,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
 
     for (; t < a.max_steps; ++t) {
         fresh();
+        float stop_v = 1.0f;
         if constexpr (!TEACH) {
         // gap work of the P5 -> P6 chain: the query-independent part of this step's attention.  The owners of a last-PreNet
         // tile do it BEFORE their tile (they are waiting for the projection tiles anyway), everybody else after arriving.
@@ -511,24 +512,25 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
         // ---- stop rule of StopTokenBasedInferenceHelper (helpers.py:90-94) for the step just finished: every row says stop
         //      and time > min_iters; the finishing step's outputs are kept, so the decode emits t steps.  Every workgroup
         //      evaluates it on the same published logits (stored before their owner arrived at this hop), so all of them
-        //      leave the loop together.
-        if (t > 0) {
-            if (tid < 64) {
-                const float v = lane < B ? ld4(xs, a.oSTOP + (unsigned)(lane * 4)) : 1.0f;
-                const bool all_stop = __all(v > 0.f);
-                if (lane == 0) s_flag[1] = (a.stop_en && all_stop && t - 1 > a.min_iters) ? 1 : 0;
-            }
-            __syncthreads();
-            if (s_flag[1]) { final_steps = t; break; }
-        }
-
+        //      leave the loop together.  The logits are fetched here and judged behind P1's product (its barrier carries the
+        //      verdict), before the cell commits anything of step t: the load's latency is off the chain.
+        if (t > 0 && tid < 64) stop_v = lane < B ? ld4(xs, a.oSTOP + (unsigned)(lane * 4)) : 1.0f;
         }
 
         // ================= P1: attention LSTM (AttentionWrapper cell call, App. A6)  =================
         if constexpr (!TEACH) seg_mma<MB, 2>(accA, bx, xs, a.oX2 + (unsigned)(wave * 2 * MB * 1024), l16);
         else seg_mma<MB, 2>(accA, bx, rX2, (unsigned)t * x.x2_stride + (unsigned)(wave * 2 * MB * 1024), l16);
         put_red(accA);
+        if constexpr (!TEACH) {
+            if (t > 0 && tid < 64) {
+                const bool all_stop = __all(stop_v > 0.f);
+                if (lane == 0) s_flag[1] = (a.stop_en && all_stop && t - 1 > a.min_iters) ? 1 : 0;
+            }
+        }
         __syncthreads();
+        if constexpr (!TEACH) {
+            if (s_flag[1]) { final_steps = t; break; }
+        }
         if (tid < MB * 64) {
             float z[4];
             gate4(z);
