@@ -127,6 +127,7 @@ struct t2_model {
     unsigned long long param_gen = 0;   // bumped by t2_trainer_load_params; trainers compare it with their own generation
     const float* last_flat = nullptr;   // flat parameter buffer of the last refresh (owned by the caller)
     long long n_persist = 0;            // persistent decodes launched (stat "persist_launches")
+    int opt_conv_mi = 0;                // 1: 64-row conv GEMM tiles always (measurement)
     int opt_bwd_splitk = 1;             // training backward: K = 4H data-gradient GEMMs split in two halves over the grid (train_step.h)
     int opt_persist = 1;                // free-running decodes of the paper-size dimension class run as ONE persistent launch (persist.h)
 };
@@ -422,6 +423,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     }
     else if (!strcmp(name, "persist")) m->opt_persist = value;
     else if (!strcmp(name, "bwd_splitk")) m->opt_bwd_splitk = value;
+    else if (!strcmp(name, "conv_mi")) m->opt_conv_mi = value;
     else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
     else return fail(T2_EINVAL, "unknown option %s", name);
     return T2_OK;
@@ -623,7 +625,7 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
     dim3 grid(ceil_div(L.cout, CG_BN), ceil_div(Mtot, CG_BM));
     if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic) {
         // fewer than ~3 workgroups of 128 rows per CU: 64-row tiles (twice the workgroups) keep more waves per SIMD
-        if ((long long)grid.x * grid.y < 3LL * m->n_cu) {
+        if ((long long)grid.x * grid.y < 3LL * m->n_cu || m->opt_conv_mi == 1) {
             grid.y = ceil_div(Mtot, 64);
             hipLaunchKernelGGL(conv_gemm_fast_kernel<1>, grid, dim3(256), 0, m->ctx->stream, a);
         } else {
