@@ -250,12 +250,12 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, c
 // f = conv(state_prev) + b_c, pre = keys + (q + b_a) + f . Wloc, tanh(pre) for its chunk and writes
 //   de [B][T] (d energies, kept tape-wide), dctx [B][E] (kept tape-wide: d values = sum_t a_t (x) dctx_t),
 //   per-chunk partial dq [U] and partial d(state_prev) over the chunk + conv halo;
-// attention_bwd_finish_kernel sums the partials in chunk order (deterministic) into dq (plain + frag16) and g_state.
+// the row's last chunk to arrive sums the partials in chunk order (deterministic) into dq (plain + frag16) and g_state.
 // The softmax-backward dot sum_j a_j da_j equals dctx . ctx_t + a . g_state (ctx_t = sum_j a_j values_j is on the tape),
 // which lets every chunk work without the other chunks' da.
 // The kernel also keeps du [B][T][U], f [B][T][F] and df [B][T][F] of the step tape-wide, so that after the loop
 //   d Wloc = f^T . du and d conv kernel = im2col(state_prev)^T . df are two split-K GEMMs over all S*B*T rows,
-//   d keys = sum_t du, d conv bias = column sums of df, and d v_a accumulates per step in the finish kernel.
+//   d keys = sum_t du, d conv bias = column sums of df, and d v_a accumulates per step in the combine.
 // Global-memory latency (about 1000 cycles a round trip) dominated the first version of these kernels: every load batch is
 // now issued before its first use, the parameters come as one prebuilt LDS image (attention_image_kernel) copied with
 // float4 loads.
@@ -429,7 +429,7 @@ struct AttnBwdArgs {
     float *part_dq, *part_dva, *part_ds;      // [B][NJ][U], [B][NJ][U], [B][NJ][J + K - 1]
     float *du_out, *f_out, *df_out;           // this step's slices of the tape-wide du [B][T][U], f [B][T][F], df [B][T][F]
     int B, T, U, E, F, K, NJ, first;
-    // the row's last chunk to arrive sums the partials (what attention_bwd_finish_kernel did as a launch of its own)
+    // the row's last chunk to arrive sums the partials (round 1 did this in a launch of its own)
     unsigned* ticket;                         // [B], zero between launches
     float *dq_plain, *dq_frag, *g_state_out, *p_va;
     int MB, cumulative;
@@ -619,32 +619,6 @@ __global__ __launch_bounds__(T2_AB_THREADS) void attention_bwd_kernel(AttnBwdArg
             if (i >= 0 && i < NI) s += __hip_atomic_load(a.part_ds + ((size_t)b * a.NJ + c2) * NI + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         a.g_state_out[(size_t)b * T + p] = s;
-    }
-}
-
-struct AttnBwdFinishArgs {
-    const float *part_dq, *part_dva, *part_ds;
-    float *dq_plain, *dq_frag, *g_state, *p_va;      // p_va [B][U]: d v_a per row, accumulated over the steps
-    int B, T, U, K, NJ, MB, cumulative, first;
-};
-
-__global__ __launch_bounds__(256) void attention_bwd_finish_kernel(AttnBwdFinishArgs a) {
-    const int b = blockIdx.x, tid = threadIdx.x, NI = T2_AB_J + a.K - 1, pad_l = (a.K - 1) / 2;
-    for (int u = tid; u < a.U; u += 256) {
-        float s = 0.f;
-        float sv = a.first ? 0.f : a.p_va[(size_t)b * a.U + u];
-        for (int ch = 0; ch < a.NJ; ++ch) { s += a.part_dq[((size_t)b * a.NJ + ch) * a.U + u]; sv += a.part_dva[((size_t)b * a.NJ + ch) * a.U + u]; }
-        a.dq_plain[(size_t)b * a.U + u] = s;
-        a.dq_frag[frag_idx(b, u, a.MB)] = s;
-        a.p_va[(size_t)b * a.U + u] = sv;
-    }
-    for (int p = tid; p < a.T; p += 256) {
-        float s = (a.cumulative && !a.first) ? a.g_state[(size_t)b * a.T + p] : 0.f;    // state_t = state_{t-1} + a_t
-        for (int ch = 0; ch < a.NJ; ++ch) {
-            const int i = p - (ch * T2_AB_J - pad_l);
-            if (i >= 0 && i < NI) s += a.part_ds[((size_t)b * a.NJ + ch) * NI + i];
-        }
-        a.g_state[(size_t)b * a.T + p] = s;
     }
 }
 
