@@ -44,6 +44,9 @@ constexpr int KBH = 64;             // LSTM width 1024
 constexpr int UA = 128;             // attention dim
 constexpr int EW = 512;             // encoder width
 constexpr int NSHARD = 8;
+#ifndef PZ_POLL_SLEEP
+#define PZ_POLL_SLEEP 1      // s_sleep between polls of a hop counter (0 measured no faster: tools A/B)
+#endif
 constexpr unsigned SPIN_LIMIT_TICKS = 25u * 1000u * 1000u;   // s_memrealtime ticks (100 MHz): 250 ms per wait
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -132,7 +135,9 @@ __device__ __forceinline__ bool hop_wait(unsigned* bar, unsigned per_shard, int*
         for (;;) {
             if (__all((int)(v - per_shard) >= 0)) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { bad = true; break; }
+#if PZ_POLL_SLEEP
             __builtin_amdgcn_s_sleep(1);
+#endif
             if (lane < NSHARD) v = __hip_atomic_load(bar + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (bad && lane == 0) *s_abort = 1;
