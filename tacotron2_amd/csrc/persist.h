@@ -848,6 +848,110 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
     if (!alive && tid == 0) atomicOr(reinterpret_cast<unsigned*>(a.ctl) + 6, 1u);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// EncoderV2's bidirectional ZoneoutLSTM (tacotron_v2.py:53-63: bidirectional_dynamic_rnn with sequence_length) as ONE launch.
+// 2 directions x 64 workgroups; workgroup g of a direction owns hidden units 4g .. 4g+3 (16 gate columns) and keeps its whole
+// weight slab in registers for the sequence (K = 512 inputs + 256 recurrent: 48 KB per workgroup, 24 registers per lane) --
+// the recurrence the register file can hold.  Per step: the input half x_s . Wx is multiplied in the gap of the previous
+// step's hop (it depends on nothing), the recurrent half h . Wh after it; cell, inference zoneout, dynamic_rnn's length
+// masking (dead steps copy the state through and emit zeros) and the plain output row follow in the same workgroup; the new
+// h goes to the other 63 workgroups of the direction through the sc1 hand-off of the decoder kernel (hop_arrive / hop_wait,
+// one counter set per direction).  The backward direction reads the per-row reversed operands seq_to_frag_kernel made and
+// writes position len - 1 - s.
+// ------------------------------------------------------------------------------------------------------------------------
+struct EArgs {
+    const float* w[2];          // packed slabs [64][48][64][4] per direction
+    const float* bias[2];       // [64][16]
+    const float* xf;            // [2][T][frag16 MB x 512] inputs per step (reversed per row for direction 1)
+    unsigned xf_bytes, xf_step; // bytes of xf, bytes per step
+    float* hx;                  // [2 directions][2 slots][frag16 MB x 256] state exchange (zeroed)
+    unsigned hx_bytes;
+    unsigned* bar;              // [2][NSHARD][32] hop counters (zeroed)
+    int* err;                   // set to 1 when a wait ran out of time
+    const int* lens;
+    float* out;                 // [B][T][512]
+    int B, T;
+    float zc, zh, fb;
+};
+constexpr int ENC_G = 64;       // workgroups per direction (256 hidden units / 4)
+
+template <int MB>
+__global__ __launch_bounds__(NT) void encoder_kernel(EArgs a) {
+    __shared__ f32x4 red[NWAVE * MB * 64];
+    __shared__ float s_bias[16];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.x / ENC_G, g = blockIdx.x - dir * ENC_G;
+    const int B = a.B, T = a.T;
+    const unsigned l16 = (unsigned)lane * 16u;
+    if (tid < 16) s_bias[tid] = a.bias[dir][(size_t)g * 16 + tid];
+    if (tid == 0) s_abort = 0;
+    const rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w[dir]), 0, ENC_G * 48 * 1024, 0x00020000);
+    const rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xf), 0, (int)a.xf_bytes, 0x00020000);
+    const rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, (int)a.hx_bytes, 0x00020000);
+    unsigned* bar = a.bar + dir * NSHARD * 32;
+    // the whole slab of this workgroup, once: 4 input k-blocks and 2 recurrent k-blocks per wave
+    f32x4 bx[4], bh[2];
+    wload<4>(bx, rW, (unsigned)((g * 48 + wave * 4) * 1024), l16);
+    wload<2>(bh, rW, (unsigned)((g * 48 + 32 + wave * 2) * 1024), l16);
+    const int erow = tid >> 2, euu = tid & 3;
+    const bool eown = tid < MB * 64 && erow < B;
+    const int len = eown ? a.lens[erow] : 0;
+    float c = 0.f, h = 0.f;
+    const unsigned hslot = (unsigned)(MB * 16 * 256 * 4), hdir = (unsigned)dir * 2u * hslot;
+    const unsigned xdir = (unsigned)dir * (unsigned)T * a.xf_step;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    seg_mma<MB, 4>(acc, bx, rX, xdir + (unsigned)(wave * 4 * MB * 1024), l16);
+    unsigned epoch = 0;
+    bool alive = true;
+    for (int s = 0; s < T; ++s) {
+        if (s > 0) {
+            if (!hop_wait(bar, (unsigned)(ENC_G / NSHARD) * epoch, &s_abort)) { alive = false; break; }
+            seg_mma<MB, 2>(acc, bh, rH, hdir + (unsigned)(s & 1) * hslot + (unsigned)(wave * 2 * MB * 1024), l16);
+        }
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
+        __syncthreads();
+        if (tid < MB * 64) {
+            const int rb = erow >> 4, rr = erow & 15;
+            const int reg = rr & 3, lbase = (rr >> 2) * 16;
+            float z[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) sum += red[(w * MB + rb) * 64 + lbase + q * 4 + euu][reg];
+                z[q] = sum + s_bias[q * 4 + euu];
+            }
+            // LSTMCell + inference zoneout (modules.py:261-283); dynamic_rnn: past the row's length the state is copied through
+            const float cn = sigmoidf_(z[2] + a.fb) * c + sigmoidf_(z[0]) * tanhf(z[1]);
+            const float hn = sigmoidf_(z[3]) * tanhf(cn);
+            const bool live = s < len;
+            if (live) {
+                c = (1.0f - a.zc) * cn + a.zc * c;
+                h = (1.0f - a.zh) * hn + a.zh * h;
+                const int tpos = dir ? (len - 1 - s) : s;
+                a.out[((size_t)erow * T + tpos) * 512 + dir * 256 + g * 4 + euu] = hn;
+            }
+            f32x4 q4;
+            q4[0] = __shfl(h, (lane & ~3) + 0); q4[1] = __shfl(h, (lane & ~3) + 1);
+            q4[2] = __shfl(h, (lane & ~3) + 2); q4[3] = __shfl(h, (lane & ~3) + 3);
+            if (eown && euu == 0) st16(rH, hdir + (unsigned)((s + 1) & 1) * hslot + frag_off16(erow, g, MB), q4);
+        }
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s + 1 < T) {
+            hop_arrive(bar); ++epoch;
+            seg_mma<MB, 4>(acc, bx, rX, xdir + (unsigned)(s + 1) * a.xf_step + (unsigned)(wave * 4 * MB * 1024), l16);
+        }
+    }
+    if (!alive && tid == 0) atomicOr(reinterpret_cast<unsigned*>(a.err), 1u);
+}
+
 // x1 of step 0: the go frame is zeros (helpers.py:187-188), so the first PreNet layer's output is relu(bias)
 __global__ void init_x1_kernel(float* x1, const float* __restrict__ bias, int B, int MB, int P) {
     const int n = B * P;

@@ -127,6 +127,8 @@ struct t2_model {
     unsigned long long param_gen = 0;   // bumped by t2_trainer_load_params; trainers compare it with their own generation
     const float* last_flat = nullptr;   // flat parameter buffer of the last refresh (owned by the caller)
     long long n_persist = 0;            // persistent decodes launched (stat "persist_launches")
+    int opt_enc_persist = 1;            // EncoderV2's BiLSTM as one persistent launch (persist.h encoder_kernel) at the paper-size class
+    unsigned long long n_enc_persist = 0;
     int opt_conv_mi = 0;                // 1: 64-row conv GEMM tiles always (measurement)
     int opt_bwd_splitk = 1;             // training backward: K = 4H data-gradient GEMMs split in two halves over the grid (train_step.h)
     int opt_persist = 1;                // free-running decodes of the paper-size dimension class run as ONE persistent launch (persist.h)
@@ -424,6 +426,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     else if (!strcmp(name, "persist")) m->opt_persist = value;
     else if (!strcmp(name, "bwd_splitk")) m->opt_bwd_splitk = value;
     else if (!strcmp(name, "conv_mi")) m->opt_conv_mi = value;
+    else if (!strcmp(name, "enc_persist")) m->opt_enc_persist = value;
     else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
     else return fail(T2_EINVAL, "unknown option %s", name);
     return T2_OK;
@@ -867,6 +870,7 @@ static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, con
     const size_t o_c = carve(2 * (size_t)MB * 16 * He * 4);
     const size_t o_h = carve(2 * 2 * (size_t)MB * 16 * KPh * 4);
     const size_t o_ctl = carve(8 * 4);
+    const size_t o_ebar = carve((size_t)2 * pz::NSHARD * 32 * 4 + 256);      // persistent BiLSTM: hop counters per direction + error word
     const size_t zero_bytes = off - o_zero;
     T2_TRY(ensure_ws(&m->enc_ws, &m->enc_ws_bytes, off));
     char* ws = (char*)m->enc_ws;
@@ -911,6 +915,29 @@ static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, con
     const int h_ctl[8] = {0, 0, T, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ctl, h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, st));
     const int hsz = MB * 16 * KPh;
+    // the whole recurrence as ONE launch (persist.h encoder_kernel): paper-size class only (512 inputs, 256 units per direction)
+    const bool enc_persist = m->opt_enc_persist && Cx == 512 && He == 256 && KPh == 256 && m->n_cu >= 2 * pz::ENC_G &&
+                             m->enc_lstm[0].n_wg == pz::ENC_G && m->enc_lstm[0].kbtot == 48 && 2LL * T * per_step_c * 4 < 0x7fffffffLL;
+    if (enc_persist) {
+        pz::EArgs a{};
+        for (int dir = 0; dir < 2; ++dir) { a.w[dir] = m->enc_lstm[dir].w; a.bias[dir] = m->enc_lstm[dir].bias; }
+        a.xf = xf; a.xf_step = (unsigned)(per_step_c * 4); a.xf_bytes = (unsigned)(2LL * T * per_step_c * 4);
+        a.hx = hst; a.hx_bytes = (unsigned)(2 * 2 * (size_t)hsz * 4);
+        a.bar = (unsigned*)(ws + o_ebar); a.err = (int*)(ws + o_ebar + (size_t)2 * pz::NSHARD * 32 * 4);
+        a.lens = d_lens; a.out = memory_out; a.B = B; a.T = T;
+        a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
+        const dim3 grid(2 * pz::ENC_G), blk(pz::NT);
+        if (MB == 1) hipLaunchKernelGGL(pz::encoder_kernel<1>, grid, blk, 0, st, a);
+        else if (MB == 2) hipLaunchKernelGGL(pz::encoder_kernel<2>, grid, blk, 0, st, a);
+        else hipLaunchKernelGGL(pz::encoder_kernel<4>, grid, blk, 0, st, a);
+        HIP_TRY(hipGetLastError());
+        int h_err = 0;
+        HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_err) return fail(T2_EHIP, "persistent encoder: a hand-off wait ran out of time (workgroups not co-resident?); outputs are invalid");
+        ++m->n_enc_persist;
+        return T2_OK;
+    }
     for (int s = 0; s < T; ++s) {
         SkinnyCore c{};
         LstmEpi e{};
@@ -1882,6 +1909,7 @@ extern "C" int t2_debug_stamps(unsigned long long* out) {     // diagnostic buil
 extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
     if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "persist_launches")) { *out = (double)m->n_persist; return T2_OK; }
+    if (!strcmp(name, "enc_persist_launches")) { *out = (double)m->n_enc_persist; return T2_OK; }
     if (!strcmp(name, "lstm_launches")) { *out = (double)(g_timer.used / 2); return T2_OK; }
     if (!strcmp(name, "lstm_ms")) {
         HIP_TRY(hipStreamSynchronize(m->ctx->stream));

@@ -192,3 +192,38 @@ def test_persistent_decode_after_a_device_side_parameter_refresh():
     np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
     for o in (tr, eng2, eng):
         o.close()
+
+
+@pytest.mark.parametrize("B", [1, 20, 64])
+def test_persistent_encoder_bilstm_against_oracle_and_launch_schedule(B):
+    """EncoderV2 (tacotron_v2.py:53-63) with the bidirectional ZoneoutLSTM as ONE launch (persist.h encoder_kernel: weights in
+    registers, h exchanged in-launch) against the oracle and against the launch-per-step schedule; ragged lengths, a row of
+    length 1 and a full-length row."""
+    from tacotron2_amd.engine import Engine
+    d = PROFILE_P
+    w = init_weights(d, seed=23, perturb=True)
+    eng = Engine(d, w)
+    try:
+        rng = np.random.default_rng(B)
+        T = 37
+        lens = rng.integers(5, T + 1, size=B).astype(np.int64)
+        lens[0] = T
+        if B > 2:
+            lens[1] = 1
+        ids = np.zeros((B, T), np.int64)
+        for b, n in enumerate(lens):
+            ids[b, :n] = rng.integers(1, d.num_symbols, size=n)
+        want = O.encoder_v2(d, w, O.embedding_lookup(ids, w["embedding"]), lens)
+        eng.set_option("enc_persist", 1)
+        before = eng.get_stat("enc_persist_launches")
+        got = _np(eng.encode(ids, lens)).copy()
+        assert eng.get_stat("enc_persist_launches") == before + 1, "the persistent encoder kernel did not run"
+        np.testing.assert_allclose(got, want, atol=2e-4)
+        eng.set_option("enc_persist", 0)
+        ref = _np(eng.encode(ids, lens))
+        assert eng.get_stat("enc_persist_launches") == before + 1
+        np.testing.assert_allclose(got, ref, atol=1e-5)
+        for b, n in enumerate(lens):                       # dynamic_rnn: zero output past the row's length
+            assert not got[b, n:].any()
+    finally:
+        eng.close()
