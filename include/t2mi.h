@@ -234,6 +234,13 @@ int t2_train_encoder_forward(t2_trainer* tr, const int64_t* ids, const int64_t* 
  * the embedding is defined for this entry point. */
 int t2_train_encoder_forward_embedded(t2_trainer* tr, const float* emb, const int64_t* lens, float drop_rate, uint32_t seed,
                                       float* memory_out, float* bn_stats_out);
+
+/* PostNetV2.call with is_training=True (tacotron/tacotron_v2.py:181-204 over Conv1d.call, tacotron/modules.py:149-157):
+ * batch-statistics batch normalisation over all B*T_out positions, tanh (none on the last convolution), dropout from the
+ * library's counter-based generator, then Dense(out_units) + residual.  Forward only (the reference's loss, models.py:58-61,
+ * does not contain the PostNet).  bn_stats_out: optional dev [postnet_layers][2][postnet_channels] (mean | biased variance). */
+int t2_train_postnet_forward(t2_model* m, const float* mel, int B, int T_out, float drop_rate, uint32_t seed, float* mel_post,
+                             float* bn_stats_out);
 /* Backward of t2_train_encoder_forward: dmemory dev [B,T_in,enc_units] (from t2_train_decoder_backward) -> gradients of
  * `embedding`, encoder/conv1d_i/{kernel, batch_normalization/gamma, beta} (through the batch statistics) and the BiLSTM
  * kernels / biases into flat_grads at the bound offsets. */

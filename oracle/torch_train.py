@@ -102,6 +102,32 @@ def encoder_train(d, W, emb, lens, seed, drop_rate):
     return torch.cat(outs, dim=-1), stats
 
 
+STREAM_POST_CONV = 40          # + layer index
+
+
+def postnet_train(d, W, mel, seed, drop_rate):
+    """PostNetV2.call with is_training=True (tacotron_v2.py:181-204; Conv1d.call modules.py:149-157): conv -> batch-statistics
+    BN -> tanh (none on the last convolution) -> dropout, then Dense(out_units) + residual on the raw input."""
+    x = mel
+    B, T, _ = x.shape
+    stats = {}
+    for i in range(1, d.postnet_layers + 1):
+        p = f"postnet/conv1d_{i}"
+        k = W[f"{p}/kernel"]
+        pad_l = (k.shape[0] - 1) // 2
+        xp = F.pad(x.transpose(1, 2), (pad_l, k.shape[0] - 1 - pad_l))
+        y = F.conv1d(xp, k.permute(2, 1, 0)).transpose(1, 2)
+        mean = y.mean(dim=(0, 1))
+        var = y.var(dim=(0, 1), unbiased=False)
+        stats[p] = (mean.detach(), var.detach())
+        y = (y - mean) / torch.sqrt(var + d.bn_eps) * W[f"{p}/batch_normalization/gamma"] + W[f"{p}/batch_normalization/beta"]
+        if i < d.postnet_layers:
+            y = torch.tanh(y)
+        u = _u(seed, STREAM_POST_CONV + i - 1, 0, B * T, y.shape[2]).reshape(B, T, -1)
+        x = _dropout(y, drop_rate, u)
+    return mel + x @ W["postnet/projection/kernel"] + W["postnet/projection/bias"], stats
+
+
 def decoder_train(d, W, memory, lens, target, seed, prenet_drop_rate):
     """DecoderV1.call(is_training=True) with the V2 cells: TrainingHelper feeds targets[:, t-1, -M*nf:]."""
     B, T, E = memory.shape

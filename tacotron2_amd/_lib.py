@@ -88,6 +88,7 @@ _SIGS = {
     "t2_train_decoder_forward": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_uint32, _p, _p, _p]),
     "t2_train_encoder_forward": (C.c_int, [_p, _p, _p, C.c_float, C.c_uint32, _p, _p]),
     "t2_train_encoder_forward_embedded": (C.c_int, [_p, _p, _p, C.c_float, C.c_uint32, _p, _p]),
+    "t2_train_postnet_forward": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_float, C.c_uint32, _p, _p]),
     "t2_train_encoder_backward": (C.c_int, [_p, _p, _p]),
     "t2_dense": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "t2_zoneout_lstm_cell": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p]),

@@ -89,6 +89,7 @@ struct t2_model {
     float* embedding = nullptr;
     std::vector<ConvLayer> enc_convs, post_convs;
     std::vector<float*> enc_bn_gamma, enc_bn_beta;   // raw batch-norm scale / offset of the encoder convs (training-mode forward)
+    std::vector<float*> post_bn_gamma, post_bn_beta; // the same of the PostNet convs (t2_train_postnet_forward)
     ConvLayer post_proj, memory_layer;
     Packed enc_lstm[2];
     Packed prenet[T2_MAX_PRENET_LAYERS];
@@ -575,6 +576,16 @@ extern "C" int t2_model_finalize(t2_model* m) {
     m->post_convs.resize(d.postnet_layers);
     for (int i = 1; i <= d.postnet_layers; ++i) {
         T2_TRY(make_conv(m, &m->post_convs[i - 1], "postnet/conv1d_" + std::to_string(i), d.postnet_kernel, cin, d.postnet_channels, true));
+        {
+            const HostWeight *g, *bb;
+            const std::string bp = "postnet/conv1d_" + std::to_string(i) + "/batch_normalization/";
+            T2_TRY(get_w(m, bp + "gamma", &g, {d.postnet_channels}));
+            T2_TRY(get_w(m, bp + "beta", &bb, {d.postnet_channels}));
+            float *dg = nullptr, *db = nullptr;
+            T2_TRY(upload(m, &dg, g->data));
+            T2_TRY(upload(m, &db, bb->data));
+            m->post_bn_gamma.push_back(dg); m->post_bn_beta.push_back(db);
+        }
         cin = d.postnet_channels;
     }
     T2_TRY(get_w(m, "postnet/projection/kernel", &w, {d.postnet_channels, M}));

@@ -1277,12 +1277,13 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
 // Conv1d.call after the convolution (modules.py:152-156), training mode: batch norm with batch statistics -> relu -> dropout
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float rate, uint32_t seed,
-                                                       int stream, float* __restrict__ out, long long M, int C) {
+                                                       int stream, float* __restrict__ out, long long M, int C, int act = 1) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M * C; i += (long long)gridDim.x * blockDim.x) {
         const long long m = i / C;
         const int c = (int)(i - m * C);
         float v = (y[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-        v = fmaxf(v, 0.f);
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = tanhf(v);
         if (rate > 0.f) v = dropout_train(v, rate, t2_u01(seed, stream, 0, (uint32_t)m, c));
         out[i] = v;
     }
@@ -1527,7 +1528,7 @@ static int train_encoder_forward_impl(t2_trainer* tr, const int64_t* ids, const 
         hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(E, 64), T2_BN_CHUNKS), dim3(256), 0, st, et->yraw[i], Mtot, E, tr->bn_part);
         hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, st, tr->bn_part, Mtot, E, d.bn_eps, et->mean[i], et->invstd[i], et->var[i]);
         hipLaunchKernelGGL(bn_apply_kernel, grid1((long long)Mtot * E), dim3(256), 0, st, et->yraw[i], et->mean[i], et->invstd[i],
-                           m->enc_bn_gamma[i], m->enc_bn_beta[i], drop_rate, seed, T2_STREAM_ENC_CONV + i, et->x[i + 1], (long long)Mtot, E);
+                           m->enc_bn_gamma[i], m->enc_bn_beta[i], drop_rate, seed, T2_STREAM_ENC_CONV + i, et->x[i + 1], (long long)Mtot, E, 1);
         if (bn_stats_out) {
             HIP_TRY(hipMemcpyAsync(bn_stats_out + (size_t)i * 2 * E, et->mean[i], (size_t)E * 4, hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemcpyAsync(bn_stats_out + (size_t)i * 2 * E + E, et->var[i], (size_t)E * 4, hipMemcpyDeviceToDevice, st));
@@ -1578,6 +1579,53 @@ extern "C" int t2_train_encoder_forward_embedded(t2_trainer* tr, const float* em
                                                  float* memory_out, float* bn_stats_out) {
     if (!emb) return fail(T2_EINVAL, "emb is null");
     return train_encoder_forward_impl(tr, nullptr, emb, lens, drop_rate, seed, memory_out, bn_stats_out);
+}
+
+// PostNetV2.call with is_training=True (tacotron_v2.py:181-204 over Conv1d.call, modules.py:149-157): every convolution is
+// followed by batch normalisation on the BATCH statistics (all B*T_out positions), its activation (tanh, none on the last
+// layer) and dropout sampled from the counter-based generator (stream T2_STREAM_POST_CONV + layer); then Dense(out_units) and
+// the residual.  Forward only: the reference's loss (models.py:58-61) does not contain the PostNet, so no gradient is needed.
+// bn_stats_out (optional): dev [layers][2][channels] batch mean | biased variance.
+#define T2_STREAM_POST_CONV 40
+extern "C" int t2_train_postnet_forward(t2_model* m, const float* mel, int B, int T_out, float drop_rate, uint32_t seed, float* mel_post,
+                                        float* bn_stats_out) {
+    if (!m || !mel || !mel_post) return fail(T2_EINVAL, "null argument");
+    if (!m->finalized) return fail(T2_ESTATE, "model not finalized");
+    if (B < 1 || T_out < 1) return fail(T2_EINVAL, "bad shape");
+    if (!(drop_rate >= 0.f && drop_rate < 1.f)) return fail(T2_EINVAL, "drop rate must be in [0, 1)");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    const int Mtot = B * T_out, C = d.postnet_channels, M = d.num_mels, L = d.postnet_layers;
+    const size_t one = align_up((size_t)Mtot * C * 4, 256), stats = align_up((size_t)3 * C * 4, 256),
+                 part = align_up((size_t)T2_BN_CHUNKS * 2 * C * sizeof(double), 256);
+    T2_TRY(ensure_ws(&m->post_ws, &m->post_ws_bytes, 3 * one + stats + part));
+    char* ws = (char*)m->post_ws;
+    float* bufs[2] = {(float*)ws, (float*)(ws + one)};
+    float* yraw = (float*)(ws + 2 * one);
+    float *mean = (float*)(ws + 3 * one), *invstd = mean + C, *var = invstd + C;
+    double* bn_part = (double*)(ws + 3 * one + stats);
+    auto grid1 = [](long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); };
+    const float* cur = mel;
+    int cur_c = M;
+    for (int i = 0; i < L; ++i) {
+        ConvLayer raw = m->post_convs[i];
+        raw.scale = nullptr; raw.shift = nullptr;               // the batch statistics replace the folded moving statistics
+        T2_TRY(launch_conv(m, raw, cur, cur_c, yraw, C, Mtot, T_out, 0, nullptr, 0));
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(C, 64), T2_BN_CHUNKS), dim3(256), 0, st, yraw, Mtot, C, bn_part);
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, bn_part, Mtot, C, d.bn_eps, mean, invstd, var);
+        hipLaunchKernelGGL(bn_apply_kernel, grid1((long long)Mtot * C), dim3(256), 0, st, yraw, mean, invstd, m->post_bn_gamma[i], m->post_bn_beta[i],
+                           drop_rate, seed, T2_STREAM_POST_CONV + i, bufs[i & 1], (long long)Mtot, C, (i + 1 < L) ? 2 : 0);
+        if (bn_stats_out) {
+            HIP_TRY(hipMemcpyAsync(bn_stats_out + (size_t)i * 2 * C, mean, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(bn_stats_out + (size_t)i * 2 * C + C, var, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+        }
+        cur = bufs[i & 1];
+        cur_c = C;
+    }
+    T2_TRY(launch_conv(m, m->post_proj, cur, C, mel_post, M, Mtot, Mtot, 0, mel, M));
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
 }
 
 static int enc_setup_backward(t2_trainer* tr, EncTape* et) {
@@ -1978,6 +2026,8 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
             T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/beta", &be));
             T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_mean", &mu));
             T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_variance", &var));
+            T2_TRY(copy(m->post_bn_gamma[i - 1], g, (size_t)d.postnet_channels));
+            T2_TRY(copy(m->post_bn_beta[i - 1], be, (size_t)d.postnet_channels));
             hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(d.postnet_channels, 256)), dim3(256), 0, st, g, be, mu, var, d.bn_eps, Lc.scale, Lc.shift, d.postnet_channels);
             cin = d.postnet_channels;
         }

@@ -221,6 +221,19 @@ class Engine:
             _lib.check(self.lib.t2_postnet(self._model, mel.data_ptr(), B, T, out.data_ptr()))
         return out
 
+    def postnet_training(self, mel, drop_rate: float = 0.5, seed: int = 0):
+        """PostNetV2.call(is_training=True): batch-statistics BN + dropout (t2_train_postnet_forward).  Returns
+        (mel_post [B, T, M], batch statistics [layers, 2, channels])."""
+        mel = self._f32(mel)
+        B, T, M = mel.shape
+        assert M == self.dims.num_mels
+        out = torch.empty_like(mel)
+        stats = torch.empty((self.dims.postnet_layers, 2, self.dims.postnet_channels), dtype=torch.float32, device=self.device)
+        with self._ordered():
+            _lib.check(self.lib.t2_train_postnet_forward(self._model, mel.data_ptr(), B, T, float(drop_rate), int(seed) & 0xFFFFFFFF,
+                                                         out.data_ptr(), stats.data_ptr()))
+        return out, stats
+
     def new_state(self, memory, lens=None) -> DecoderState:
         memory = self._f32(memory)
         lens = _i64(lens)

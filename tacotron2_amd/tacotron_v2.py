@@ -157,14 +157,18 @@ class DecoderRNNV2:
 
 
 class PostNetV2:
-    """tacotron_v2.py:181-204."""
+    """tacotron_v2.py:181-204.  Inference arithmetic (moving statistics folded into the convolutions, no dropout), or with
+    ``is_training`` the training arithmetic of Conv1d.call (modules.py:149-157: batch statistics over all positions, dropout
+    sampled from the library's counter-based generator; ``seed`` advances per call, ``batch_statistics`` keeps the last
+    call's mean | variance per layer).  Forward only: the reference's loss does not contain the PostNet (models.py:58-61)."""
 
     def __init__(self, out_units, num_postnet_layers, kernel_size, out_channels, is_training, drop_rate=0.5,
                  engine: Optional[Engine] = None, name=None, dtype=None):
-        if is_training:
-            raise NotImplementedError("training-mode PostNetV2 (batch-statistics BN, dropout) is not built")
         self.out_units, self.num_postnet_layers, self.kernel_size, self.out_channels = out_units, num_postnet_layers, kernel_size, out_channels
+        self.is_training, self.drop_rate = is_training, drop_rate
         self._engine = engine
+        self.seed = 0
+        self.batch_statistics = None
 
     def __call__(self, inputs, **kwargs):
         return self.call(inputs)
@@ -172,7 +176,11 @@ class PostNetV2:
     def call(self, inputs, **kwargs):
         if self._engine is None:
             raise RuntimeError("PostNetV2 needs an engine (see TacotronV2Model)")
-        return self._engine.postnet(inputs)
+        if not self.is_training:
+            return self._engine.postnet(inputs)
+        out, self.batch_statistics = self._engine.postnet_training(inputs, drop_rate=self.drop_rate, seed=self.seed)
+        self.seed += 1
+        return out
 
 
 def dynamic_decode(cell, helper, initial_state, maximum_iterations=None):

@@ -1,6 +1,6 @@
 """The reference's RNNCell / layer protocol at every level of the V2 cell stack, built from the public
 constructors only: DecoderRNNV2.call, AttentionRNN.call and its inner wrappers, ZoneoutLSTMCell.__call__, PreNet.call,
-EncoderV2(is_training=True), and every field of the final_state tuple -- each against the oracle."""
+EncoderV2 / PostNetV2(is_training=True), and every field of the final_state tuple -- each against the oracle."""
 import numpy as np
 import pytest
 import torch
@@ -264,3 +264,37 @@ def test_gru_cell_factory_describes_the_v1_cell():
     from tacotron2_amd.rnn_impl import GRUImpl, gru_cell_factory
     cell = gru_cell_factory(GRUImpl.GRUCell, 12)
     assert cell.num_units == 12 and cell.state_size == 12 and cell.output_size == 12
+
+
+def test_postnet_v2_training_mode_against_autograd_oracle():
+    """PostNetV2(is_training=True): batch-statistics BN, tanh (none on the last convolution), dropout (modules.py:149-157),
+    Dense + residual (tacotron_v2.py:200-204)."""
+    from tacotron2_amd.engine import Engine
+    from tacotron2_amd.tacotron_v2 import PostNetV2
+    d = MID
+    w = init_weights(d, 8, perturb=True)
+    eng = Engine(d, w)
+    try:
+        rng = np.random.default_rng(5)
+        B, T = 3, 17
+        mel = rng.normal(0, 0.7, (B, T, d.num_mels)).astype(np.float32)
+        post = PostNetV2(d.num_mels, d.postnet_layers, d.postnet_kernel, d.postnet_channels, True, drop_rate=0.5, engine=eng)
+        post.seed = 11
+        W = {k: TT._t(v) for k, v in w.items()}
+        for call in range(2):
+            out = post(torch.from_numpy(mel).cuda())
+            want, stats = TT.postnet_train(d, W, TT._t(mel), 11 + call, 0.5)
+            np.testing.assert_allclose(_np(out), want.numpy(), atol=ATOL)
+            for i in range(d.postnet_layers):
+                m, v = stats[f"postnet/conv1d_{i + 1}"]
+                np.testing.assert_allclose(_np(post.batch_statistics[i, 0]), m.numpy(), atol=ATOL)
+                np.testing.assert_allclose(_np(post.batch_statistics[i, 1]), v.numpy(), atol=ATOL)
+        assert post.seed == 13
+        # zero drop rate: only the statistics differ from inference
+        post0 = PostNetV2(d.num_mels, d.postnet_layers, d.postnet_kernel, d.postnet_channels, True, drop_rate=0.0, engine=eng)
+        want0, _ = TT.postnet_train(d, W, TT._t(mel), 0, 0.0)
+        np.testing.assert_allclose(_np(post0(torch.from_numpy(mel).cuda())), want0.numpy(), atol=ATOL)
+        post_i = PostNetV2(d.num_mels, d.postnet_layers, d.postnet_kernel, d.postnet_channels, False, engine=eng)
+        np.testing.assert_allclose(_np(post_i(torch.from_numpy(mel).cuda())), O.postnet_v2(d, w, mel), atol=ATOL)
+    finally:
+        eng.close()
