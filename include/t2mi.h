@@ -110,6 +110,15 @@ int t2_dense(t2_ctx* ctx, const float* x, const float* kernel, const float* bias
 int t2_zoneout_lstm_cell(t2_ctx* ctx, const float* xh, const float* c_prev, const float* h_prev, const float* kernel, const float* bias,
                          int B, int K, int H, float zoneout_cell, float zoneout_output, float forget_bias, float* z_ws, float* h_raw,
                          float* c_new, float* h_new);
+/* The sampled (is_training = True) forms of the same two layers, masks from the library's counter-based generator
+ * u = u01[seed, stream, t, row, column] (csrc/kernels.h; TensorFlow's stateful random stream cannot be reproduced, the oracle shares it):
+ * t2_dropout: tf.layers.dropout(training=True) as PreNet.call applies it (modules.py:90,96-98) -- y = x / (1 - rate) where u >= rate, else 0;
+ * t2_zoneout_lstm_cell_train: ZoneoutLSTMCell.__call__ with is_training = True (modules.py:274-276) -- c' = (1 - zc) dropout(c_new - c) + c,
+ * h' likewise with stream + 1; h_raw is the cell output. */
+int t2_dropout(t2_ctx* ctx, const float* x, long long rows, int cols, float rate, uint32_t seed, int stream, int t, float* y);
+int t2_zoneout_lstm_cell_train(t2_ctx* ctx, const float* xh, const float* c_prev, const float* h_prev, const float* kernel, const float* bias,
+                               int B, int K, int H, float zoneout_cell, float zoneout_output, float forget_bias, uint32_t seed, int stream, int t,
+                               float* z_ws, float* h_raw, float* c_new, float* h_new);
 
 /* Decoder state = OutputAndStopTokenWrapper.zero_state (rnn_wrappers.py:99-100) of the cell stack
  * OutputAndStopTokenWrapper(DecoderRNNV2(AttentionRNN(ZoneoutLSTMCell, prenets,

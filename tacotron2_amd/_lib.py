@@ -91,6 +91,9 @@ _SIGS = {
     "t2_train_postnet_forward": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_float, C.c_uint32, _p, _p]),
     "t2_train_encoder_backward": (C.c_int, [_p, _p, _p]),
     "t2_dense": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "t2_dropout": (C.c_int, [_p, _p, C.c_longlong, C.c_int, C.c_float, C.c_uint32, C.c_int, C.c_int, _p]),
+    "t2_zoneout_lstm_cell_train": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int,
+                                             C.c_int, _p, _p, _p, _p]),
     "t2_zoneout_lstm_cell": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p]),
     "t2_trainer_load_params": (C.c_int, [_p, _p]),
     "t2_trainer_set_loss_counts": (C.c_int, [_p, _p]),

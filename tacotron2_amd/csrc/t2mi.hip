@@ -670,6 +670,32 @@ __global__ __launch_bounds__(256) void lstm_cell_pointwise_kernel(const float* _
     }
 }
 
+// the sampled branch of ZoneoutLSTMCell (modules.py:274-276): binary keep masks from t2_u01(seed, stream | stream + 1, t, row, unit)
+__global__ __launch_bounds__(256) void lstm_cell_pointwise_train_kernel(const float* __restrict__ z, const float* __restrict__ c_prev,
+                                                                        const float* __restrict__ h_prev, int B, int H, float zc, float zh, float fb,
+                                                                        uint32_t seed, int stream, int t, float* __restrict__ h_raw,
+                                                                        float* __restrict__ c_new, float* __restrict__ h_new) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * H; i += gridDim.x * blockDim.x) {
+        const int b = i / H, u = i - b * H;
+        const float* zr = z + (size_t)b * 4 * H;
+        const float cp = c_prev[i], hp = h_prev[i];
+        const float cn = sigmoidf_(zr[2 * H + u] + fb) * cp + sigmoidf_(zr[u]) * tanhf(zr[H + u]);
+        const float hn = sigmoidf_(zr[3 * H + u]) * tanhf(cn);
+        h_raw[i] = hn;
+        c_new[i] = (1.0f - zc) * dropout_train(cn - cp, zc, t2_u01(seed, stream, t, b, u)) + cp;
+        h_new[i] = (1.0f - zh) * dropout_train(hn - hp, zh, t2_u01(seed, stream + 1, t, b, u)) + hp;
+    }
+}
+
+// tf.layers.dropout(training=True) with the library's counter-based generator: y = x / keep * [u01(seed, stream, t, row, col) >= rate]
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long long rows, int cols, float rate, uint32_t seed, int stream, int t,
+                                                      float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols;
+        y[i] = dropout_train(x[i], rate, t2_u01(seed, stream, t, (uint32_t)r, (uint32_t)(i - r * cols)));
+    }
+}
+
 // y = act(x . kernel + bias) on plain operands (tf.layers.Dense: PreNet.call modules.py:88-91 without dropout; any [rows][K] input)
 static int dense_plain(t2_ctx* ctx, const float* x, const float* kernel, const float* bias, int rows, int K, int N, int act, float* y) {
     ConvArgs a{};
@@ -687,6 +713,31 @@ extern "C" int t2_dense(t2_ctx* ctx, const float* x, const float* kernel, const 
     if (rows < 1 || K < 1 || N < 1 || activation < 0 || activation > 2) return fail(T2_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     return dense_plain(ctx, x, kernel, bias, rows, K, N, activation, y);
+}
+
+extern "C" int t2_dropout(t2_ctx* ctx, const float* x, long long rows, int cols, float rate, uint32_t seed, int stream, int t, float* y) {
+    if (!ctx || !x || !y) return fail(T2_EINVAL, "null argument");
+    if (rows < 1 || cols < 1 || !(rate >= 0.f && rate < 1.f)) return fail(T2_EINVAL, "bad argument (rate must be in [0, 1))");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (rows * cols + 255) / 256))), dim3(256), 0, ctx->stream,
+                       x, rows, cols, rate, seed, stream, t, y);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+extern "C" int t2_zoneout_lstm_cell_train(t2_ctx* ctx, const float* xh, const float* c_prev, const float* h_prev, const float* kernel,
+                                          const float* bias, int B, int K, int H, float zoneout_cell, float zoneout_output, float forget_bias,
+                                          uint32_t seed, int stream, int t, float* z_ws, float* h_raw, float* c_new, float* h_new) {
+    if (!ctx || !xh || !c_prev || !h_prev || !kernel || !bias || !z_ws || !h_raw || !c_new || !h_new) return fail(T2_EINVAL, "null argument");
+    if (B < 1 || H < 1 || K <= H) return fail(T2_EINVAL, "bad shape: the kernel has K = inputs + H rows");
+    const float zm = std::min(zoneout_cell, zoneout_output), zs = std::max(zoneout_cell, zoneout_output);
+    if (zm < 0.f || zs >= 1.f) return fail(T2_EINVAL, "sampled zoneout factors must be in [0, 1)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    T2_TRY(dense_plain(ctx, xh, kernel, bias, B, K, 4 * H, 0, z_ws));
+    hipLaunchKernelGGL(lstm_cell_pointwise_train_kernel, dim3(std::max(1, std::min(1024, ceil_div(B * H, 256)))), dim3(256), 0, ctx->stream, z_ws, c_prev,
+                       h_prev, B, H, zoneout_cell, zoneout_output, forget_bias, seed, stream, t, h_raw, c_new, h_new);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
 }
 
 extern "C" int t2_zoneout_lstm_cell(t2_ctx* ctx, const float* xh, const float* c_prev, const float* h_prev, const float* kernel,

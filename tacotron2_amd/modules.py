@@ -34,9 +34,10 @@ class Embedding:
 
 
 class PreNet:
-    """modules.py:73-98: Dense(out_units, relu) + dropout(drop_rate) when is_training or
-    apply_dropout_on_inference.  The HIP path implements the dropout-free arithmetic; a request for
-    active dropout is rejected when the prenet is bound to a decoder."""
+    """modules.py:73-98: Dense(out_units, relu) + dropout(drop_rate) when is_training or apply_dropout_on_inference.
+    Bound to a decoder, active dropout is sampled inside the training step; called on its own (``weights`` given), the dropout
+    mask comes from the library's counter-based generator: u01(seed, stream, time, row, column) with ``seed`` / ``stream`` /
+    ``time`` attributes of this object (``time`` advances per call; TensorFlow's random stream cannot be reproduced)."""
 
     def __init__(self, out_units, is_training, drop_rate=0.5, apply_dropout_on_inference=False, weights=None, name=None):
         self.out_units = out_units
@@ -44,6 +45,7 @@ class PreNet:
         self.is_training = is_training
         self.apply_dropout_on_inference = apply_dropout_on_inference
         self.weights = weights          # {"kernel": [in, out], "bias": [out]}
+        self.seed, self.stream, self.time = 0, 1, 0
 
     @property
     def dropout_enabled(self):
@@ -56,15 +58,11 @@ class PreNet:
         return self.call(inputs)
 
     def call(self, inputs, **kwargs):
-        """Dense(out_units, relu) of modules.py:88-91 on the HIP library (t2_dense).  Stand-alone use needs ``weights``; active
-        dropout (is_training or apply_dropout_on_inference with drop_rate > 0) is sampled only inside the training step."""
-        import ctypes as C
+        """Dense(out_units, relu) of modules.py:88-91 on the HIP library (t2_dense), then tf.layers.dropout(training=
+        dropout_enabled) (modules.py:90,96-98; t2_dropout).  Stand-alone use needs ``weights``."""
         import torch
         from . import _lib
         from .engine import shared_context
-        if self.dropout_enabled and self.drop_rate > 0:
-            raise NotImplementedError("PreNet dropout is sampled inside the training step (training.Trainer); stand-alone calls run "
-                                      "the dropout-free arithmetic: construct the PreNet with drop_rate=0")
         if self.weights is None:
             raise ValueError("PreNet called without weights")
         x = inputs if isinstance(inputs, torch.Tensor) and inputs.is_cuda else None
@@ -75,6 +73,10 @@ class PreNet:
         y = torch.empty(tuple(x.shape[:-1]) + (self.out_units,), dtype=torch.float32, device=ctx.device)
         with ctx.ordered():
             _lib.check(ctx.lib.t2_dense(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), rows, int(x.shape[-1]), self.out_units, 1, y.data_ptr()))
+            if self.dropout_enabled and self.drop_rate > 0:
+                _lib.check(ctx.lib.t2_dropout(ctx.handle, y.data_ptr(), rows, self.out_units, float(self.drop_rate), int(self.seed) & 0xFFFFFFFF,
+                                              int(self.stream), int(self.time), y.data_ptr()))
+                self.time += 1
         return y
 
 
@@ -110,6 +112,7 @@ class ZoneoutLSTMCell:
         self.is_training = is_training
         self.state_is_tuple = state_is_tuple
         self.weights = weights          # {"kernel": [in + h, 4h], "bias": [4h]}
+        self.seed, self.stream, self.time = 0, 10, 0     # counter-based generator coordinates of the sampled branch (time advances per call)
 
     @property
     def num_units(self):
@@ -129,16 +132,15 @@ class ZoneoutLSTMCell:
         return (z(), z())                       # LSTMStateTuple(c, h)
 
     def __call__(self, inputs, state, scope=None):
-        """modules.py:261-283 on the HIP library (t2_zoneout_lstm_cell): returns (raw output h, (zoned c, zoned h)).  Stand-alone
-        use needs ``weights``; the sampled training branch (:274-276) runs only inside the training step."""
+        """modules.py:261-283 on the HIP library: returns (raw output h, (zoned c, zoned h)).  Stand-alone use needs ``weights``.
+        ``is_training`` with non-zero factors runs the sampled branch (:274-276; t2_zoneout_lstm_cell_train) with masks
+        u01(seed, stream | stream + 1, time, row, unit) of this object's ``seed`` / ``stream`` / ``time``."""
         import torch
         from . import _lib
         from .engine import shared_context
         if not self.state_is_tuple:
             raise NotImplementedError("non-tuple state is not implemented")
-        if self.is_training and (self._zoneout_cell > 0 or self._zoneout_outputs > 0):
-            raise NotImplementedError("zoneout masks are sampled inside the training step (training.Trainer); a stand-alone cell runs "
-                                      "the inference blend: construct it with is_training=False")
+        sampled = self.is_training and (self._zoneout_cell > 0 or self._zoneout_outputs > 0)
         if self.weights is None:
             raise ValueError("ZoneoutLSTMCell called without weights")
         dev = inputs.device.index if isinstance(inputs, torch.Tensor) and inputs.is_cuda else torch.cuda.current_device()
@@ -152,7 +154,14 @@ class ZoneoutLSTMCell:
         z = torch.empty((B, 4 * H), dtype=torch.float32, device=ctx.device)
         out, c2, h2 = (torch.empty((B, H), dtype=torch.float32, device=ctx.device) for _ in range(3))
         with ctx.ordered():
-            _lib.check(ctx.lib.t2_zoneout_lstm_cell(ctx.handle, xh.data_ptr(), c.data_ptr(), h.data_ptr(), kernel.data_ptr(), bias.data_ptr(),
-                                                    B, int(xh.shape[1]), H, float(self._zoneout_cell), float(self._zoneout_outputs), 1.0,
-                                                    z.data_ptr(), out.data_ptr(), c2.data_ptr(), h2.data_ptr()))
+            if sampled:
+                _lib.check(ctx.lib.t2_zoneout_lstm_cell_train(ctx.handle, xh.data_ptr(), c.data_ptr(), h.data_ptr(), kernel.data_ptr(), bias.data_ptr(),
+                                                              B, int(xh.shape[1]), H, float(self._zoneout_cell), float(self._zoneout_outputs), 1.0,
+                                                              int(self.seed) & 0xFFFFFFFF, int(self.stream), int(self.time),
+                                                              z.data_ptr(), out.data_ptr(), c2.data_ptr(), h2.data_ptr()))
+                self.time += 1
+            else:
+                _lib.check(ctx.lib.t2_zoneout_lstm_cell(ctx.handle, xh.data_ptr(), c.data_ptr(), h.data_ptr(), kernel.data_ptr(), bias.data_ptr(),
+                                                        B, int(xh.shape[1]), H, float(self._zoneout_cell), float(self._zoneout_outputs), 1.0,
+                                                        z.data_ptr(), out.data_ptr(), c2.data_ptr(), h2.data_ptr()))
         return out, (c2, h2)

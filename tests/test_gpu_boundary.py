@@ -154,8 +154,22 @@ def test_zoneout_lstm_cell_and_prenet_stand_alone():
             np.testing.assert_allclose(_np(out), out_o, atol=ATOL)
             np.testing.assert_allclose(_np(c), c_o, atol=ATOL)
             np.testing.assert_allclose(_np(h), h_o, atol=ATOL)
-    with pytest.raises(NotImplementedError):
-        ZoneoutLSTMCell(4, True, 0.1, 0.1, weights={})(torch.zeros(1, 3).cuda(), (torch.zeros(1, 4).cuda(), torch.zeros(1, 4).cuda()))
+    # the sampled branch (is_training=True, modules.py:274-276): masks from the shared counter-based generator
+    B, n_in, H, zc, zh = 5, 9, 12, 0.3, 0.2
+    kernel = rng.normal(0, 0.3, (n_in + H, 4 * H)).astype(np.float32)
+    bias = rng.normal(0, 0.1, 4 * H).astype(np.float32)
+    cell = ZoneoutLSTMCell(H, True, zc, zh, weights={"kernel": kernel, "bias": bias})
+    cell.seed, cell.stream = 77, 12
+    c, h = cell.zero_state(B)
+    c_o, h_o = np.zeros((B, H), np.float32), np.zeros((B, H), np.float32)
+    for step in range(3):
+        x = rng.uniform(-1, 1, (B, n_in)).astype(np.float32)
+        out, (c, h) = cell(torch.from_numpy(x).cuda(), (c, h))
+        out_o, (c_o, h_o) = O.zoneout_lstm_cell_train(x, (c_o, h_o), kernel, bias, zc, zh, O.rng_u01(77, 12, step, B, H), O.rng_u01(77, 13, step, B, H))
+        np.testing.assert_allclose(_np(out), out_o, atol=ATOL)
+        np.testing.assert_allclose(_np(c), c_o, atol=ATOL)
+        np.testing.assert_allclose(_np(h), h_o, atol=ATOL)
+    assert cell.time == 3
     with pytest.raises(ValueError):
         ZoneoutLSTMCell(4, False, 1.5, 0.1)
     for rows, n_in, n_out in (((3,), 6, 8), ((64,), 80, 256), ((5, 7), 9, 12)):
@@ -165,8 +179,16 @@ def test_zoneout_lstm_cell_and_prenet_stand_alone():
         y = PreNet(n_out, False, 0.5, weights={"kernel": k, "bias": b})(torch.from_numpy(x).cuda())
         assert tuple(y.shape) == rows + (n_out,)
         np.testing.assert_allclose(_np(y), O.dense(x, k, b, O.relu), atol=ATOL)
-    with pytest.raises(NotImplementedError):
-        PreNet(4, True, 0.5, weights={})(torch.zeros(1, 3).cuda())
+    # active dropout (is_training or apply_dropout_on_inference, modules.py:90,96-98)
+    k = rng.normal(0, 0.3, (7, 10)).astype(np.float32)
+    b = rng.normal(0, 0.1, 10).astype(np.float32)
+    x = rng.uniform(-1, 1, (6, 7)).astype(np.float32)
+    for kw in ({"is_training": True}, {"is_training": False, "apply_dropout_on_inference": True}):
+        pn = PreNet(10, drop_rate=0.4, weights={"kernel": k, "bias": b}, **kw)
+        pn.seed, pn.stream = 5, 2
+        for step in range(2):
+            y = pn(torch.from_numpy(x).cuda())
+            np.testing.assert_allclose(_np(y), O.dropout_train(O.dense(x, k, b, O.relu), 0.4, O.rng_u01(5, 2, step, 6, 10)), atol=ATOL)
 
 
 def test_encoder_v2_training_mode_against_autograd_oracle():
