@@ -128,7 +128,7 @@ def postnet_train(d, W, mel, seed, drop_rate):
     return mel + x @ W["postnet/projection/kernel"] + W["postnet/projection/bias"], stats
 
 
-def decoder_train(d, W, memory, lens, target, seed, prenet_drop_rate):
+def decoder_train(d, W, memory, lens, target, seed, prenet_drop_rate, return_state=False):
     """DecoderV1.call(is_training=True) with the V2 cells: TrainingHelper feeds targets[:, t-1, -M*nf:]."""
     B, T, E = memory.shape
     M, r, nf = d.num_mels, d.outputs_per_step, d.n_feed_frame
@@ -172,6 +172,10 @@ def decoder_train(d, W, memory, lens, target, seed, prenet_drop_rate):
         stops.append(y2 @ W["decoder/stop_token_projection/kernel"] + W["decoder/stop_token_projection/bias"])
         aligns.append(a)
     mel = torch.stack(mels, 1).reshape(B, S * r, M)
+    if return_state:    # the MultiRNNCell state tuple after the last step (tacotron_v2.py:155-161), each LSTM state as (c, h)
+        state = dict(attention_c=s_att[0], attention_h=s_att[1], lstm1_c=s1[0], lstm1_h=s1[1], lstm2_c=s2[0], lstm2_h=s2[1],
+                     attention=ctx, alignments=a, attention_state=att_state)
+        return mel, torch.stack(stops, 1), torch.stack(aligns, 0), state
     return mel, torch.stack(stops, 1), torch.stack(aligns, 0)
 
 

@@ -687,6 +687,7 @@ extern "C" int t2_trainer_destroy(t2_trainer* tr) {
     (void)hipSetDevice(tr->m->ctx->device);
     (void)hipStreamSynchronize(tr->m->ctx->stream);
     enc_tape_release(tr);
+    if (tr->state && tr->m->last_loop == tr->state) tr->m->last_loop = nullptr;
     if (tr->slab) (void)hipFree(tr->slab);
     if (tr->bslab) (void)hipFree(tr->bslab);
     if (tr->cs_part) (void)hipFree(tr->cs_part);
@@ -764,8 +765,13 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     // the whole teacher-forced recurrence as ONE persistent launch (persist.h, teacher mode + tape), else one launch per phase
     const bool persist = m->opt_persist && m->opt_tfproj && s->pz_xs != nullptr && s->tf_frag != nullptr && s->proj_tmp != nullptr &&
                          !m->opt_lstm_only && tr->tape.hraw[2] != nullptr;
+    m->last_loop = s; m->last_persist = persist;   // t2_decode_final_state reads the trainer's state until the trainer goes
     if (persist) T2_TRY(persist_decode(s, S, 0, 0, true, &tr->tape));
-    else for (int t = 0; t < S; ++t) T2_TRY(launch_step(s, t, io));       // eager launches: seed and rates are per-call kernel arguments
+    else {
+        for (int t = 0; t < S; ++t) T2_TRY(launch_step(s, t, io));        // eager launches: seed and rates are per-call kernel arguments
+        // the steps ran with explicit offsets; leave the step count where t2_state_get looks for the parity of the h slots
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(s->ctl + CTL_BASE), S, 1, st));
+    }
     if (persist || io.defer_proj) T2_TRY(teacher_projection(s, tr->tape.hraw[2], s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * S * r * M * 4, hipMemcpyDeviceToDevice, st));

@@ -219,13 +219,16 @@ class OutputAndStopTokenWrapper(_Delegating):
         self._engine = engine
         self._seed = seed
         self._num_mels = num_mels
+        self._step_checked = False
 
     @property
     def output_size(self):
         return (self._out_units, 1)
 
     # -- binding to the HIP library ---------------------------------------------------------
-    def decoder_dims(self) -> T2Dims:
+    def decoder_dims(self, allow_sampling=False) -> T2Dims:
+        """``allow_sampling``: the caller runs the whole teacher-forced loop (DecoderV2.call -> t2_train_decoder_forward),
+        where sampled zoneout / PreNet dropout are built; the per-step ``call`` protocol has inference arithmetic only."""
         att = self._cell.attention_cell
         mech = att.mechanism
         g = self._num_mels or gcd(self._out_units, self._n_feed_units)
@@ -237,11 +240,11 @@ class OutputAndStopTokenWrapper(_Delegating):
         if len(zc) != 1 or len(zh) != 1:
             raise NotImplementedError("one pair of zoneout factors per decoder is supported")
         for c in (att.lstm, lstms[0], lstms[1]):
-            if c.is_training and (c._zoneout_cell > 0 or c._zoneout_outputs > 0):
-                raise NotImplementedError("training-mode zoneout sampling is not built (inference arithmetic only)")
+            if not allow_sampling and c.is_training and (c._zoneout_cell > 0 or c._zoneout_outputs > 0):
+                raise NotImplementedError("training-mode zoneout sampling is built for DecoderV2.call's loop, not for single steps")
         for p in att.prenets:
-            if p.dropout_enabled and p.drop_rate > 0:
-                raise NotImplementedError("active PreNet dropout is not built (inference arithmetic only)")
+            if not allow_sampling and p.dropout_enabled and p.drop_rate > 0:
+                raise NotImplementedError("active PreNet dropout is built for DecoderV2.call's loop, not for single steps")
         return T2Dims(num_symbols=2, embedding_dim=mech.values_depth, enc_conv_layers=0, enc_units=mech.values_depth,
                       prenet_units=tuple(p.out_units for p in att.prenets), attention_lstm_units=att.lstm.num_units,
                       decoder_lstm_units=lstms[0].num_units, attention_dim=mech.num_units,
@@ -253,7 +256,7 @@ class OutputAndStopTokenWrapper(_Delegating):
     def engine(self):
         if self._engine is None:
             from .engine import Engine
-            dims = self.decoder_dims()
+            dims = self.decoder_dims(allow_sampling=True)     # sizes only; ``call`` checks the mode again
             w = init_weights(dims, self._seed)
             if self._weights:
                 for k, v in self._weights.items():
@@ -271,5 +274,8 @@ class OutputAndStopTokenWrapper(_Delegating):
     def call(self, inputs, state):
         if inputs.shape[-1] != self._n_feed_units:
             raise ValueError(f"decoder input width {inputs.shape[-1]} != n_feed_units {self._n_feed_units}")
+        if not self._step_checked:
+            self.decoder_dims()                       # single steps: refuses active sampling
+            self._step_checked = True
         mel_output, stop_token = self.engine().decode_step(real_state(state), inputs)
         return (mel_output, stop_token), state

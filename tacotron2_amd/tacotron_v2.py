@@ -237,8 +237,9 @@ class DecoderV2:
         self.cumulative_weights = cumulative_weights
         self.zoneout_factor_cell, self.zoneout_factor_output = zoneout_factor_cell, zoneout_factor_output
         self._engine, self._weights, self._seed = engine, weights, seed
+        self.seed = seed & 0xFFFFFFFF       # mask seed of the next training-mode call (advances by one per call)
 
-    def _cell_for(self, source, is_training, memory_sequence_length):
+    def _cell_for(self, source, is_training, memory_sequence_length, allow_sampling=False):
         prenets = tuple(PreNet(u, is_training, self._drop_rate) for u in self._prenet_out_units)
         mech = LocationSensitiveAttention(self.attention_dim, source, memory_sequence_length, self.attention_kernel,
                                           self.attention_filters, cumulative_weights=self.cumulative_weights)
@@ -249,9 +250,18 @@ class DecoderV2:
         cell = OutputAndStopTokenWrapper(decoder_cell, self.num_mels * self.outputs_per_step, weights=self._weights,
                                          n_feed_units=self.num_mels * self.n_feed_frame, engine=self._engine, seed=self._seed,
                                          num_mels=self.num_mels)
-        cell.decoder_dims()          # runs the training-mode / size checks of the stack
+        cell.decoder_dims(allow_sampling=allow_sampling)   # runs the training-mode / size checks of the stack
         self._engine = cell.engine()
         return cell
+
+    def _sampling(self, is_training):
+        return bool(is_training) and ((self._drop_rate or 0) > 0 or self.zoneout_factor_cell > 0 or self.zoneout_factor_output > 0)
+
+    def _trainer_for(self, B, T_in, S):
+        key = (id(self._engine), B, T_in, S)
+        if getattr(self, "_trainer_key", None) != key:
+            self._trainer, self._trainer_key = training.Trainer(self._engine, B, T_in, S), key
+        return self._trainer
 
     def __call__(self, source, **kw):
         return self.call(source, **kw)
@@ -260,11 +270,20 @@ class DecoderV2:
              target=None, generic_loop=False):
         assert is_training is not None
         assert self.n_feed_frame <= self.outputs_per_step            # helpers.py:55,100,144
-        cell = self._cell_for(source, is_training, memory_sequence_length)
+        sampled = self._sampling(is_training) and not generic_loop
+        cell = self._cell_for(source, is_training, memory_sequence_length, allow_sampling=sampled)
         eng = self._engine
         B = source.shape[0]
         M, r, nf = self.num_mels, self.outputs_per_step, self.n_feed_frame
-        if generic_loop:
+        if sampled:
+            # TrainingHelper with sampled PreNet dropout (modules.py:90,96-98) and zoneout (modules.py:274-276): the training
+            # forward of the library (t2_train_decoder_forward), masks from (seed, stream, step, row, column)
+            S = min(target.shape[1] // r, self.max_iters)            # maximum_iterations=max_iters (:150)
+            tr = self._trainer_for(B, source.shape[1], S)
+            mel_output, stop, align = tr.decoder_forward(source, memory_sequence_length, eng._f32(target)[:, :S * r].contiguous(),
+                                                         prenet_drop_rate=self._drop_rate, seed=self.seed)
+            self.seed = (self.seed + 1) & 0xFFFFFFFF
+        elif generic_loop:
             # literal transcription of tacotron_v1.py:132-152 on the RNNCell / Helper protocol
             tgt = eng._f32(target) if target is not None else None
             helper = TrainingHelper(tgt, M, r, n_feed_frame=nf) if is_training \

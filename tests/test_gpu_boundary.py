@@ -282,6 +282,54 @@ def test_final_state_after_persistent_decode_at_paper_sizes(persist):
         eng.close()
 
 
+@pytest.mark.parametrize("dims,B,T,S", [("mid", 3, 11, 5), ("paper", 5, 37, 6)])
+def test_decoder_v2_training_mode_samples_dropout_and_zoneout(dims, B, T, S):
+    """DecoderV2.call(is_training=True) with drop_rate / zoneout factors > 0 (tacotron_v1.py:134-150, modules.py:90,96-98,
+    274-276): the library's training forward (one persistent launch at paper sizes), masks from the shared counter-based
+    generator; outputs, alignment history and the final state tuple against the torch oracle; the seed advances per call."""
+    from tacotron2_amd.engine import Engine
+    from tacotron2_amd.tacotron_v2 import DecoderV2
+    d = MID if dims == "mid" else PROFILE_P
+    w = init_weights(d, seed=17, perturb=True)
+    eng = Engine(d, w)
+    try:
+        rng = np.random.default_rng(4)
+        lens = np.array([T, T - 4, T - 2, T, 9][:B])
+        memory = rng.uniform(-1, 1, (B, T, d.enc_units)).astype(np.float32)
+        r, M = d.outputs_per_step, d.num_mels
+        tgt = rng.uniform(-1, 1, (B, S * r, M)).astype(np.float32)
+        dec = DecoderV2(prenet_out_units=d.prenet_units, drop_rate=0.5, attention_out_units=d.attention_lstm_units,
+                        decoder_out_units=d.decoder_lstm_units, num_mels=M, outputs_per_step=r, max_iters=200,
+                        n_feed_frame=d.n_feed_frame, attention_dim=d.attention_dim, attention_kernel=d.attention_kernel,
+                        attention_filters=d.attention_filters, zoneout_factor_cell=d.zoneout_cell,
+                        zoneout_factor_output=d.zoneout_output, engine=eng, seed=300)
+        W = {k: TT._t(v) for k, v in w.items()}
+        before = eng.get_stat("persist_launches")
+        for call in range(2):
+            mel, stop, st = dec(torch.from_numpy(memory).cuda(), is_training=True, memory_sequence_length=lens, target=tgt)
+            mel_o, stop_o, align_o, st_o = TT.decoder_train(d, W, TT._t(memory), lens, TT._t(tgt), 300 + call, 0.5, return_state=True)
+            np.testing.assert_allclose(_np(mel), mel_o.numpy(), atol=ATOL)
+            np.testing.assert_allclose(_np(stop), stop_o.numpy(), atol=ATOL)
+            np.testing.assert_allclose(_np(st[0].alignment_history.stack()), align_o.numpy(), atol=ATOL)
+            fields = {"attention_c": st[0].cell_state.c, "attention_h": st[0].cell_state.h, "attention": st[0].attention,
+                      "alignments": st[0].alignments, "attention_state": st[0].attention_state,
+                      "lstm1_c": st[1].c, "lstm1_h": st[1].h, "lstm2_c": st[2].c, "lstm2_h": st[2].h}
+            for name, got in fields.items():
+                np.testing.assert_allclose(_np(got), st_o[name].numpy(), atol=ATOL, err_msg=name)
+            assert st[0].time == S
+        assert eng.get_stat("persist_launches") == before + (2 if dims == "paper" else 0)
+        # the masks matter: the inference arithmetic on the same inputs differs
+        mel_inf, _, _ = dec(torch.from_numpy(memory).cuda(), is_training=False, is_validation=True, teacher_forcing=True,
+                            memory_sequence_length=lens, target=tgt)
+        assert np.abs(_np(mel_inf) - _np(mel)).max() > 1e-3
+        # maximum_iterations=max_iters truncates the loop (tacotron_v1.py:150)
+        dec.max_iters = S - 2
+        mel_s, stop_s, st_s = dec(torch.from_numpy(memory).cuda(), is_training=True, memory_sequence_length=lens, target=tgt)
+        assert mel_s.shape == (B, (S - 2) * r, M) and stop_s.shape == (B, S - 2, 1) and st_s[0].time == S - 2
+    finally:
+        eng.close()
+
+
 def test_gru_cell_factory_describes_the_v1_cell():
     from tacotron2_amd.rnn_impl import GRUImpl, gru_cell_factory
     cell = gru_cell_factory(GRUImpl.GRUCell, 12)

@@ -117,8 +117,8 @@ def test_api_rejections():
         EncoderV2(1, 3, 7, 0.0, 0.0, 0.0, False)
     dec = DecoderV2(prenet_out_units=(8,), drop_rate=0.5, attention_out_units=8, decoder_out_units=8, num_mels=4,
                     outputs_per_step=2, attention_dim=4, attention_kernel=3, attention_filters=2)
-    with pytest.raises(NotImplementedError):            # active dropout in training mode is not built
-        dec(mem.cuda(), is_training=True, target=torch.zeros(1, 4, 4))
+    with pytest.raises(NotImplementedError):            # sampled dropout is built for the whole loop, not for single steps
+        dec(mem.cuda(), is_training=True, target=torch.zeros(1, 4, 4), generic_loop=True)
     with pytest.raises(AssertionError):
         DecoderV2(num_mels=4, outputs_per_step=1, n_feed_frame=2)(mem.cuda(), is_training=False)
 
