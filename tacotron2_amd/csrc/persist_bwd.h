@@ -1,0 +1,527 @@
+// Persistent backward recurrence of the teacher-forced training step: the whole reverse-time loop of the V2 cell stack
+// (ZoneoutLSTMCell x 3, rnn_wrappers.py:118-127,143-144 AttentionRNN, tacotron_v2.py:118-141 location-sensitive attention,
+// :155-161 DecoderRNNV2) as ONE launch, for the paper-size dimension class of persist.h.
+//
+// Structure (mirrors pz::decode_kernel).  256 workgroups stay resident for all S steps.  Workgroup g owns hidden units
+// 4g..4g+3 of the three LSTM cells: the gradients of their cell / hidden states are carried in registers across steps, the
+// ZoneoutLSTMCell backward (modules.py:261-283, sampled masks from the counter-based generator) runs where the units live, and
+// the gate gradients dz [rows x 4H] are published to the exchange slab as frag16 operands.  The data-gradient products
+// d x = dz . W^T (K = 4H = 4096) are column-owner GEMMs: workgroup g multiplies the whole dz by ITS columns of W^T only --
+// exactly the columns whose result it consumes itself (its units' d h, its two context columns, its PreNet column), packed
+// densely by pack_bwd_tiles_kernel -- so a product's result never crosses workgroups.  A step is four all-to-all hops:
+//   GEMM 2 (dz2 -> d y1 | d h2_prev) -> LSTM 2 backward of step t-1, LSTM 1 backward of step t  -> hop A ->
+//   GEMM 1 (dz1 -> d h_att | d ctx | d h1_prev), d ctx published                                 -> hop B ->
+//   attention backward (row split over C workgroups by encoder position, partial d q / d state)  -> hop C ->
+//   query-layer product (sum of the C partials), attention LSTM backward                          -> hop D ->
+//   GEMM 0 (dz_att -> d prenet | d ctx_prev | d h_att_prev).
+// LSTM 2's chain (dz2 of step t-1 needs only GEMM 2 of step t) runs one step ahead, so its operand is complete long before
+// GEMM 2 needs it.  Hand-off protocol: persist.h (sc1 stores, drain, barrier, one agent-scope add per workgroup; sc1 loads).
+// Everything the weight-gradient GEMMs after the loop read (dz, dq, du / f / df, d ctx, d prenet) is written to the same
+// plain tape buffers as the launch-per-phase backward writes, so the code after the loop is shared.
+#pragma once
+#include "persist.h"
+
+namespace pz {
+
+struct BArgs {
+    const float *wT2, *wT1, *wT0, *wTQ;        // column-owner tiles of W^T: [256][KB][4][NC][4] (pack_bwd_tiles_kernel)
+    const float *conv_w, *conv_b, *wloc, *v_a;
+    const float *keys, *values;                // [B][T][128], [B][T][512]
+    const int* lens;
+    // forward tape (TrainTape) and loss gradient
+    const float *z[3], *cprev[3], *cnew[3];    // attention LSTM, LSTM 1, LSTM 2
+    const float *q, *state_prev, *ctx, *hist;  // [S][B][128], [S][B][T], [S][B][512], [S][B][T]
+    const float* dy2_all;                      // [S][B][1024] d (LSTM 2 raw output) from the projections
+    const float* xp_last;                      // [S][B][256] last PreNet layer's output after dropout
+    // backward tape (read by the weight-gradient GEMMs after the loop)
+    float* dz[3];                              // [S][B][4096]
+    float *dq, *de_all, *dctx_all, *du_all, *f_all, *df_all, *dpre, *pva_part;
+    long long dctx_row_ld;                     // floats between batch rows of dctx_all (S * 512)
+    float* xs; unsigned xs_bytes;
+    unsigned oDZ2, oDZ1, oDZ0, oDCTX, oDQ, oDS; // byte offsets into xs; DZ2 and DS hold two step parities
+    unsigned dz_bytes, dq_bytes;               // bytes of one dz operand / one d q partial operand
+    unsigned* bar; int* err;
+    int B, T, S, C, CH, F, KA, cumulative;
+    unsigned seed;
+    float zc, zh, fb, inv_keep;
+};
+
+constexpr int NC2 = 8, NC1 = 10, NC0 = 7, NCQ = 4;     // columns a workgroup owns in the four products
+constexpr int KBZ = 256;                                // k-blocks of a dz operand (4H / 16)
+constexpr int DUS = 132;                                // LDS row stride of the du tile
+
+__host__ __device__ inline int bwd_lds_floats(int MB, int T, int CH) {
+    const int CHP = (CH + 15) & ~15, TP = (T + 3) & ~3;
+    return NWAVE * MB * 64 * 4 + 512 + 2 * TP + (CHP + 48) + 2 * CHP * 36 + CHP * DUS + 32 * 32 + 32 + 2 * UA + 2 * CHP + 32 + 16;
+}
+
+// Source: plain [N][Kc] row-major (a TF kernel [inputs][outputs]: d x[n] = sum_k dz[k] W[n][k]).  Tile of workgroup g: column c
+// is source row n(g, c) = base[s] + per_g[s] * g + (c - c0[s]) of the segment s that holds c.  Output [g][kb][kg][c][j] with
+// k = 16 kb + 4 kg + j: one k-block is 4 * NC float4, the B operand of lane (kg, c) of v_mfma_f32_16x16x4_f32.
+struct TileMap { int nseg, NC, c0[3], base[3], per_g[3]; };
+__global__ __launch_bounds__(256) void pack_bwd_tiles_kernel(const float* __restrict__ src, int Kc, TileMap mp, float* __restrict__ dst) {
+    const int KB = Kc / 16;
+    const long long n4 = (long long)NWG * KB * 4 * mp.NC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % mp.NC);
+        const int kg = (int)((i / mp.NC) & 3);
+        const int kb = (int)((i / (4 * mp.NC)) % KB);
+        const int g = (int)(i / ((long long)4 * mp.NC * KB));
+        int s = 0;
+        for (int q = 1; q < mp.nseg; ++q) if (c >= mp.c0[q]) s = q;
+        const int n = mp.base[s] + mp.per_g[s] * g + (c - mp.c0[s]);
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)n * Kc + kb * 16 + kg * 4);
+        reinterpret_cast<float4*>(dst)[i] = v;
+    }
+}
+
+template <int NKB>
+__device__ __forceinline__ void wloadc(f32x4 (&b)[NKB], rsrc_t w, unsigned soff, unsigned loff, unsigned kbs) {
+#pragma unroll
+    for (int i = 0; i < NKB; ++i) b[i] = ldw(w, loff, soff + (unsigned)i * kbs);
+}
+
+// acc += dz[rows x 4096] . tile: this wave's 32 k-blocks in four rounds, the next round's weights in flight during a round
+template <int MB>
+__device__ __forceinline__ void gemm_dz(f32x4 (&acc)[MB], rsrc_t rW, unsigned wsoff, unsigned kbs, unsigned loff, rsrc_t xs, unsigned xoff,
+                                        unsigned l16) {
+    f32x4 b0[8], b1[8];
+    wloadc<8>(b0, rW, wsoff, loff, kbs);
+    wloadc<8>(b1, rW, wsoff + 8u * kbs, loff, kbs);
+    seg_mma<MB, 8>(acc, b0, xs, xoff, l16);
+    wloadc<8>(b0, rW, wsoff + 16u * kbs, loff, kbs);
+    seg_mma<MB, 8>(acc, b1, xs, xoff + (unsigned)(8 * MB * 1024), l16);
+    wloadc<8>(b1, rW, wsoff + 24u * kbs, loff, kbs);
+    seg_mma<MB, 8>(acc, b0, xs, xoff + (unsigned)(16 * MB * 1024), l16);
+    seg_mma<MB, 8>(acc, b1, xs, xoff + (unsigned)(24 * MB * 1024), l16);
+}
+
+template <int MB>
+__global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int tid = threadIdx.x, lane = tid & 63;
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    const int B = a.B, T = a.T, S = a.S, C = a.C, CH = a.CH;
+    const int CHP = (CH + 15) & ~15, TP = (T + 3) & ~3, NIP = CH + 32;
+    // ---- LDS carve ----
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                 // [8][MB][64] float4
+    float* s_dctx = smem + NWAVE * MB * 64 * 4;                  // [512]
+    float* s_al = s_dctx + 512;                                  // [TP] alignments of the step
+    float* s_gs = s_al + TP;                                     // [TP] d / d attention state after the step (carried)
+    float* s_sp = s_gs + TP;                                     // [CHP + 48] attention state before the step, with the conv halo
+    float* s_f = s_sp + CHP + 48;                                // [CHP][36]
+    float* s_df = s_f + CHP * 36;                                // [CHP][36]
+    float* s_du = s_df + CHP * 36;                               // [CHP][DUS]
+    float* s_cw = s_du + CHP * DUS;                              // [32 taps][32 filters]
+    float* s_cb = s_cw + 32 * 32;                                // [32]
+    float* s_q = s_cb + 32;                                      // [128]
+    float* s_dq = s_q + UA;                                      // [128]
+    float* s_de = s_dq + UA;                                     // [CHP]
+    float* s_da = s_de + CHP;                                    // [CHP]
+    float* s_rd = s_da + CHP;                                    // [32] block reductions
+    int* s_flag = reinterpret_cast<int*>(s_rd + 32);             // [0] abort
+
+    const rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(a.xs, 0, (int)a.xs_bytes, 0x00020000);
+    const rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wT2), 0, NWG * KBZ * 64 * NC2, 0x00020000);
+    const rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wT1), 0, NWG * KBZ * 64 * NC1, 0x00020000);
+    const rsrc_t rW0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wT0), 0, NWG * KBZ * 64 * NC0, 0x00020000);
+    const rsrc_t rWQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wTQ), 0, NWG * 8 * 64 * NCQ, 0x00020000);
+
+    // ---- roles ----
+    const bool isAtt = wg < B * C;
+    const int ab = isAtt ? wg / C : 0, ac = isAtt ? wg - ab * C : 0;
+    const int p0 = ac * CH, pl = (a.KA - 1) >> 1;
+    const int n_pos = isAtt ? max(0, min(CH, T - p0)) : 0;
+    const int NRT = (n_pos + 15) >> 4;
+    const int len_b = isAtt ? min(a.lens[ab], T) : 0;
+
+    if (tid == 0) s_flag[0] = 0;
+    for (int i = tid; i < 32 * 32; i += NT) {
+        const int j = i >> 5, f = i & 31;
+        s_cw[i] = (j < a.KA && f < a.F) ? a.conv_w[j * a.F + f] : 0.f;
+    }
+    if (tid < 32) s_cb[tid] = tid < a.F ? a.conv_b[tid] : 0.f;
+    for (int i = tid; i < TP; i += NT) s_gs[i] = 0.f;
+    int kg = lane >> 4, c16 = lane & 15;
+    // location layer as B fragments (forward orientation: k = filter, column = this wave's 16 attention units)
+    float wlB[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int k = 16 * (s >> 2) + 4 * kg + (s & 3);
+        wlB[s] = k < a.F ? a.wloc[(size_t)k * UA + wave * 16 + c16] : 0.f;
+    }
+    // ... and transposed (k = attention unit, column = filter 16 (wave & 1) + c16) for d f = d u . Wloc^T
+    f32x4 wdf[8];
+    {
+        const int filt = 16 * (wave & 1) + c16;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wdf[kb][j] = filt < a.F ? a.wloc[(size_t)filt * UA + 16 * kb + 4 * kg + j] : 0.f;
+    }
+    const float va_l = a.v_a[wave * 16 + c16];
+    float dva_acc = 0.f;
+
+    int erow = tid >> 2, euu = tid & 3;
+    bool eown = tid < MB * 64 && erow < B;
+    unsigned l16 = (unsigned)lane * 16u;
+    auto fresh = [&]() {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        kg = lane >> 4; c16 = lane & 15; erow = tid >> 2; euu = tid & 3;
+        eown = tid < MB * 64 && erow < B; l16 = (unsigned)lane * 16u;
+    };
+    // carried gradients of this thread's (row, unit): cell state, the part of d h_prev that bypasses the cell, and the parts
+    // of next step's d state that this workgroup's own product columns produced
+    float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, ghp0 = 0.f, ghp1 = 0.f, ghp2 = 0.f;
+    float dh2p = 0.f, dh1p = 0.f, dhAp = 0.f, dctxp = 0.f;
+
+    auto colsum = [&](int c) -> float {
+        const int rb = erow >> 4, rr = erow & 15;
+        const int reg = rr & 3, lbase = (rr >> 2) * 16;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) s += red[(w * MB + rb) * 64 + lbase + c][reg];
+        return s;
+    };
+    auto put_red = [&](f32x4 (&acc)[MB]) {
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
+    };
+    struct TapeRow { float zi, zj, zf, zo, cp, cn; };
+    auto tape_load = [&](int layer, int tt) -> TapeRow {
+        TapeRow r{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (eown && tt >= 0) {
+            const int unit = wg * 4 + euu, H = NWG * 4;
+            const size_t ti = (size_t)tt * B + erow;
+            const float* tz = a.z[layer] + ti * 4 * H;
+            r.zi = tz[unit]; r.zj = tz[H + unit]; r.zf = tz[2 * H + unit]; r.zo = tz[3 * H + unit];
+            r.cp = a.cprev[layer][ti * H + unit]; r.cn = a.cnew[layer][ti * H + unit];
+        }
+        return r;
+    };
+    // ZoneoutLSTMCell backward of one (row, unit) (train_step.h lstm_bwd_elem): writes dz to the tape and the exchange slab
+    auto cell_bwd = [&](int layer, int tt, const TapeRow& r, float g_out, float g_hs, float& gc, float& ghp, unsigned off_dz) {
+        const int unit = wg * 4 + euu, H = NWG * 4;
+        const unsigned stream = (unsigned)(T2_STREAM_ZONE_ATT + 2 * layer);
+        const float gi = sigmoidf_(r.zi), gj = tanhf(r.zj), gf = sigmoidf_(r.zf + a.fb), go = sigmoidf_(r.zo);
+        const float mc = t2_u01(a.seed, stream, (unsigned)tt, (unsigned)erow, (unsigned)unit) >= a.zc ? 1.f : 0.f;
+        const float mh = t2_u01(a.seed, stream + 1u, (unsigned)tt, (unsigned)erow, (unsigned)unit) >= a.zh ? 1.f : 0.f;
+        const float tc = tanhf(r.cn);
+        const float dhn = g_out + mh * g_hs;
+        const float dcn = mc * gc + dhn * go * (1.f - tc * tc);
+        gc = (1.f - mc) * gc + dcn * gf;
+        ghp = (1.f - mh) * g_hs;
+        float dz4[4] = {dcn * gj * gi * (1.f - gi), dcn * gi * (1.f - gj * gj), dcn * r.cp * gf * (1.f - gf), dhn * tc * go * (1.f - go)};
+        if (!eown) { dz4[0] = 0.f; dz4[1] = 0.f; dz4[2] = 0.f; dz4[3] = 0.f; }
+        float* dzt = a.dz[layer] + ((size_t)tt * B + erow) * 4 * H + unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (eown) dzt[g * H] = dz4[g];
+            f32x4 q;
+            q[0] = __shfl(dz4[g], (lane & ~3) + 0); q[1] = __shfl(dz4[g], (lane & ~3) + 1);
+            q[2] = __shfl(dz4[g], (lane & ~3) + 2); q[3] = __shfl(dz4[g], (lane & ~3) + 3);
+            if (eown && euu == 0) st16(xs, off_dz + frag_off16(erow, g * NWG + wg, MB), q);
+        }
+    };
+
+    unsigned epoch = 0;
+    bool alive = true;
+    f32x4 acc[MB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    __syncthreads();
+
+    // ---- LSTM 2 backward of the last step: its raw-output gradient comes from the projections only ----
+    if (tid < MB * 64) {
+        const TapeRow r2 = tape_load(2, S - 1);
+        const float g_out = eown ? a.dy2_all[((size_t)(S - 1) * B + erow) * (NWG * 4) + wg * 4 + euu] : 0.f;
+        cell_bwd(2, S - 1, r2, g_out, 0.f, gc2, ghp2, a.oDZ2 + (unsigned)((S - 1) & 1) * a.dz_bytes);
+    }
+    hop_arrive(a.bar); ++epoch;
+    if (!hop_wait(a.bar, 32u * epoch, s_flag)) alive = false;
+
+    for (int t = S - 1; alive && t >= 0; --t) {
+        fresh();
+        // tape rows of this step's cell backwards (plain loads, in flight during GEMM 2)
+        TapeRow r2{}, r1{}, r0{};
+        float dy2p = 0.f, xpv = 0.f;
+        if (tid < MB * 64) {
+            r2 = tape_load(2, t - 1); r1 = tape_load(1, t); r0 = tape_load(0, t);
+            if (eown && t > 0) dy2p = a.dy2_all[((size_t)(t - 1) * B + erow) * (NWG * 4) + wg * 4 + euu];
+            if (eown && euu == 2) xpv = a.xp_last[((size_t)t * B + erow) * 256 + wg];
+        }
+        // ================= GEMM 2: d [y1 | h2_prev] = dz2(t) . W2^T =================
+        zero_acc();
+        gemm_dz<MB>(acc, rW2, (unsigned)((wg * KBZ + wave * 32) * 64 * NC2), 64u * NC2, (unsigned)((kg * NC2 + min(c16, NC2 - 1)) * 16), xs,
+                    a.oDZ2 + (unsigned)(t & 1) * a.dz_bytes + (unsigned)(wave * 32 * MB * 1024), l16);
+        put_red(acc);
+        __syncthreads();
+        fresh();
+        if (tid < MB * 64) {
+            const float dy1 = colsum(euu);
+            dh2p = colsum(4 + euu);
+            if (t > 0) cell_bwd(2, t - 1, r2, dy2p, ghp2 + dh2p, gc2, ghp2, a.oDZ2 + (unsigned)((t - 1) & 1) * a.dz_bytes);
+            cell_bwd(1, t, r1, dy1, ghp1 + dh1p, gc1, ghp1, a.oDZ1);
+        }
+        hop_arrive(a.bar); ++epoch; fresh();
+        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+        fresh();
+
+        // ================= GEMM 1: d [h_att | ctx | h1_prev] = dz1(t) . W1^T =================
+        zero_acc();
+        gemm_dz<MB>(acc, rW1, (unsigned)((wg * KBZ + wave * 32) * 64 * NC1), 64u * NC1, (unsigned)((kg * NC1 + min(c16, NC1 - 1)) * 16), xs,
+                    a.oDZ1 + (unsigned)(wave * 32 * MB * 1024), l16);
+        put_red(acc);
+        __syncthreads();
+        fresh();
+        float dhA1 = 0.f;
+        if (tid < MB * 64) {
+            dhA1 = colsum(euu);
+            dh1p = colsum(4 + euu);
+            if (euu < 2) {
+                // d context of step t: LSTM 1's input part + the attention LSTM's input part of step t + 1
+                const float dc = colsum(8 + euu) + dctxp;
+                if (eown) {
+                    st4(xs, a.oDCTX + (unsigned)((erow * EW + wg * 2 + euu) * 4), dc);
+                    a.dctx_all[(size_t)erow * a.dctx_row_ld + (size_t)t * EW + wg * 2 + euu] = dc;
+                }
+            }
+        }
+        hop_arrive(a.bar); ++epoch; fresh();
+        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+        fresh();
+
+        // ================= attention backward (train_step.h attention_bwd_kernel's arithmetic) =================
+        if (isAtt) {
+            const size_t tb = (size_t)t * B + ab;
+            // (a) inputs of the step
+            s_dctx[tid] = ld4(xs, a.oDCTX + (unsigned)((ab * EW + tid) * 4));
+            float part = s_dctx[tid] * a.ctx[tb * EW + tid];
+            for (int p = tid; p < T; p += NT) s_al[p] = a.hist[tb * T + p];
+            // d state after this step = (cumulative: d state after step t + 1) + the C chunks' partials of step t + 1
+            if (t < S - 1) {
+                const unsigned ds_prev = a.oDS + (unsigned)((((t + 1) & 1) * B + ab) * C * NIP * 4);
+                for (int p = tid; p < T; p += NT) {
+                    float s = a.cumulative ? s_gs[p] : 0.f;
+                    for (int c2 = 0; c2 < C; ++c2) {
+                        const int i = p - (c2 * CH - pl);
+                        if (i >= 0 && i < NIP) s += ld4(xs, ds_prev + (unsigned)((c2 * NIP + i) * 4));
+                    }
+                    s_gs[p] = s;
+                }
+            }
+            for (int i = tid; i < CHP + 48; i += NT) {
+                const int p = p0 - pl + i;
+                s_sp[i] = (p >= 0 && p < T && i < n_pos + a.KA - 1) ? a.state_prev[tb * T + p] : 0.f;
+            }
+            if (tid < UA) s_q[tid] = a.q[tb * UA + tid];
+            float pre[4][4];
+            {
+                const float* keys_b = a.keys + (size_t)ab * T * UA + wave * 16 + c16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int p = min(p0 + 16 * r + 4 * kg + g, T - 1);
+                        pre[r][g] = r < NRT ? keys_b[(size_t)p * UA] : 0.f;
+                    }
+            }
+            __syncthreads();
+            // (b) softmax-backward dot: d ctx . ctx_t + a . d state  (every chunk computes the row's whole dot)
+            for (int p = tid; p < T; p += NT) part = fmaf(s_al[p], s_gs[p], part);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) s_rd[wave] = part;
+            // (c) location features of the chunk (as persist.h attention_pre)
+            {
+                const int f = tid & 31, pq = tid >> 5;
+                if (4 * pq < CHP) {
+                    float win[36];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_sp + 4 * pq + 4 * i);
+                        win[4 * i] = w4[0]; win[4 * i + 1] = w4[1]; win[4 * i + 2] = w4[2]; win[4 * i + 3] = w4[3];
+                    }
+                    const float cb = s_cb[f];
+                    float fa[4] = {cb, cb, cb, cb};
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        const float wj = s_cw[j * 32 + f];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fa[i] = fmaf(wj, win[i + j], fa[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s_f[(4 * pq + i) * 36 + f] = (4 * pq + i < n_pos) ? fa[i] : 0.f;
+                }
+            }
+            // (d) d alignments: da_j = d ctx . values_j + d state_j; wave w takes positions w, w + 8, ...
+            {
+                const float* vals = a.values + ((size_t)ab * T + p0) * EW;
+                for (int j = wave; j < n_pos; j += NWAVE) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s = fmaf(s_dctx[lane + 64 * i], vals[(size_t)j * EW + lane + 64 * i], s);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                    if (lane == 0) s_da[j] = s + s_gs[p0 + j];
+                }
+            }
+            __syncthreads();
+            if (tid < CHP) {
+                float dot = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) dot += s_rd[w];
+                const float de = (tid < n_pos && p0 + tid < len_b) ? s_al[p0 + tid] * (s_da[tid] - dot) : 0.f;
+                s_de[tid] = de;
+                if (tid < n_pos) a.de_all[tb * T + p0 + tid] = de;
+            }
+            // processed location features on the matrix pipe, then pre = keys + q + f . Wloc
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < NRT) {
+                    f32x4 pf = {0.f, 0.f, 0.f, 0.f};
+                    const float* fr = s_f + (16 * r + c16) * 36 + 4 * kg;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(fr), a1 = *reinterpret_cast<const f32x4*>(fr + 16);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], wlB[s], pf, 0, 0, 0);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], wlB[4 + s], pf, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pre[r][g] += pf[g];
+                }
+            }
+            __syncthreads();
+            // (e) d u = d e * v * (1 - tanh^2), d v_a += d e * tanh, d q = sum over positions of d u
+            {
+                const float q_l = s_q[wave * 16 + c16];
+                float dqs = 0.f;
+                float* du_t = a.du_all + (tb * T + p0) * UA + wave * 16 + c16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r < NRT) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int pos = 16 * r + 4 * kg + g;
+                            const float de = s_de[pos];
+                            const float th = tanhf(pre[r][g] + q_l);
+                            const float du = de * va_l * (1.f - th * th);
+                            dva_acc = fmaf(de, th, dva_acc);
+                            dqs += du;
+                            s_du[pos * DUS + wave * 16 + c16] = du;
+                            if (pos < n_pos) du_t[(size_t)pos * UA] = du;
+                        }
+                    }
+                }
+                dqs += __shfl_xor(dqs, 16); dqs += __shfl_xor(dqs, 32);
+                if (kg == 0) s_dq[wave * 16 + c16] = dqs;
+            }
+            __syncthreads();
+            // this chunk's partial d q as a frag16 operand of the query-layer product
+            if (tid < UA / 4) st16(xs, a.oDQ + (unsigned)ac * a.dq_bytes + frag_off16(ab, tid, MB), *reinterpret_cast<const f32x4*>(s_dq + 4 * tid));
+            // (f) d f = d u . Wloc^T on the matrix pipe: wave w -> positions 16 (w >> 1) .., filters 16 (w & 1) ..
+            {
+                const int r = wave >> 1, ct = wave & 1;
+                if (r < NRT) {
+                    f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                    const float* ur = s_du + (16 * r + c16) * DUS + 4 * kg;
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ur + 16 * kb);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], wdf[kb][j], d4, 0, 0, 0);
+                    }
+                    const int filt = 16 * ct + c16;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int pos = 16 * r + 4 * kg + g;
+                        s_df[pos * 36 + filt] = d4[g];
+                        if (pos < n_pos && filt < a.F) {
+                            a.df_all[(tb * T + p0 + pos) * a.F + filt] = d4[g];
+                            a.f_all[(tb * T + p0 + pos) * a.F + filt] = s_f[pos * 36 + filt];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // (g) partial d state_prev over the chunk + conv halo: ds[i] <-> position p0 - pad_l + i
+            {
+                const int i = tid >> 2, cg = tid & 3;
+                float s = 0.f;
+                if (i < NIP) {
+                    const int ja = max(0, i - a.KA + 1), jb = min(n_pos - 1, i);
+                    for (int j = ja; j <= jb; ++j)
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) s = fmaf(s_cw[(i - j) * 32 + cg + 4 * c], s_df[j * 36 + cg + 4 * c], s);
+                }
+                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+                if (i < NIP && cg == 0) st4(xs, a.oDS + (unsigned)(((((t & 1) * B + ab) * C + ac) * NIP + i) * 4), s);
+            }
+        }
+        hop_arrive(a.bar); ++epoch; fresh();
+        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+        fresh();
+
+        // ================= query layer: d h_att += (sum of the C partial d q) . Wq^T; attention LSTM backward =================
+        {
+            const f32x4 bq = ldw(rWQ, (unsigned)((kg * NCQ + min(c16, NCQ - 1)) * 16), (unsigned)((wg * 8 + wave) * 64 * NCQ));
+            zero_acc();
+            for (int c2 = 0; c2 < C; ++c2) {
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) {
+                    const f32x4 av = ldx(xs, l16, a.oDQ + (unsigned)c2 * a.dq_bytes + (unsigned)((wave * MB + rb) * 1024));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[j], acc[rb], 0, 0, 0);
+                }
+            }
+            put_red(acc);
+            // d q of the row (tape of the query layer's weight gradient): workgroup b < B sums row b's partials
+            if (wg < B && tid < UA) {
+                float s = 0.f;
+                const unsigned off = frag_off16(wg, tid >> 2, MB) + (unsigned)((tid & 3) * 4);
+                for (int c2 = 0; c2 < C; ++c2) s += ld4(xs, a.oDQ + (unsigned)c2 * a.dq_bytes + off);
+                a.dq[((size_t)t * B + wg) * UA + tid] = s;
+            }
+            __syncthreads();
+            fresh();
+            if (tid < MB * 64) {
+                const float dhq = colsum(euu);
+                cell_bwd(0, t, r0, dhA1 + dhq, ghp0 + dhAp, gc0, ghp0, a.oDZ0);
+            }
+        }
+        hop_arrive(a.bar); ++epoch; fresh();
+        if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+        fresh();
+
+        // ================= GEMM 0: d [prenet out | ctx_prev | h_att_prev] = dz_att(t) . W0^T =================
+        zero_acc();
+        gemm_dz<MB>(acc, rW0, (unsigned)((wg * KBZ + wave * 32) * 64 * NC0), 64u * NC0, (unsigned)((kg * NC0 + min(c16, NC0 - 1)) * 16), xs,
+                    a.oDZ0 + (unsigned)(wave * 32 * MB * 1024), l16);
+        put_red(acc);
+        __syncthreads();
+        fresh();
+        if (tid < MB * 64) {
+            dhAp = colsum(euu);
+            if (euu < 2) dctxp = colsum(4 + euu);
+            if (euu == 2 && eown) {
+                // PreNet backward through dropout(relu(.)) (modules.py:88-91): d pre = (y != 0) ? d y / keep : 0
+                const float v = colsum(6);
+                a.dpre[((size_t)t * B + erow) * 256 + wg] = xpv != 0.f ? v * a.inv_keep : 0.f;
+            }
+        }
+        __syncthreads();          // the next step's GEMM 2 overwrites the reduction tiles
+    }
+    fresh();
+    // d v_a: this workgroup's sum over all steps of its chunk (rows of pva_part are added in order after the launch)
+    {
+        float s = dva_acc;
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        if (kg == 0) a.pva_part[(size_t)wg * UA + wave * 16 + c16] = isAtt ? s : 0.f;
+    }
+    if (!alive && tid == 0) atomicOr(reinterpret_cast<unsigned*>(a.err), 1u);
+}
+
+}  // namespace pz

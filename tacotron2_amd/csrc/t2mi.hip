@@ -4,6 +4,7 @@
 #include "../../include/t2mi.h"
 #include "kernels.h"
 #include "persist.h"
+#include "persist_bwd.h"
 
 #include <algorithm>
 #include <cmath>
@@ -131,6 +132,8 @@ struct t2_model {
     int opt_enc_persist = 1;            // EncoderV2's BiLSTM as one persistent launch (persist.h encoder_kernel) at the paper-size class
     unsigned long long n_enc_persist = 0;
     int opt_conv_mi = 0;                // 1: 64-row conv GEMM tiles always (measurement)
+    int opt_bwd_persist = 1;            // training backward: the reverse-time recurrence as ONE persistent launch (persist_bwd.h)
+    unsigned long long n_bwd_persist = 0;
     int opt_bwd_splitk = 1;             // training backward: K = 4H data-gradient GEMMs split in two halves over the grid (train_step.h)
     int opt_persist = 1;                // free-running decodes of the paper-size dimension class run as ONE persistent launch (persist.h)
 };
@@ -426,6 +429,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     }
     else if (!strcmp(name, "persist")) m->opt_persist = value;
     else if (!strcmp(name, "bwd_splitk")) m->opt_bwd_splitk = value;
+    else if (!strcmp(name, "bwd_persist")) m->opt_bwd_persist = value;
     else if (!strcmp(name, "conv_mi")) m->opt_conv_mi = value;
     else if (!strcmp(name, "enc_persist")) m->opt_enc_persist = value;
     else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
@@ -1972,6 +1976,7 @@ extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
     if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "persist_launches")) { *out = (double)m->n_persist; return T2_OK; }
     if (!strcmp(name, "enc_persist_launches")) { *out = (double)m->n_enc_persist; return T2_OK; }
+    if (!strcmp(name, "bwd_persist_launches")) { *out = (double)m->n_bwd_persist; return T2_OK; }
     if (!strcmp(name, "lstm_launches")) { *out = (double)(g_timer.used / 2); return T2_OK; }
     if (!strcmp(name, "lstm_ms")) {
         HIP_TRY(hipStreamSynchronize(m->ctx->stream));

@@ -644,6 +644,11 @@ struct t2_trainer {
     float* projTp = nullptr;            // [M*r + 1][D] projections transposed (plain): d y2 of all steps is one GEMM before the loop
     float* dy2_all = nullptr;           // [S*B][D]
     float* dzf2b = nullptr;             // second frag16 operand of LSTM 2's dz (ping-pong with dzf[2] by step parity)
+    // persistent backward recurrence (persist_bwd.h): column-owner tiles of the transposed kernels, exchange slab, counters
+    float* pzb_w[4] = {};               // LSTM 2, LSTM 1, attention LSTM, query layer
+    char* pzb_slab = nullptr; size_t pzb_slab_bytes = 0;
+    unsigned pzb_off[6] = {}, pzb_dz_bytes = 0, pzb_dq_bytes = 0, pzb_xs_bytes = 0;
+    unsigned* pzb_bar = nullptr; float* pzb_pva = nullptr;
     void* bslab = nullptr; size_t bslab_bytes = 0;
     float *dY = nullptr, *dYf = nullptr, *dz[3] = {}, *dzf[3] = {}, *dq = nullptr, *dqf = nullptr;
     float *dpre[T2_MAX_PRENET_LAYERS] = {}, *dpref[T2_MAX_PRENET_LAYERS] = {}, *xin = nullptr;
@@ -677,6 +682,117 @@ static int trainer_pack_T(t2_trainer* tr, Packed* out, const std::string& name, 
     T2_TRY(pack_skinny(m, out, t.data(), rows, {{0, ncols}}, 0, rows, nullptr));
     for (size_t i = before; i < m->allocs.size(); ++i) tr->allocs.push_back(m->allocs[i]);     // owned by the trainer
     m->allocs.resize(before);
+    return T2_OK;
+}
+
+
+// ---- persistent backward recurrence (persist_bwd.h): operands and workspace ----------------------------------------------
+// which: 0 LSTM 2 (d y1 | d h2_prev), 1 LSTM 1 (d h_att | d h1_prev | d ctx), 2 attention LSTM (d h_att_prev | d ctx_prev | d prenet),
+// 3 query layer (d h_att).  Column c of workgroup g's tile = row n of the TF kernel [inputs][outputs].
+static pz::TileMap pzb_map(int which) {
+    pz::TileMap mp{};
+    auto seg = [&](int i, int c0, int base, int per_g) { mp.c0[i] = c0; mp.base[i] = base; mp.per_g[i] = per_g; };
+    if (which == 0) { mp.nseg = 2; mp.NC = pz::NC2; seg(0, 0, 0, 4); seg(1, 4, pz::KBH * 16, 4); }
+    else if (which == 1) { mp.nseg = 3; mp.NC = pz::NC1; seg(0, 0, 0, 4); seg(1, 4, pz::KBH * 16 + pz::EW, 4); seg(2, 8, pz::KBH * 16, 2); }
+    else if (which == 2) { mp.nseg = 3; mp.NC = pz::NC0; seg(0, 0, pz::KBX * 16 + pz::EW, 4); seg(1, 4, pz::KBX * 16, 2); seg(2, 6, 0, 1); }
+    else { mp.nseg = 1; mp.NC = pz::NCQ; seg(0, 0, 0, 4); }
+    return mp;
+}
+static inline size_t pzb_tile_bytes(int which) {
+    const pz::TileMap mp = pzb_map(which);
+    return (size_t)pz::NWG * (which == 3 ? pz::UA / 16 : pz::KBZ) * 64 * mp.NC;
+}
+static int pzb_pack(t2_trainer* tr, int which, const float* w_dev) {
+    if (!tr->pzb_w[which]) return T2_OK;
+    const pz::TileMap mp = pzb_map(which);
+    const int Kc = which == 3 ? pz::UA : pz::KBZ * 16;
+    const long long n4 = (long long)pzb_tile_bytes(which) / 16;
+    hipLaunchKernelGGL(pz::pack_bwd_tiles_kernel, dim3((unsigned)std::min<long long>(4096, (n4 + 255) / 256)), dim3(256), 0, tr->m->ctx->stream,
+                       w_dev, Kc, mp, tr->pzb_w[which]);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+static int pzb_setup(t2_trainer* tr) {
+    t2_model* m = tr->m;
+    const int B = tr->B, T = tr->T, MB = mb_for(B);
+    if (!persist_dims_ok(m, B, T)) return T2_OK;
+    const int C = persist_chunks(B), CH = (T + C - 1) / C;
+    if ((size_t)pz::bwd_lds_floats(MB, T, CH) * 4 > 150 * 1024) return T2_OK;
+    hipStream_t st = m->ctx->stream;
+    const char* names[4] = {"decoder/lstm_2/kernel", "decoder/lstm_1/kernel", "decoder/attention_lstm/kernel", "attention/query_layer/kernel"};
+    const int rows[4] = {2 * pz::KBH * 16, 2 * pz::KBH * 16 + pz::EW, pz::KBX * 16 + pz::EW + pz::KBH * 16, pz::KBH * 16};
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, (size_t)rows[1] * pz::KBZ * 16 * 4));
+    for (int i = 0; i < 4; ++i) {
+        const int Kc = i == 3 ? pz::UA : pz::KBZ * 16;
+        const HostWeight* w;
+        int rc = get_w(m, names[i], &w, {rows[i], Kc});
+        hipError_t e = rc == T2_OK ? hipMalloc((void**)&tr->pzb_w[i], pzb_tile_bytes(i)) : hipErrorUnknown;
+        if (e == hipSuccess) { tr->allocs.push_back(tr->pzb_w[i]); e = hipMemcpyAsync(tmp, w->data.data(), (size_t)rows[i] * Kc * 4, hipMemcpyHostToDevice, st); }
+        if (e == hipSuccess) rc = pzb_pack(tr, i, tmp);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (rc != T2_OK || e != hipSuccess) { (void)hipFree(tmp); return rc != T2_OK ? rc : fail(T2_EHIP, "persistent backward operands: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(hipFree(tmp));
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return (unsigned)o; };
+    tr->pzb_dz_bytes = (unsigned)((size_t)MB * 16 * pz::KBZ * 16 * 4);
+    tr->pzb_dq_bytes = (unsigned)((size_t)MB * 16 * pz::UA * 4);
+    tr->pzb_off[0] = carve(2 * (size_t)tr->pzb_dz_bytes); tr->pzb_off[1] = carve(tr->pzb_dz_bytes); tr->pzb_off[2] = carve(tr->pzb_dz_bytes);
+    tr->pzb_off[3] = carve((size_t)MB * 16 * pz::EW * 4);
+    tr->pzb_off[4] = carve((size_t)C * tr->pzb_dq_bytes);
+    tr->pzb_off[5] = carve(2 * (size_t)B * C * (CH + 32) * 4);
+    tr->pzb_xs_bytes = (unsigned)off;
+    const size_t o_bar = carve((size_t)(pz::NSHARD + 1) * 32 * 4);
+    tr->pzb_slab_bytes = off;
+    const size_t o_pva = carve((size_t)pz::NWG * pz::UA * 4);
+    HIP_TRY(hipMalloc((void**)&tr->pzb_slab, off));
+    tr->allocs.push_back(tr->pzb_slab);
+    tr->pzb_bar = (unsigned*)(tr->pzb_slab + o_bar);
+    tr->pzb_pva = (float*)(tr->pzb_slab + o_pva);
+    HIP_TRY(hipFuncSetAttribute((const void*)pz::backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)pz::backward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)pz::backward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    return T2_OK;
+}
+// the whole reverse-time recurrence as one launch; fills the same tape buffers as the launch-per-phase loop
+static int pzb_launch(t2_trainer* tr) {
+    t2_model* m = tr->m;
+    const t2_dims& d = m->d;
+    hipStream_t st = m->ctx->stream;
+    t2_state* s = tr->state;
+    const TrainTape& tp = tr->tape;
+    const int B = tr->B, T = tr->T, S = tr->S, MB = mb_for(B), np = d.num_prenet_layers;
+    HIP_TRY(hipMemsetAsync(tr->pzb_slab, 0, tr->pzb_slab_bytes, st));
+    pz::BArgs a{};
+    a.wT2 = tr->pzb_w[0]; a.wT1 = tr->pzb_w[1]; a.wT0 = tr->pzb_w[2]; a.wTQ = tr->pzb_w[3];
+    a.conv_w = m->conv_w; a.conv_b = m->conv_b; a.wloc = m->wloc; a.v_a = m->v_a;
+    a.keys = s->keys; a.values = s->values; a.lens = s->lens;
+    for (int l = 0; l < 3; ++l) { a.z[l] = tp.z[l]; a.cprev[l] = tp.cprev[l]; a.cnew[l] = tp.cnew[l]; a.dz[l] = tr->dz[l]; }
+    a.q = tp.q; a.state_prev = tp.state_prev; a.ctx = tp.ctx; a.hist = s->o_hist;
+    a.dy2_all = tr->dy2_all; a.xp_last = tp.xp[np - 1];
+    a.dq = tr->dq; a.de_all = tr->de_all; a.dctx_all = tr->dctx_all; a.du_all = tr->du_all; a.f_all = tr->f_all; a.df_all = tr->df_all;
+    a.dpre = tr->dpre[np - 1]; a.pva_part = tr->pzb_pva; a.dctx_row_ld = (long long)S * pz::EW;
+    a.xs = (float*)tr->pzb_slab; a.xs_bytes = tr->pzb_xs_bytes;
+    a.oDZ2 = tr->pzb_off[0]; a.oDZ1 = tr->pzb_off[1]; a.oDZ0 = tr->pzb_off[2]; a.oDCTX = tr->pzb_off[3]; a.oDQ = tr->pzb_off[4]; a.oDS = tr->pzb_off[5];
+    a.dz_bytes = tr->pzb_dz_bytes; a.dq_bytes = tr->pzb_dq_bytes;
+    a.bar = tr->pzb_bar; a.err = (int*)(tr->pzb_bar + pz::NSHARD * 32);
+    a.B = B; a.T = T; a.S = S; a.C = persist_chunks(B); a.CH = (T + a.C - 1) / a.C;
+    a.F = d.attention_filters; a.KA = d.attention_kernel; a.cumulative = d.cumulative_weights;
+    a.seed = tp.seed; a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
+    a.inv_keep = 1.0f / (1.0f - tp.prenet_drop_rate);
+    const size_t lds = (size_t)pz::bwd_lds_floats(MB, T, a.CH) * 4;
+    const dim3 grid(pz::NWG), blk(pz::NT);
+    if (MB == 1) hipLaunchKernelGGL((pz::backward_kernel<1>), grid, blk, lds, st, a);
+    else if (MB == 2) hipLaunchKernelGGL((pz::backward_kernel<2>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((pz::backward_kernel<4>), grid, blk, lds, st, a);
+    HIP_TRY(hipGetLastError());
+    ++m->n_bwd_persist;
+    // a hop that ran out of time leaves garbage gradients: fail loudly (the caller reads the loss after this call anyway)
+    int h_err = 0;
+    HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_err) return fail(T2_EHIP, "persistent backward: a grid-wide hop timed out");
     return T2_OK;
 }
 
@@ -897,6 +1013,7 @@ static int trainer_setup_backward(t2_trainer* tr) {
     const size_t lds = (size_t)attn_bwd_lds_floats(U, E, d.attention_filters, d.attention_kernel) * 4;
     if (lds > 150 * 1024) return fail(T2_EINVAL, "attention dimensions too large for the attention backward kernels' LDS");
     HIP_TRY(hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    T2_TRY(pzb_setup(tr));
     return T2_OK;
 }
 
@@ -1081,9 +1198,12 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias; a.first = first_;
         return a;
     };
-    hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * D), dim3(256), 0, st,
-                       lstm_args_at(2, S - 1, 1, tr->dy2_all + (size_t)(S - 1) * B * D, D, nullptr, 0, dzf2[(S - 1) & 1]));
-    for (int t = S - 1; t >= 0; --t) {
+    // the reverse-time recurrence: ONE persistent launch at the paper-size class (persist_bwd.h), else 5 launches per step
+    const bool pzb = m->opt_bwd_persist && tr->pzb_slab != nullptr;
+    if (pzb) T2_TRY(pzb_launch(tr));
+    else hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * D), dim3(256), 0, st,
+                            lstm_args_at(2, S - 1, 1, tr->dy2_all + (size_t)(S - 1) * B * D, D, nullptr, 0, dzf2[(S - 1) & 1]));
+    for (int t = S - 1; !pzb && t >= 0; --t) {
         const int first = (t == S - 1) ? 1 : 0;
         auto lstm_args = [&](int l, const float* go0, int ld0, const float* gh1, int ldh1) {
             return lstm_args_at(l, t, first, go0, ld0, gh1, ldh1, tr->dzf[l]);
@@ -1198,7 +1318,8 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         const long long rows = (long long)SB * T;
         hipLaunchKernelGGL(batch_sum_kernel, grid1((long long)B * T * U), dim3(256), 0, st, tr->du_all, S, (long long)B * T * U, tr->dkeys);
         T2_TRY(grad_dst(tr, flat_grads, "attention/attention_variable", &g));
-        hipLaunchKernelGGL(batch_sum_kernel, grid1(U), dim3(256), 0, st, tr->p_va, B, (long long)U, g);
+        if (pzb) hipLaunchKernelGGL(batch_sum_kernel, grid1(U), dim3(256), 0, st, tr->pzb_pva, pz::NWG, (long long)U, g);
+        else hipLaunchKernelGGL(batch_sum_kernel, grid1(U), dim3(256), 0, st, tr->p_va, B, (long long)U, g);
         T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_layer/kernel", &g));
         T2_TRY(bwd_wgrad(tr, tr->f_all, F, F, tr->du_all, U, U, rows, g, U));
         T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/kernel", &g));
@@ -1948,6 +2069,7 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
     T2_TRY(flat_src(tr, flat, "attention/query_layer/kernel", &w));
     if (model_part) { T2_TRY(copy(m->wq, w, (size_t)A * U)); repack(st, m->wq_pk, w, U, 1, U); }
     if (trainer_part) repack(st, tr->wqT, w, 1, U, A);
+    if (trainer_part) T2_TRY(pzb_pack(tr, 3, w));
     if (model_part) {
         T2_TRY(flat_src(tr, flat, "attention/location_features_convolution/kernel", &w)); T2_TRY(copy(m->conv_w, w, (size_t)K * F));
         T2_TRY(flat_src(tr, flat, "attention/location_features_convolution/bias", &w)); T2_TRY(copy(m->conv_b, w, F));
@@ -1984,6 +2106,7 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
             hipLaunchKernelGGL(lstm_bias_pack_kernel, grid1(lp[l]->n_wg * 16), dim3(256), 0, st, lp[l]->bias, b, lp[l]->n_wg, Hh[l]);
         }
         if (trainer_part) repack(st, tr->lstmT[l], w, 1, 4 * Hh[l], KXs[l]);
+        if (trainer_part) T2_TRY(pzb_pack(tr, 2 - l, w));
     }
     {   // projections: concatenated [D][M*r + 1] operand and its transpose
         const int N = M * r + 1;

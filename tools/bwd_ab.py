@@ -1,0 +1,76 @@
+"""Persistent backward recurrence (option bwd_persist=1) against the launch-per-phase backward (=0) on the same tape:
+per-variable gradient differences and the time of t2_train_decoder_backward.  usage: bwd_ab.py B T S [B T S ...]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+from tacotron2_amd import training as TR
+from tacotron2_amd.engine import Engine
+from tacotron2_amd.hparams import PROFILE_P
+from tacotron2_amd.weights import init_weights
+
+
+def run(B, T, S, reps=3):
+    d = PROFILE_P
+    w = init_weights(d, seed=5, perturb=True)
+    rng = np.random.default_rng(B * 1000 + T + S)
+    r = d.outputs_per_step
+    lens = rng.integers(max(1, T // 2), T + 1, B).astype(np.int64)
+    lens[0] = T
+    memory = rng.uniform(-1, 1, (B, T, d.enc_units)).astype(np.float32)
+    tl = rng.integers(max(1, S * r // 2), S * r + 1, B)
+    tl[0] = S * r
+    sl = (tl + r - 1) // r
+    labels = {"mel": rng.uniform(0, 1, (B, S * r, d.num_mels)).astype(np.float32),
+              "done": (np.arange(S)[None, :] >= (sl[:, None] - 1)).astype(np.float32),
+              "spec_loss_mask": (np.arange(S * r)[None, :] < tl[:, None]).astype(np.float32),
+              "binary_loss_mask": (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)}
+    eng = Engine(d, w)
+    tr = TR.Trainer(eng, B, T, S)
+    spec = TR.flatten_spec(w)
+    tr.bind_gradients(spec)
+    out = {}
+    for opt in (0, 1):
+        eng.set_option("bwd_persist", opt)
+        tr.decoder_forward(memory, lens, labels["mel"], prenet_drop_rate=0.5, seed=3)
+        flat = torch.zeros(TR.flat_size(spec), dtype=torch.float32, device="cuda")
+        n0 = eng.get_stat("bwd_persist_launches")
+        dmem, losses = tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat)
+        torch.cuda.synchronize()
+        assert eng.get_stat("bwd_persist_launches") == n0 + opt, "persistent backward did not run"
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out[opt] = (TR.unflatten(flat, spec), dmem.cpu().numpy(), min(ts))
+    g0, m0, t0 = out[0]
+    g1, m1, t1 = out[1]
+    worst = []
+    for name in sorted(g0):
+        if not (name.startswith("decoder") or name.startswith("attention")):
+            continue
+        scale = float(np.abs(g0[name]).max())
+        err = float(np.abs(g1[name] - g0[name]).max())
+        worst.append((err / (scale + 1e-12), name, err, scale))
+    worst.append((float(np.abs(m1 - m0).max()) / (float(np.abs(m0).max()) + 1e-12), "dmemory", float(np.abs(m1 - m0).max()), float(np.abs(m0).max())))
+    worst.sort(reverse=True)
+    print(f"B={B} T={T} S={S}: backward {t0:.2f} ms (launch per phase) -> {t1:.2f} ms (persistent); worst relative differences:")
+    for rel, name, err, scale in worst[:6]:
+        print(f"    {name:55s} rel {rel:.2e} (abs {err:.3e}, scale {scale:.3e})")
+    bad = [x for x in worst if x[0] > 2e-4]
+    tr.close()
+    eng.close()
+    return not bad
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:]]
+    ok = True
+    for i in range(0, len(a), 3):
+        ok = run(a[i], a[i + 1], a[i + 2]) and ok
+    print("ALL OK" if ok else "MISMATCH")
+    sys.exit(0 if ok else 1)
