@@ -226,6 +226,12 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         }
     };
 
+#ifdef PZ_STAMPS
+    unsigned long long st_acc[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) st_acc[i] = 0;
+    unsigned long long st_prev = __builtin_amdgcn_s_memrealtime();
+#endif
     unsigned epoch = 0;
     bool alive = true;
     f32x4 acc[MB];
@@ -235,6 +241,240 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     };
     __syncthreads();
 
+    f32x4 acc2[MB];            // GEMM 2 of the step ahead, accumulated piecewise in the hop gaps
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // k-blocks [k0, k0 + NKB) of this wave's 32 of GEMM 2 over dz2(tt)
+    auto gemm2_part8 = [&](int tt, int k0) {
+        f32x4 b[8];
+        wloadc<8>(b, rW2, (unsigned)((wg * KBZ + wave * 32 + k0) * 64 * NC2), (unsigned)((kg * NC2 + min(c16, NC2 - 1)) * 16), 64u * NC2);
+        seg_mma<MB, 8>(acc2, b, xs, a.oDZ2 + (unsigned)(tt & 1) * a.dz_bytes + (unsigned)((wave * 32 + k0) * MB * 1024), l16);
+    };
+    auto gemm2_part4 = [&](int tt, int k0) {
+        f32x4 b[4];
+        wloadc<4>(b, rW2, (unsigned)((wg * KBZ + wave * 32 + k0) * 64 * NC2), (unsigned)((kg * NC2 + min(c16, NC2 - 1)) * 16), 64u * NC2);
+        seg_mma<MB, 4>(acc2, b, xs, a.oDZ2 + (unsigned)(tt & 1) * a.dz_bytes + (unsigned)((wave * 32 + k0) * MB * 1024), l16);
+    };
+    // GEMM 0 of step tt (d [prenet out | ctx_prev | h_att_prev] = dz_att(tt) . W0^T) and what this workgroup keeps of it
+    auto gemm0 = [&](int tt) {
+        float xpv = 0.f;
+        if (tid < MB * 64 && eown && euu == 2) xpv = a.xp_last[((size_t)tt * B + erow) * 256 + wg];
+        zero_acc();
+        gemm_dz<MB>(acc, rW0, (unsigned)((wg * KBZ + wave * 32) * 64 * NC0), 64u * NC0, (unsigned)((kg * NC0 + min(c16, NC0 - 1)) * 16), xs,
+                    a.oDZ0 + (unsigned)(wave * 32 * MB * 1024), l16);
+        put_red(acc);
+        __syncthreads();
+        fresh();
+        if (tid < MB * 64) {
+            dhAp = colsum(euu);
+            if (euu < 2) dctxp = colsum(4 + euu);
+            if (euu == 2 && eown) {
+                // PreNet backward through dropout(relu(.)) (modules.py:88-91): d pre = (y != 0) ? d y / keep : 0
+                const float v = colsum(6);
+                a.dpre[((size_t)tt * B + erow) * 256 + wg] = xpv != 0.f ? v * a.inv_keep : 0.f;
+            }
+        }
+        __syncthreads();          // the next product overwrites the reduction tiles
+    };
+    // ---- attention backward, part 1 (hop gap): everything that does not need d ctx of the step ----
+    float pre[4][4];
+    float ctx_v = 0.f, part_gs = 0.f;
+    constexpr int VN = 5;       // values rows per wave kept in registers across the hop (positions wave, wave + 8, ...)
+    float vv[VN][8];
+    auto att_pre = [&](int t) {
+        const size_t tb = (size_t)t * B + ab;
+        ctx_v = a.ctx[tb * EW + tid];
+        for (int p = tid; p < T; p += NT) s_al[p] = a.hist[tb * T + p];
+        // d state after this step = (cumulative: d state after step t + 1) + the C chunks' partials of step t + 1
+        if (t < S - 1) {
+            const unsigned ds_prev = a.oDS + (unsigned)((((t + 1) & 1) * B + ab) * C * NIP * 4);
+            for (int p = tid; p < T; p += NT) {
+                float s = a.cumulative ? s_gs[p] : 0.f;
+                for (int c2 = 0; c2 < C; ++c2) {
+                    const int i = p - (c2 * CH - pl);
+                    if (i >= 0 && i < NIP) s += ld4(xs, ds_prev + (unsigned)((c2 * NIP + i) * 4));
+                }
+                s_gs[p] = s;
+            }
+        }
+        for (int i = tid; i < CHP + 48; i += NT) {
+            const int p = p0 - pl + i;
+            s_sp[i] = (p >= 0 && p < T && i < n_pos + a.KA - 1) ? a.state_prev[tb * T + p] : 0.f;
+        }
+        if (tid < UA) s_q[tid] = a.q[tb * UA + tid];
+        {
+            const float* keys_b = a.keys + (size_t)ab * T * UA + wave * 16 + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int p = min(p0 + 16 * r + 4 * kg + g, T - 1);
+                    pre[r][g] = r < NRT ? keys_b[(size_t)p * UA] : 0.f;
+                }
+            const float* vals = a.values + ((size_t)ab * T + p0) * EW;
+#pragma unroll
+            for (int jj = 0; jj < VN; ++jj) {
+                const int j = min(wave + jj * NWAVE, max(n_pos - 1, 0));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vv[jj][i] = vals[(size_t)j * EW + lane + 64 * i];
+            }
+        }
+        __syncthreads();
+        // a . d state part of the softmax-backward dot (every chunk computes the row's whole dot)
+        part_gs = 0.f;
+        for (int p = tid; p < T; p += NT) part_gs = fmaf(s_al[p], s_gs[p], part_gs);
+        // location features of the chunk (as persist.h attention_pre)
+        {
+            const int f = tid & 31, pq = tid >> 5;
+            if (4 * pq < CHP) {
+                float win[36];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_sp + 4 * pq + 4 * i);
+                    win[4 * i] = w4[0]; win[4 * i + 1] = w4[1]; win[4 * i + 2] = w4[2]; win[4 * i + 3] = w4[3];
+                }
+                const float cb = s_cb[f];
+                float fa[4] = {cb, cb, cb, cb};
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const float wj = s_cw[j * 32 + f];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[i] = fmaf(wj, win[i + j], fa[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_f[(4 * pq + i) * 36 + f] = (4 * pq + i < n_pos) ? fa[i] : 0.f;
+            }
+        }
+        __syncthreads();
+        // processed location features on the matrix pipe, then pre = keys + f . Wloc (the query joins in part 2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < NRT) {
+                f32x4 pf = {0.f, 0.f, 0.f, 0.f};
+                const float* fr = s_f + (16 * r + c16) * 36 + 4 * kg;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(fr), a1 = *reinterpret_cast<const f32x4*>(fr + 16);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], wlB[s], pf, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], wlB[4 + s], pf, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[r][g] += pf[g];
+            }
+        }
+    };
+    // ---- attention backward, part 2 (after hop B): train_step.h attention_bwd_kernel's arithmetic from d ctx on ----
+    auto att_main = [&](int t) {
+        const size_t tb = (size_t)t * B + ab;
+        const float dcx = ld4(xs, a.oDCTX + (unsigned)((ab * EW + tid) * 4));
+        s_dctx[tid] = dcx;
+        // softmax-backward dot: d ctx . ctx_t + a . d state
+        float part = fmaf(dcx, ctx_v, part_gs);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) s_rd[wave] = part;
+        __syncthreads();
+        // d alignments: da_j = d ctx . values_j + d state_j; wave w takes positions w, w + 8, ...
+        {
+            float dv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dv[i] = s_dctx[lane + 64 * i];
+#pragma unroll
+            for (int jj = 0; jj < VN; ++jj) {
+                const int j = wave + jj * NWAVE;
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s = fmaf(dv[i], vv[jj][i], s);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0 && j < n_pos) s_da[j] = s + s_gs[p0 + j];
+            }
+            const float* vals = a.values + ((size_t)ab * T + p0) * EW;
+            for (int j = wave + VN * NWAVE; j < n_pos; j += NWAVE) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s = fmaf(dv[i], vals[(size_t)j * EW + lane + 64 * i], s);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0) s_da[j] = s + s_gs[p0 + j];
+            }
+        }
+        __syncthreads();
+        if (tid < CHP) {
+            float dot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) dot += s_rd[w];
+            const float de = (tid < n_pos && p0 + tid < len_b) ? s_al[p0 + tid] * (s_da[tid] - dot) : 0.f;
+            s_de[tid] = de;
+            if (tid < n_pos) a.de_all[tb * T + p0 + tid] = de;
+        }
+        __syncthreads();
+        // d u = d e * v * (1 - tanh^2), d v_a += d e * tanh, d q = sum over positions of d u
+        {
+            const float q_l = s_q[wave * 16 + c16];
+            float dqs = 0.f;
+            float* du_t = a.du_all + (tb * T + p0) * UA + wave * 16 + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < NRT) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int pos = 16 * r + 4 * kg + g;
+                        const float de = s_de[pos];
+                        const float th = tanhf(pre[r][g] + q_l);
+                        const float du = de * va_l * (1.f - th * th);
+                        dva_acc = fmaf(de, th, dva_acc);
+                        dqs += du;
+                        s_du[pos * DUS + wave * 16 + c16] = du;
+                        if (pos < n_pos) du_t[(size_t)pos * UA] = du;
+                    }
+                }
+            }
+            dqs += __shfl_xor(dqs, 16); dqs += __shfl_xor(dqs, 32);
+            if (kg == 0) s_dq[wave * 16 + c16] = dqs;
+        }
+        __syncthreads();
+        // this chunk's partial d q as a frag16 operand of the query-layer product
+        if (tid < UA / 4) st16(xs, a.oDQ + (unsigned)ac * a.dq_bytes + frag_off16(ab, tid, MB), *reinterpret_cast<const f32x4*>(s_dq + 4 * tid));
+        // d f = d u . Wloc^T on the matrix pipe: wave w -> positions 16 (w >> 1) .., filters 16 (w & 1) ..
+        {
+            const int r = wave >> 1, ct = wave & 1;
+            if (r < NRT) {
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                const float* ur = s_du + (16 * r + c16) * DUS + 4 * kg;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ur + 16 * kb);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], wdf[kb][j], d4, 0, 0, 0);
+                }
+                const int filt = 16 * ct + c16;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int pos = 16 * r + 4 * kg + g;
+                    s_df[pos * 36 + filt] = d4[g];
+                    if (pos < n_pos && filt < a.F) {
+                        a.df_all[(tb * T + p0 + pos) * a.F + filt] = d4[g];
+                        a.f_all[(tb * T + p0 + pos) * a.F + filt] = s_f[pos * 36 + filt];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // partial d state_prev over the chunk + conv halo: ds[i] <-> position p0 - pad_l + i
+        {
+            const int i = tid >> 2, cg = tid & 3;
+            float s = 0.f;
+            if (i < NIP) {
+                const int ja = max(0, i - a.KA + 1), jb = min(n_pos - 1, i);
+                for (int j = ja; j <= jb; ++j)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) s = fmaf(s_cw[(i - j) * 32 + cg + 4 * c], s_df[j * 36 + cg + 4 * c], s);
+            }
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            if (i < NIP && cg == 0) st4(xs, a.oDS + (unsigned)(((((t & 1) * B + ab) * C + ac) * NIP + i) * 4), s);
+        }
+    };
+
     // ---- LSTM 2 backward of the last step: its raw-output gradient comes from the projections only ----
     if (tid < MB * 64) {
         const TapeRow r2 = tape_load(2, S - 1);
@@ -243,33 +483,36 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     }
     hop_arrive(a.bar); ++epoch;
     if (!hop_wait(a.bar, 32u * epoch, s_flag)) alive = false;
+    if (alive) { gemm2_part8(S - 1, 0); gemm2_part8(S - 1, 8); gemm2_part8(S - 1, 16); gemm2_part8(S - 1, 24); }
 
+#ifdef PZ_STAMPS
+    st_prev = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = S - 1; alive && t >= 0; --t) {
         fresh();
-        // tape rows of this step's cell backwards (plain loads, in flight during GEMM 2)
-        TapeRow r2{}, r1{}, r0{};
-        float dy2p = 0.f, xpv = 0.f;
+        // ================= GEMM 2 of this step is complete (accumulated in the previous step's gaps): cell backwards =================
+        put_red(acc2);
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        TapeRow r0{}, r1{}, r2{};
+        float dy2p = 0.f;
         if (tid < MB * 64) {
             r2 = tape_load(2, t - 1); r1 = tape_load(1, t); r0 = tape_load(0, t);
             if (eown && t > 0) dy2p = a.dy2_all[((size_t)(t - 1) * B + erow) * (NWG * 4) + wg * 4 + euu];
-            if (eown && euu == 2) xpv = a.xp_last[((size_t)t * B + erow) * 256 + wg];
         }
-        // ================= GEMM 2: d [y1 | h2_prev] = dz2(t) . W2^T =================
-        zero_acc();
-        gemm_dz<MB>(acc, rW2, (unsigned)((wg * KBZ + wave * 32) * 64 * NC2), 64u * NC2, (unsigned)((kg * NC2 + min(c16, NC2 - 1)) * 16), xs,
-                    a.oDZ2 + (unsigned)(t & 1) * a.dz_bytes + (unsigned)(wave * 32 * MB * 1024), l16);
-        put_red(acc);
         __syncthreads();
-        fresh();
         if (tid < MB * 64) {
             const float dy1 = colsum(euu);
             dh2p = colsum(4 + euu);
             if (t > 0) cell_bwd(2, t - 1, r2, dy2p, ghp2 + dh2p, gc2, ghp2, a.oDZ2 + (unsigned)((t - 1) & 1) * a.dz_bytes);
             cell_bwd(1, t, r1, dy1, ghp1 + dh1p, gc1, ghp1, a.oDZ1);
         }
-        hop_arrive(a.bar); ++epoch; fresh();
+        PZ_STAMP(1); hop_arrive(a.bar); ++epoch; fresh();
+        // gap A: GEMM 0 of step t + 1 (its results are first needed behind this hop: d ctx_prev below, d h_att_prev in the query phase)
+        if (t < S - 1) gemm0(t + 1);
+        PZ_STAMP(0);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
+        fresh(); PZ_STAMP(2);
 
         // ================= GEMM 1: d [h_att | ctx | h1_prev] = dz1(t) . W1^T =================
         zero_acc();
@@ -291,183 +534,36 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
                 }
             }
         }
-        hop_arrive(a.bar); ++epoch; fresh();
+        PZ_STAMP(3); hop_arrive(a.bar); ++epoch; fresh();
+        // gap B: first part of GEMM 2 of step t - 1 (dz2(t - 1) was published before hop A), attention pre-work
+        if (t > 0) { gemm2_part8(t - 1, 0); gemm2_part4(t - 1, 8); fresh(); }
+        // (dead values for the workgroups without an attention role: keeps these registers from being live around the loop)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[r][g] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < VN; ++jj)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vv[jj][i] = 0.f;
+        ctx_v = 0.f; part_gs = 0.f;
+        if (isAtt) { att_pre(t); fresh(); }
+        PZ_STAMP(9);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
+        fresh(); PZ_STAMP(4);
 
-        // ================= attention backward (train_step.h attention_bwd_kernel's arithmetic) =================
-        if (isAtt) {
-            const size_t tb = (size_t)t * B + ab;
-            // (a) inputs of the step
-            s_dctx[tid] = ld4(xs, a.oDCTX + (unsigned)((ab * EW + tid) * 4));
-            float part = s_dctx[tid] * a.ctx[tb * EW + tid];
-            for (int p = tid; p < T; p += NT) s_al[p] = a.hist[tb * T + p];
-            // d state after this step = (cumulative: d state after step t + 1) + the C chunks' partials of step t + 1
-            if (t < S - 1) {
-                const unsigned ds_prev = a.oDS + (unsigned)((((t + 1) & 1) * B + ab) * C * NIP * 4);
-                for (int p = tid; p < T; p += NT) {
-                    float s = a.cumulative ? s_gs[p] : 0.f;
-                    for (int c2 = 0; c2 < C; ++c2) {
-                        const int i = p - (c2 * CH - pl);
-                        if (i >= 0 && i < NIP) s += ld4(xs, ds_prev + (unsigned)((c2 * NIP + i) * 4));
-                    }
-                    s_gs[p] = s;
-                }
-            }
-            for (int i = tid; i < CHP + 48; i += NT) {
-                const int p = p0 - pl + i;
-                s_sp[i] = (p >= 0 && p < T && i < n_pos + a.KA - 1) ? a.state_prev[tb * T + p] : 0.f;
-            }
-            if (tid < UA) s_q[tid] = a.q[tb * UA + tid];
-            float pre[4][4];
-            {
-                const float* keys_b = a.keys + (size_t)ab * T * UA + wave * 16 + c16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int p = min(p0 + 16 * r + 4 * kg + g, T - 1);
-                        pre[r][g] = r < NRT ? keys_b[(size_t)p * UA] : 0.f;
-                    }
-            }
-            __syncthreads();
-            // (b) softmax-backward dot: d ctx . ctx_t + a . d state  (every chunk computes the row's whole dot)
-            for (int p = tid; p < T; p += NT) part = fmaf(s_al[p], s_gs[p], part);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if (lane == 0) s_rd[wave] = part;
-            // (c) location features of the chunk (as persist.h attention_pre)
-            {
-                const int f = tid & 31, pq = tid >> 5;
-                if (4 * pq < CHP) {
-                    float win[36];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) {
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_sp + 4 * pq + 4 * i);
-                        win[4 * i] = w4[0]; win[4 * i + 1] = w4[1]; win[4 * i + 2] = w4[2]; win[4 * i + 3] = w4[3];
-                    }
-                    const float cb = s_cb[f];
-                    float fa[4] = {cb, cb, cb, cb};
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) {
-                        const float wj = s_cw[j * 32 + f];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) fa[i] = fmaf(wj, win[i + j], fa[i]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s_f[(4 * pq + i) * 36 + f] = (4 * pq + i < n_pos) ? fa[i] : 0.f;
-                }
-            }
-            // (d) d alignments: da_j = d ctx . values_j + d state_j; wave w takes positions w, w + 8, ...
-            {
-                const float* vals = a.values + ((size_t)ab * T + p0) * EW;
-                for (int j = wave; j < n_pos; j += NWAVE) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) s = fmaf(s_dctx[lane + 64 * i], vals[(size_t)j * EW + lane + 64 * i], s);
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                    if (lane == 0) s_da[j] = s + s_gs[p0 + j];
-                }
-            }
-            __syncthreads();
-            if (tid < CHP) {
-                float dot = 0.f;
-#pragma unroll
-                for (int w = 0; w < NWAVE; ++w) dot += s_rd[w];
-                const float de = (tid < n_pos && p0 + tid < len_b) ? s_al[p0 + tid] * (s_da[tid] - dot) : 0.f;
-                s_de[tid] = de;
-                if (tid < n_pos) a.de_all[tb * T + p0 + tid] = de;
-            }
-            // processed location features on the matrix pipe, then pre = keys + q + f . Wloc
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r < NRT) {
-                    f32x4 pf = {0.f, 0.f, 0.f, 0.f};
-                    const float* fr = s_f + (16 * r + c16) * 36 + 4 * kg;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(fr), a1 = *reinterpret_cast<const f32x4*>(fr + 16);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], wlB[s], pf, 0, 0, 0);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) pf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], wlB[4 + s], pf, 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) pre[r][g] += pf[g];
-                }
-            }
-            __syncthreads();
-            // (e) d u = d e * v * (1 - tanh^2), d v_a += d e * tanh, d q = sum over positions of d u
-            {
-                const float q_l = s_q[wave * 16 + c16];
-                float dqs = 0.f;
-                float* du_t = a.du_all + (tb * T + p0) * UA + wave * 16 + c16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (r < NRT) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int pos = 16 * r + 4 * kg + g;
-                            const float de = s_de[pos];
-                            const float th = tanhf(pre[r][g] + q_l);
-                            const float du = de * va_l * (1.f - th * th);
-                            dva_acc = fmaf(de, th, dva_acc);
-                            dqs += du;
-                            s_du[pos * DUS + wave * 16 + c16] = du;
-                            if (pos < n_pos) du_t[(size_t)pos * UA] = du;
-                        }
-                    }
-                }
-                dqs += __shfl_xor(dqs, 16); dqs += __shfl_xor(dqs, 32);
-                if (kg == 0) s_dq[wave * 16 + c16] = dqs;
-            }
-            __syncthreads();
-            // this chunk's partial d q as a frag16 operand of the query-layer product
-            if (tid < UA / 4) st16(xs, a.oDQ + (unsigned)ac * a.dq_bytes + frag_off16(ab, tid, MB), *reinterpret_cast<const f32x4*>(s_dq + 4 * tid));
-            // (f) d f = d u . Wloc^T on the matrix pipe: wave w -> positions 16 (w >> 1) .., filters 16 (w & 1) ..
-            {
-                const int r = wave >> 1, ct = wave & 1;
-                if (r < NRT) {
-                    f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-                    const float* ur = s_du + (16 * r + c16) * DUS + 4 * kg;
-#pragma unroll
-                    for (int kb = 0; kb < 8; ++kb) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ur + 16 * kb);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) d4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], wdf[kb][j], d4, 0, 0, 0);
-                    }
-                    const int filt = 16 * ct + c16;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int pos = 16 * r + 4 * kg + g;
-                        s_df[pos * 36 + filt] = d4[g];
-                        if (pos < n_pos && filt < a.F) {
-                            a.df_all[(tb * T + p0 + pos) * a.F + filt] = d4[g];
-                            a.f_all[(tb * T + p0 + pos) * a.F + filt] = s_f[pos * 36 + filt];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // (g) partial d state_prev over the chunk + conv halo: ds[i] <-> position p0 - pad_l + i
-            {
-                const int i = tid >> 2, cg = tid & 3;
-                float s = 0.f;
-                if (i < NIP) {
-                    const int ja = max(0, i - a.KA + 1), jb = min(n_pos - 1, i);
-                    for (int j = ja; j <= jb; ++j)
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) s = fmaf(s_cw[(i - j) * 32 + cg + 4 * c], s_df[j * 36 + cg + 4 * c], s);
-                }
-                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-                if (i < NIP && cg == 0) st4(xs, a.oDS + (unsigned)(((((t & 1) * B + ab) * C + ac) * NIP + i) * 4), s);
-            }
-        }
-        hop_arrive(a.bar); ++epoch; fresh();
+        // ================= attention backward =================
+        if (isAtt) { att_main(t); fresh(); }
+        PZ_STAMP(5); hop_arrive(a.bar); ++epoch; fresh();
+        // gap C: second part of GEMM 2 of step t - 1
+        if (t > 0) { gemm2_part8(t - 1, 12); gemm2_part4(t - 1, 20); fresh(); }
+        const f32x4 bq = ldw(rWQ, (unsigned)((kg * NCQ + min(c16, NCQ - 1)) * 16), (unsigned)((wg * 8 + wave) * 64 * NCQ));
+        PZ_STAMP(10);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
+        fresh(); PZ_STAMP(6);
 
         // ================= query layer: d h_att += (sum of the C partial d q) . Wq^T; attention LSTM backward =================
         {
-            const f32x4 bq = ldw(rWQ, (unsigned)((kg * NCQ + min(c16, NCQ - 1)) * 16), (unsigned)((wg * 8 + wave) * 64 * NCQ));
             zero_acc();
             for (int c2 = 0; c2 < C; ++c2) {
 #pragma unroll
@@ -492,28 +588,21 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
                 cell_bwd(0, t, r0, dhA1 + dhq, ghp0 + dhAp, gc0, ghp0, a.oDZ0);
             }
         }
-        hop_arrive(a.bar); ++epoch; fresh();
+        PZ_STAMP(7); hop_arrive(a.bar); ++epoch; fresh();
+        // gap D: last part of GEMM 2 of step t - 1
+        if (t > 0) { gemm2_part8(t - 1, 24); fresh(); }
+        PZ_STAMP(11);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
-        fresh();
-
-        // ================= GEMM 0: d [prenet out | ctx_prev | h_att_prev] = dz_att(t) . W0^T =================
-        zero_acc();
-        gemm_dz<MB>(acc, rW0, (unsigned)((wg * KBZ + wave * 32) * 64 * NC0), 64u * NC0, (unsigned)((kg * NC0 + min(c16, NC0 - 1)) * 16), xs,
-                    a.oDZ0 + (unsigned)(wave * 32 * MB * 1024), l16);
-        put_red(acc);
-        __syncthreads();
-        fresh();
-        if (tid < MB * 64) {
-            dhAp = colsum(euu);
-            if (euu < 2) dctxp = colsum(4 + euu);
-            if (euu == 2 && eown) {
-                // PreNet backward through dropout(relu(.)) (modules.py:88-91): d pre = (y != 0) ? d y / keep : 0
-                const float v = colsum(6);
-                a.dpre[((size_t)t * B + erow) * 256 + wg] = xpv != 0.f ? v * a.inv_keep : 0.f;
-            }
-        }
-        __syncthreads();          // the next step's GEMM 2 overwrites the reduction tiles
+        fresh(); PZ_STAMP(8);
     }
+    // the last product: d prenet of step 0
+    if (alive) gemm0(0);
+#ifdef PZ_STAMPS
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) g_pz_stamps[wg][i] = st_acc[i];
+    }
+#endif
     fresh();
     // d v_a: this workgroup's sum over all steps of its chunk (rows of pva_part are added in order after the launch)
     {
