@@ -290,9 +290,18 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
             const unsigned ds_prev = a.oDS + (unsigned)((((t + 1) & 1) * B + ab) * C * NIP * 4);
             for (int p = tid; p < T; p += NT) {
                 float s = a.cumulative ? s_gs[p] : 0.f;
-                for (int c2 = 0; c2 < C; ++c2) {
-                    const int i = p - (c2 * CH - pl);
-                    if (i >= 0 && i < NIP) s += ld4(xs, ds_prev + (unsigned)((c2 * NIP + i) * 4));
+                // chunks whose window [c CH - pad_l, c CH - pad_l + NIP) holds p; four loads in flight per round
+                const int c_hi = min(C - 1, (p + pl) / CH);
+                const int c_lo = max(0, (p + pl - NIP + CH) / CH);
+                for (int c0 = c_lo; c0 <= c_hi; c0 += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c2 = min(c0 + k, c_hi);
+                        v[k] = ld4(xs, ds_prev + (unsigned)((c2 * NIP + p - (c2 * CH - pl)) * 4));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (c0 + k <= c_hi) s += v[k];
                 }
                 s_gs[p] = s;
             }
@@ -484,6 +493,12 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     hop_arrive(a.bar); ++epoch;
     if (!hop_wait(a.bar, 32u * epoch, s_flag)) alive = false;
     if (alive) { gemm2_part8(S - 1, 0); gemm2_part8(S - 1, 8); gemm2_part8(S - 1, 16); gemm2_part8(S - 1, 24); }
+    TapeRow r1{}, r2{};
+    float dy2p = 0.f;
+    if (tid < MB * 64) {
+        r2 = tape_load(2, S - 2); r1 = tape_load(1, S - 1);
+        dy2p = (eown && S > 1) ? a.dy2_all[((size_t)(S - 2) * B + erow) * (NWG * 4) + wg * 4 + euu] : 0.f;
+    }
 
 #ifdef PZ_STAMPS
     st_prev = __builtin_amdgcn_s_memrealtime();
@@ -494,12 +509,8 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         put_red(acc2);
 #pragma unroll
         for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        TapeRow r0{}, r1{}, r2{};
-        float dy2p = 0.f;
-        if (tid < MB * 64) {
-            r2 = tape_load(2, t - 1); r1 = tape_load(1, t); r0 = tape_load(0, t);
-            if (eown && t > 0) dy2p = a.dy2_all[((size_t)(t - 1) * B + erow) * (NWG * 4) + wg * 4 + euu];
-        }
+        TapeRow r0{};
+        if (tid < MB * 64) r0 = tape_load(0, t);
         __syncthreads();
         if (tid < MB * 64) {
             const float dy1 = colsum(euu);
@@ -565,22 +576,30 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         // ================= query layer: d h_att += (sum of the C partial d q) . Wq^T; attention LSTM backward =================
         {
             zero_acc();
-            for (int c2 = 0; c2 < C; ++c2) {
+            // d q of the row (tape of the query layer's weight gradient): workgroup b < B sums row b's partials (C is 4, 8 or 16)
+            float dq_row = 0.f;
+            const bool dq_owner = wg < B && tid < UA;
+            const unsigned dq_off = frag_off16(min(wg, B - 1), (tid & (UA - 1)) >> 2, MB) + (unsigned)((tid & 3) * 4);
+            for (int c0 = 0; c0 < C; c0 += 4) {
+                f32x4 av[4][MB];
+                float dv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int rb = 0; rb < MB; ++rb) {
-                    const f32x4 av = ldx(xs, l16, a.oDQ + (unsigned)c2 * a.dq_bytes + (unsigned)((wave * MB + rb) * 1024));
+                for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[j], acc[rb], 0, 0, 0);
+                    for (int rb = 0; rb < MB; ++rb) av[k][rb] = ldx(xs, l16, a.oDQ + (unsigned)(c0 + k) * a.dq_bytes + (unsigned)((wave * MB + rb) * 1024));
+                    if (dq_owner) dv[k] = ld4(xs, a.oDQ + (unsigned)(c0 + k) * a.dq_bytes + dq_off);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int rb = 0; rb < MB; ++rb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][rb][j], bq[j], acc[rb], 0, 0, 0);
+                    dq_row += dv[k];
                 }
             }
             put_red(acc);
-            // d q of the row (tape of the query layer's weight gradient): workgroup b < B sums row b's partials
-            if (wg < B && tid < UA) {
-                float s = 0.f;
-                const unsigned off = frag_off16(wg, tid >> 2, MB) + (unsigned)((tid & 3) * 4);
-                for (int c2 = 0; c2 < C; ++c2) s += ld4(xs, a.oDQ + (unsigned)c2 * a.dq_bytes + off);
-                a.dq[((size_t)t * B + wg) * UA + tid] = s;
-            }
+            if (dq_owner) a.dq[((size_t)t * B + wg) * UA + tid] = dq_row;
             __syncthreads();
             fresh();
             if (tid < MB * 64) {
@@ -591,6 +610,11 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         PZ_STAMP(7); hop_arrive(a.bar); ++epoch; fresh();
         // gap D: last part of GEMM 2 of step t - 1
         if (t > 0) { gemm2_part8(t - 1, 24); fresh(); }
+        // tape rows of the next step's LSTM 2 / LSTM 1 backwards: in flight across the hop
+        if (tid < MB * 64 && t > 0) {
+            r2 = tape_load(2, t - 2); r1 = tape_load(1, t - 1);
+            dy2p = (eown && t > 1) ? a.dy2_all[((size_t)(t - 2) * B + erow) * (NWG * 4) + wg * 4 + euu] : 0.f;
+        }
         PZ_STAMP(11);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
         fresh(); PZ_STAMP(8);
