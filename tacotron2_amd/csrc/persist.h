@@ -872,10 +872,14 @@ struct EArgs {
     float* out;                 // [B][T][512]
     int B, T;
     float zc, zh, fb;
+    // training forward (TRAIN instantiation): sampled zoneout (modules.py:274-276) and the tape of the backward pass,
+    // per direction [T][B][.] in step order (train_step.h EncTape)
+    float *tz[2], *tcprev[2], *tcnew[2], *thstate[2];
+    unsigned seed; int stream;
 };
 constexpr int ENC_G = 64;       // workgroups per direction (256 hidden units / 4)
 
-template <int MB>
+template <int MB, bool TRAIN = false>
 __global__ __launch_bounds__(NT) void encoder_kernel(EArgs a) {
     __shared__ f32x4 red[NWAVE * MB * 64];
     __shared__ float s_bias[16];
@@ -931,11 +935,25 @@ __global__ __launch_bounds__(NT) void encoder_kernel(EArgs a) {
             const float cn = sigmoidf_(z[2] + a.fb) * c + sigmoidf_(z[0]) * tanhf(z[1]);
             const float hn = sigmoidf_(z[3]) * tanhf(cn);
             const bool live = s < len;
+            const float cp = c;
             if (live) {
-                c = (1.0f - a.zc) * cn + a.zc * c;
-                h = (1.0f - a.zh) * hn + a.zh * h;
+                if constexpr (TRAIN) {
+                    const unsigned stream = (unsigned)(a.stream + 2 * dir), unit = (unsigned)(g * 4 + euu);
+                    c = (1.0f - a.zc) * dropout_train(cn - c, a.zc, t2_u01(a.seed, stream, (unsigned)s, (unsigned)erow, unit)) + c;
+                    h = (1.0f - a.zh) * dropout_train(hn - h, a.zh, t2_u01(a.seed, stream + 1u, (unsigned)s, (unsigned)erow, unit)) + h;
+                } else {
+                    c = (1.0f - a.zc) * cn + a.zc * c;
+                    h = (1.0f - a.zh) * hn + a.zh * h;
+                }
                 const int tpos = dir ? (len - 1 - s) : s;
                 a.out[((size_t)erow * T + tpos) * 512 + dir * 256 + g * 4 + euu] = hn;
+            }
+            if (TRAIN && eown) {
+                const size_t ti = (size_t)s * B + erow;
+                const int unit = g * 4 + euu;
+                float* tz = a.tz[dir] + ti * 1024;
+                tz[unit] = z[0]; tz[256 + unit] = z[1]; tz[512 + unit] = z[2]; tz[768 + unit] = z[3];
+                a.tcprev[dir][ti * 256 + unit] = cp; a.tcnew[dir][ti * 256 + unit] = cn; a.thstate[dir][ti * 256 + unit] = h;
             }
             f32x4 q4;
             q4[0] = __shfl(h, (lane & ~3) + 0); q4[1] = __shfl(h, (lane & ~3) + 1);

@@ -59,9 +59,9 @@ __host__ __device__ inline int bwd_lds_floats(int MB, int T, int CH) {
 // is source row n(g, c) = base[s] + per_g[s] * g + (c - c0[s]) of the segment s that holds c.  Output [g][kb][kg][c][j] with
 // k = 16 kb + 4 kg + j: one k-block is 4 * NC float4, the B operand of lane (kg, c) of v_mfma_f32_16x16x4_f32.
 struct TileMap { int nseg, NC, c0[3], base[3], per_g[3]; };
-__global__ __launch_bounds__(256) void pack_bwd_tiles_kernel(const float* __restrict__ src, int Kc, TileMap mp, float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_bwd_tiles_kernel(const float* __restrict__ src, int Kc, int nwg, TileMap mp, float* __restrict__ dst) {
     const int KB = Kc / 16;
-    const long long n4 = (long long)NWG * KB * 4 * mp.NC;
+    const long long n4 = (long long)nwg * KB * 4 * mp.NC;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % mp.NC);
         const int kg = (int)((i / mp.NC) & 3);
@@ -633,6 +633,127 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         float s = dva_acc;
         s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
         if (kg == 0) a.pva_part[(size_t)wg * UA + wave * 16 + c16] = isAtt ? s : 0.f;
+    }
+    if (!alive && tid == 0) atomicOr(reinterpret_cast<unsigned*>(a.err), 1u);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Backward of EncoderV2's bidirectional ZoneoutLSTM (tacotron_v2.py:53-63, training branch modules.py:274-276) as ONE launch:
+// the reverse-time mirror of pz::encoder_kernel.  2 directions x 64 workgroups; workgroup g of a direction owns hidden units
+// 4g..4g+3: their state gradients stay in registers, the cell backward (with dynamic_rnn's length masking: dead steps pass the
+// state gradient through) runs where the units live, dz [rows x 1024] goes to the other 63 workgroups as a frag16 operand, and
+// the product d [x | h_prev] = dz . W^T is column-owner: this workgroup's 4 recurrent columns + 8 of the 512 input columns,
+// the 48 KB tile resident in registers for the whole sequence.  One hop per step.
+// ------------------------------------------------------------------------------------------------------------------------
+struct EBArgs {
+    const float* wT[2];                        // per direction [64][64 k-blocks][4][12][4] (pack_bwd_tiles_kernel)
+    const float *z[2], *cprev[2], *cnew[2];    // forward tape per direction, step order: [T][B][1024], [T][B][256] x 2
+    const float* dmem;                         // [B][T][512] d loss / d memory
+    const int* lens;
+    float* dzp[2];                             // [T][B][1024] gate gradients (weight-gradient GEMMs after the launch)
+    float* dX[2];                              // [T][B][768]: the 512 input columns are written
+    float* xs; unsigned xs_bytes;              // [2 directions][2 slots] dz operands, frag16 MB x 1024 (zeroed)
+    unsigned* bar; int* err;                   // [2][NSHARD][32] hop counters (zeroed), error word
+    int B, T, stream;
+    unsigned seed;
+    float zc, zh, fb;
+};
+constexpr int NCE = 12;
+
+template <int MB>
+__global__ __launch_bounds__(NT) void encoder_bwd_kernel(EBArgs a) {
+    __shared__ f32x4 red[NWAVE * MB * 64];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.x / ENC_G, g = blockIdx.x - dir * ENC_G;
+    const int B = a.B, T = a.T;
+    const unsigned l16 = (unsigned)lane * 16u;
+    const int kg = lane >> 4, c16 = lane & 15;
+    if (tid == 0) s_abort = 0;
+    const rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wT[dir]), 0, ENC_G * 64 * 64 * NCE, 0x00020000);
+    const rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(a.xs, 0, (int)a.xs_bytes, 0x00020000);
+    unsigned* bar = a.bar + dir * NSHARD * 32;
+    f32x4 b[8];                                 // this wave's 8 k-blocks of the tile, resident
+    wloadc<8>(b, rW, (unsigned)((g * 64 + wave * 8) * 64 * NCE), (unsigned)((kg * NCE + min(c16, NCE - 1)) * 16), 64u * NCE);
+    const int erow = tid >> 2, euu = tid & 3;
+    const bool eown = tid < MB * 64 && erow < B;
+    const int len = eown ? min(a.lens[erow], T) : 0;
+    const int unit = g * 4 + euu;
+    const unsigned dzslot = (unsigned)(MB * 16 * 1024 * 4), ddir = (unsigned)dir * 2u * dzslot;
+    float gc = 0.f, ghp = 0.f;
+    struct Row { float zi, zj, zf, zo, cp, cn, go; };
+    auto tape_load = [&](int s) -> Row {
+        Row r{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (eown && s >= 0 && s < len) {
+            const size_t ti = (size_t)s * B + erow;
+            const float* tz = a.z[dir] + ti * 1024;
+            r.zi = tz[unit]; r.zj = tz[256 + unit]; r.zf = tz[512 + unit]; r.zo = tz[768 + unit];
+            r.cp = a.cprev[dir][ti * 256 + unit]; r.cn = a.cnew[dir][ti * 256 + unit];
+            const int pos = dir ? (len - 1 - s) : s;
+            r.go = a.dmem[((size_t)erow * T + pos) * 512 + dir * 256 + unit];
+        }
+        return r;
+    };
+    // ZoneoutLSTMCell backward of step s for this thread's (row, unit); dhp: d h_prev of step s + 1 from this workgroup's columns
+    auto cell = [&](int s, const Row& r, float dhp) {
+        float dz4[4] = {0.f, 0.f, 0.f, 0.f};
+        const float g_hs = ghp + dhp;
+        if (eown && s < len) {
+            const unsigned stream = (unsigned)(a.stream + 2 * dir);
+            const float gi = sigmoidf_(r.zi), gj = tanhf(r.zj), gf = sigmoidf_(r.zf + a.fb), go = sigmoidf_(r.zo);
+            const float mc = t2_u01(a.seed, stream, (unsigned)s, (unsigned)erow, (unsigned)unit) >= a.zc ? 1.f : 0.f;
+            const float mh = t2_u01(a.seed, stream + 1u, (unsigned)s, (unsigned)erow, (unsigned)unit) >= a.zh ? 1.f : 0.f;
+            const float tc = tanhf(r.cn);
+            const float dhn = r.go + mh * g_hs;
+            const float dcn = mc * gc + dhn * go * (1.f - tc * tc);
+            gc = (1.f - mc) * gc + dcn * gf;
+            ghp = (1.f - mh) * g_hs;
+            dz4[0] = dcn * gj * gi * (1.f - gi); dz4[1] = dcn * gi * (1.f - gj * gj); dz4[2] = dcn * r.cp * gf * (1.f - gf); dz4[3] = dhn * tc * go * (1.f - go);
+        } else {
+            ghp = g_hs;                         // dead step (dynamic_rnn copied the state through): the state gradient passes
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (eown) a.dzp[dir][((size_t)s * B + erow) * 1024 + q * 256 + unit] = dz4[q];
+            f32x4 v;
+            v[0] = __shfl(dz4[q], (lane & ~3) + 0); v[1] = __shfl(dz4[q], (lane & ~3) + 1);
+            v[2] = __shfl(dz4[q], (lane & ~3) + 2); v[3] = __shfl(dz4[q], (lane & ~3) + 3);
+            if (eown && euu == 0) st16(xs, ddir + (unsigned)(s & 1) * dzslot + frag_off16(erow, q * ENC_G + g, MB), v);
+        }
+    };
+    __syncthreads();
+    unsigned epoch = 0;
+    bool alive = true;
+    if (tid < MB * 64) cell(T - 1, tape_load(T - 1), 0.f);
+    hop_arrive(bar); ++epoch;
+    for (int s = T - 1; s >= 0; --s) {
+        Row r{};
+        if (tid < MB * 64) r = tape_load(s - 1);            // in flight across the hop
+        if (!hop_wait(bar, (unsigned)(ENC_G / NSHARD) * epoch, &s_abort)) { alive = false; break; }
+        f32x4 acc[MB];
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        seg_mma<MB, 8>(acc, b, xs, ddir + (unsigned)(s & 1) * dzslot + (unsigned)(wave * 8 * MB * 1024), l16);
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
+        __syncthreads();
+        if (tid < MB * 64) {
+            const int rb = erow >> 4, rr = erow & 15;
+            const int reg = rr & 3, lbase = (rr >> 2) * 16;
+            float dhp = 0.f, dx0 = 0.f, dx1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) {
+                const f32x4* rw = red + (w * MB + rb) * 64 + lbase;
+                dhp += rw[euu][reg]; dx0 += rw[4 + 2 * euu][reg]; dx1 += rw[5 + 2 * euu][reg];
+            }
+            if (eown) {
+                float* dx = a.dX[dir] + ((size_t)s * B + erow) * 768 + g * 8 + 2 * euu;
+                dx[0] = dx0; dx[1] = dx1;
+            }
+            if (s > 0) cell(s - 1, r, dhp);
+        }
+        if (s > 0) { hop_arrive(bar); ++epoch; }
     }
     if (!alive && tid == 0) atomicOr(reinterpret_cast<unsigned*>(a.err), 1u);
 }

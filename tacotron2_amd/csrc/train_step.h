@@ -708,7 +708,7 @@ static int pzb_pack(t2_trainer* tr, int which, const float* w_dev) {
     const int Kc = which == 3 ? pz::UA : pz::KBZ * 16;
     const long long n4 = (long long)pzb_tile_bytes(which) / 16;
     hipLaunchKernelGGL(pz::pack_bwd_tiles_kernel, dim3((unsigned)std::min<long long>(4096, (n4 + 255) / 256)), dim3(256), 0, tr->m->ctx->stream,
-                       w_dev, Kc, mp, tr->pzb_w[which]);
+                       w_dev, Kc, pz::NWG, mp, tr->pzb_w[which]);
     HIP_TRY(hipGetLastError());
     return T2_OK;
 }
@@ -1553,6 +1553,11 @@ struct EncTape {
     float *xs = nullptr, *gout = nullptr, *dzp = nullptr, *dzf = nullptr, *dX = nullptr, *g_c = nullptr, *g_hp = nullptr;
     float *dxa = nullptr, *dxb = nullptr, *dgamma = nullptr, *dbeta = nullptr;
     bool have_forward = false, have_bwd = false;
+    // persistent forward / backward recurrences (persist.h encoder_kernel<., true>, persist_bwd.h encoder_bwd_kernel)
+    unsigned* pz_bar = nullptr;       // forward: [2][NSHARD][32] counters + error word (in the tape slab)
+    float* pze_w[2] = {};             // backward: column-owner tiles of the transposed kernels
+    char* pze_slab = nullptr; size_t pze_slab_bytes = 0; unsigned pze_xs_bytes = 0; unsigned* pze_bar = nullptr;
+    float *dzp2 = nullptr, *dX2 = nullptr;
 };
 
 static std::map<t2_trainer*, EncTape*> g_enc_tapes;      // trainer -> encoder tape (kept outside t2_trainer's layout)
@@ -1594,6 +1599,7 @@ static int enc_tape_alloc(t2_trainer* tr, EncTape* et) {
     const size_t per_step = (size_t)MB * 16 * KPc;
     const size_t o_xf = carve(2 * (size_t)T * per_step * 4), o_h = carve(2 * 2 * (size_t)MB * 16 * KPh * 4), o_c = carve(2 * (size_t)MB * 16 * He * 4);
     const size_t o_ctl = carve(64);
+    const size_t o_pzbar = carve((size_t)(2 * pz::NSHARD * 32 + 64) * 4);
     et->bytes = off;
     HIP_TRY(hipMalloc(&et->slab, off));
     char* p = (char*)et->slab;
@@ -1609,6 +1615,7 @@ static int enc_tape_alloc(t2_trainer* tr, EncTape* et) {
         et->hstate[dir] = (float*)(p + o_hs[dir]);
     }
     et->xf = (float*)(p + o_xf); et->hfrag = (float*)(p + o_h); et->cst = (float*)(p + o_c); et->ctl = (int*)(p + o_ctl);
+    et->pz_bar = (unsigned*)(p + o_pzbar);
     return T2_OK;
 }
 
@@ -1672,6 +1679,35 @@ static int train_encoder_forward_impl(t2_trainer* tr, const int64_t* ids, const 
     HIP_TRY(hipMemcpyAsync(et->ctl, h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int hsz = MB * 16 * KPh;
+    // the whole recurrence as ONE launch (persist.h encoder_kernel, training instantiation) at the paper-size class
+    const bool enc_persist = m->opt_enc_persist && Cx == 512 && He == 256 && KPh == 256 && m->n_cu >= 2 * pz::ENC_G &&
+                             m->enc_lstm[0].n_wg == pz::ENC_G && m->enc_lstm[0].kbtot == 48 && 2LL * T * (long long)per_step * 4 < 0x7fffffffLL;
+    if (enc_persist) {
+        HIP_TRY(hipMemsetAsync(et->pz_bar, 0, (size_t)(2 * pz::NSHARD * 32 + 64) * 4, st));
+        pz::EArgs a{};
+        for (int dir = 0; dir < 2; ++dir) {
+            a.w[dir] = m->enc_lstm[dir].w; a.bias[dir] = m->enc_lstm[dir].bias;
+            a.tz[dir] = et->z[dir]; a.tcprev[dir] = et->cprev[dir]; a.tcnew[dir] = et->cnew[dir]; a.thstate[dir] = et->hstate[dir];
+        }
+        a.xf = et->xf; a.xf_step = (unsigned)(per_step * 4); a.xf_bytes = (unsigned)(2LL * T * per_step * 4);
+        a.hx = et->hfrag; a.hx_bytes = (unsigned)(2 * 2 * (size_t)hsz * 4);
+        a.bar = et->pz_bar; a.err = (int*)(et->pz_bar + 2 * pz::NSHARD * 32);
+        a.lens = et->lens; a.out = memory_out; a.B = B; a.T = T;
+        a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
+        a.seed = seed; a.stream = T2_STREAM_ZONE_ENC;
+        const dim3 grid(2 * pz::ENC_G), blk(pz::NT);
+        if (MB == 1) hipLaunchKernelGGL((pz::encoder_kernel<1, true>), grid, blk, 0, st, a);
+        else if (MB == 2) hipLaunchKernelGGL((pz::encoder_kernel<2, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((pz::encoder_kernel<4, true>), grid, blk, 0, st, a);
+        HIP_TRY(hipGetLastError());
+        int h_err = 0;
+        HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_err) return fail(T2_EHIP, "persistent encoder (training): a hand-off wait ran out of time; outputs are invalid");
+        ++m->n_enc_persist;
+        et->have_forward = ids != nullptr;
+        return T2_OK;
+    }
     for (int s = 0; s < T; ++s)
         for (int dir = 0; dir < 2; ++dir) {
             SkinnyCore c{};
@@ -1755,6 +1791,55 @@ extern "C" int t2_train_postnet_forward(t2_model* m, const float* mel, int B, in
     return T2_OK;
 }
 
+
+// column-owner tiles of an encoder direction's transposed kernel (persist_bwd.h encoder_bwd_kernel): workgroup g's columns are
+// d h_prev of its units 4g..4g+3 and the input columns 8g..8g+7; source: the TF kernel [Cx + He][4 He] on the device
+static int pze_pack(t2_trainer* tr, EncTape* et, int dir, const float* w_dev) {
+    if (!et->pze_w[dir]) return T2_OK;
+    pz::TileMap mp{};
+    mp.nseg = 2; mp.NC = pz::NCE;
+    mp.c0[0] = 0; mp.base[0] = 512; mp.per_g[0] = 4;
+    mp.c0[1] = 4; mp.base[1] = 0; mp.per_g[1] = 8;
+    const long long n4 = (long long)pz::ENC_G * 64 * 4 * pz::NCE;
+    hipLaunchKernelGGL(pz::pack_bwd_tiles_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, tr->m->ctx->stream, w_dev, 1024, pz::ENC_G, mp, et->pze_w[dir]);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+static int pze_setup(t2_trainer* tr, EncTape* et) {
+    t2_model* m = tr->m;
+    const t2_dims& d = m->d;
+    const int B = tr->B, T = tr->T, MB = mb_for(B), E = d.enc_units, He = E / 2, L = d.enc_conv_layers;
+    const int Cx = L > 0 ? E : d.embedding_dim;
+    if (Cx != 512 || He != 256 || m->n_cu < 2 * pz::ENC_G) return T2_OK;
+    hipStream_t st = m->ctx->stream;
+    const char* dirs[2] = {"fw", "bw"};
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, (size_t)768 * 1024 * 4));
+    for (int dir = 0; dir < 2; ++dir) {
+        const HostWeight* w;
+        int rc = get_w(m, std::string("encoder/bidirectional_rnn/") + dirs[dir] + "/lstm_cell/kernel", &w, {768, 1024});
+        hipError_t e = rc == T2_OK ? hipMalloc((void**)&et->pze_w[dir], (size_t)pz::ENC_G * 64 * 64 * pz::NCE) : hipErrorUnknown;
+        if (e == hipSuccess) { tr->allocs.push_back(et->pze_w[dir]); e = hipMemcpyAsync(tmp, w->data.data(), (size_t)768 * 1024 * 4, hipMemcpyHostToDevice, st); }
+        if (e == hipSuccess) rc = pze_pack(tr, et, dir, tmp);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (rc != T2_OK || e != hipSuccess) { (void)hipFree(tmp); return rc != T2_OK ? rc : fail(T2_EHIP, "persistent encoder backward operands: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(hipFree(tmp));
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    et->pze_xs_bytes = (unsigned)carve(2 * 2 * (size_t)MB * 16 * 1024 * 4);
+    et->pze_xs_bytes = (unsigned)off;
+    const size_t o_bar = carve((size_t)(2 * pz::NSHARD * 32 + 64) * 4);
+    et->pze_slab_bytes = off;
+    const size_t o_dz2 = carve((size_t)T * B * 1024 * 4), o_dx2 = carve((size_t)T * B * 768 * 4);
+    HIP_TRY(hipMalloc((void**)&et->pze_slab, off));
+    tr->allocs.push_back(et->pze_slab);
+    HIP_TRY(hipMemset(et->pze_slab, 0, off));
+    et->pze_bar = (unsigned*)(et->pze_slab + o_bar);
+    et->dzp2 = (float*)(et->pze_slab + o_dz2); et->dX2 = (float*)(et->pze_slab + o_dx2);
+    return T2_OK;
+}
+
 static int enc_setup_backward(t2_trainer* tr, EncTape* et) {
     t2_model* m = tr->m;
     const t2_dims& d = m->d;
@@ -1796,6 +1881,7 @@ static int enc_setup_backward(t2_trainer* tr, EncTape* et) {
     et->xs = (float*)(p + o_xs); et->gout = (float*)(p + o_go); et->dzp = (float*)(p + o_dzp); et->dzf = (float*)(p + o_dzf);
     et->dX = (float*)(p + o_dX); et->g_c = (float*)(p + o_gc); et->g_hp = (float*)(p + o_ghp);
     et->dxa = (float*)(p + o_a); et->dxb = (float*)(p + o_b); et->dgamma = (float*)(p + o_dg); et->dbeta = (float*)(p + o_db);
+    T2_TRY(pze_setup(tr, et));
     et->have_bwd = true;
     return T2_OK;
 }
@@ -1819,9 +1905,35 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
     float* g = nullptr;
     HIP_TRY(hipMemsetAsync(et->dxa, 0, (size_t)Mtot * Cx * 4, st));
     const char* dirs[2] = {"fw", "bw"};
+    // both directions' reverse-time recurrences as ONE persistent launch at the paper-size class (persist_bwd.h), else one launch per step
+    const bool pze = m->opt_bwd_persist && et->pze_slab != nullptr;
+    if (pze) {
+        HIP_TRY(hipMemsetAsync(et->pze_slab, 0, et->pze_slab_bytes, st));
+        pz::EBArgs a{};
+        for (int dir = 0; dir < 2; ++dir) { a.wT[dir] = et->pze_w[dir]; a.z[dir] = et->z[dir]; a.cprev[dir] = et->cprev[dir]; a.cnew[dir] = et->cnew[dir]; }
+        a.dmem = dmemory; a.lens = et->lens;
+        a.dzp[0] = et->dzp; a.dzp[1] = et->dzp2; a.dX[0] = et->dX; a.dX[1] = et->dX2;
+        a.xs = (float*)et->pze_slab; a.xs_bytes = et->pze_xs_bytes;
+        a.bar = et->pze_bar; a.err = (int*)(et->pze_bar + 2 * pz::NSHARD * 32);
+        a.B = B; a.T = T; a.stream = T2_STREAM_ZONE_ENC; a.seed = et->seed;
+        a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
+        const dim3 grid(2 * pz::ENC_G), blk(pz::NT);
+        if (MB == 1) hipLaunchKernelGGL((pz::encoder_bwd_kernel<1>), grid, blk, 0, st, a);
+        else if (MB == 2) hipLaunchKernelGGL((pz::encoder_bwd_kernel<2>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((pz::encoder_bwd_kernel<4>), grid, blk, 0, st, a);
+        HIP_TRY(hipGetLastError());
+        ++m->n_bwd_persist;
+        int h_err = 0;
+        HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_err) return fail(T2_EHIP, "persistent encoder backward: a hand-off wait ran out of time");
+    }
     for (int dir = 0; dir < 2; ++dir) {
         hipLaunchKernelGGL(seq_gather_kernel, grid1((long long)T * B * Cx), dim3(256), 0, st, et->x[L], et->lens, et->xs, B, T, Cx, dir);
+        float* const dzp = (pze && dir == 1) ? et->dzp2 : et->dzp;
+        float* const dXd = (pze && dir == 1) ? et->dX2 : et->dX;
         const size_t fsz = (size_t)R * pad16(4 * He);
+        if (!pze) {
         HIP_TRY(hipMemsetAsync(et->dzf, 0, 2 * fsz * 4, st));
         hipLaunchKernelGGL(enc_gout_kernel, grid1((long long)T * B * He), dim3(256), 0, st, dmemory, et->lens, et->gout, B, T, E, He, dir * He, dir);
         auto lstm_args = [&](int s) {
@@ -1841,15 +1953,16 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
             if (s > 0) { e.mode = 3; e.col0 = Cx; e.lb = lstm_args(s - 1); }
             bwd_dense_epi(tr, et->lstmT[dir], et->dzf + (size_t)(s & 1) * fsz, e);
         }
-        hipLaunchKernelGGL(enc_dx_scatter_kernel, grid1((long long)T * B * Cx), dim3(256), 0, st, et->dX, Cx + He, et->lens, et->dxa, B, T, Cx, dir);
+        }
+        hipLaunchKernelGGL(enc_dx_scatter_kernel, grid1((long long)T * B * Cx), dim3(256), 0, st, dXd, Cx + He, et->lens, et->dxa, B, T, Cx, dir);
         const std::string pn = std::string("encoder/bidirectional_rnn/") + dirs[dir] + "/lstm_cell";
         const int n4 = 4 * He;
         T2_TRY(grad_dst(tr, flat_grads, pn + "/kernel", &g));
-        T2_TRY(bwd_wgrad(tr, et->xs, Cx, Cx, et->dzp, n4, n4, (long long)T * B, g, n4));
-        if (T > 1) T2_TRY(bwd_wgrad(tr, et->hstate[dir], He, He, et->dzp + (size_t)B * n4, n4, n4, (long long)(T - 1) * B, g + (size_t)Cx * n4, n4));
+        T2_TRY(bwd_wgrad(tr, et->xs, Cx, Cx, dzp, n4, n4, (long long)T * B, g, n4));
+        if (T > 1) T2_TRY(bwd_wgrad(tr, et->hstate[dir], He, He, dzp + (size_t)B * n4, n4, n4, (long long)(T - 1) * B, g + (size_t)Cx * n4, n4));
         else HIP_TRY(hipMemsetAsync(g + (size_t)Cx * n4, 0, (size_t)He * n4 * 4, st));
         T2_TRY(grad_dst(tr, flat_grads, pn + "/bias", &g));
-        T2_TRY(col_sum(tr, et->dzp, (long long)T * B, n4, g));
+        T2_TRY(col_sum(tr, dzp, (long long)T * B, n4, g));
     }
     // conv stack: dropout / relu / batch-statistics batch norm / convolution, last layer first
     float* d_out = et->dxa;
@@ -2062,6 +2175,7 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
             hipLaunchKernelGGL(lstm_bias_pack_kernel, grid1(m->enc_lstm[dir].n_wg * 16), dim3(256), 0, st, m->enc_lstm[dir].bias, b, m->enc_lstm[dir].n_wg, He);
         }
         if (trainer_part) repack(st, et->lstmT[dir], w, 1, 4 * He, cin + He);
+        if (trainer_part) T2_TRY(pze_pack(tr, et, dir, w));
     }
     T2_TRY(flat_src(tr, flat, "attention/memory_layer/kernel", &w));
     if (model_part) T2_TRY(copy(m->memory_layer.w, w, (size_t)E * U));

@@ -227,3 +227,61 @@ def test_persistent_encoder_bilstm_against_oracle_and_launch_schedule(B):
             assert not got[b, n:].any()
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,S", [(1, 9, 3), (20, 77, 7), (64, 140, 5)])
+def test_persistent_backward_matches_launch_per_phase(B, T, S):
+    """The training backward's reverse-time recurrences as persistent launches (csrc/persist_bwd.h: decoder cell stack +
+    attention, and the encoder BiLSTM; option bwd_persist) and the encoder's training forward on pz::encoder_kernel
+    (option enc_persist) against the launch-per-phase schedule on the same inputs and masks: every gradient and d memory
+    to 2e-4 of its scale (the launch-per-phase backward is checked against the fp64 autograd oracle in test_gpu_train.py /
+    test_gpu_fullsize.py; at B = 32 the persistent one is too, there)."""
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    d = PROFILE_P
+    w = init_weights(d, seed=5, perturb=True)
+    rng = np.random.default_rng(B * 1000 + T + S)
+    r = d.outputs_per_step
+    lens = rng.integers(max(1, T // 2), T + 1, B).astype(np.int64)
+    lens[0] = T
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    tl = rng.integers(max(1, S * r // 2), S * r + 1, B)
+    tl[0] = S * r
+    sl = (tl + r - 1) // r
+    mel = rng.uniform(0, 1, (B, S * r, d.num_mels)).astype(np.float32)
+    done = (np.arange(S)[None, :] >= (sl[:, None] - 1)).astype(np.float32)
+    smask = (np.arange(S * r)[None, :] < tl[:, None]).astype(np.float32)
+    bmask = (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)
+    eng = Engine(d, w)
+    tr = TR.Trainer(eng, B, T, S)
+    try:
+        spec = TR.flatten_spec(w)
+        tr.bind_gradients(spec)
+        out = {}
+        for opt in (0, 1):
+            eng.set_option("bwd_persist", opt)
+            eng.set_option("enc_persist", opt)
+            n_b, n_e = eng.get_stat("bwd_persist_launches"), eng.get_stat("enc_persist_launches")
+            memory, _ = tr.encoder_forward(ids, lens, drop_rate=0.5, seed=3)
+            tr.decoder_forward(memory, lens, mel, prenet_drop_rate=0.5, seed=3)
+            flat = torch.zeros(TR.flat_size(spec), dtype=torch.float32, device="cuda")
+            dmem, losses = tr.decoder_backward(done, smask, bmask, flat)
+            tr.encoder_backward(dmem, flat)
+            assert eng.get_stat("bwd_persist_launches") == n_b + 2 * opt          # decoder + encoder recurrences
+            assert eng.get_stat("enc_persist_launches") == n_e + opt
+            out[opt] = (TR.unflatten(flat, spec), _np(dmem), _np(memory), float(losses[2]))
+        g0, m0, mem0, l0 = out[0]
+        g1, m1, mem1, l1 = out[1]
+        np.testing.assert_allclose(mem1, mem0, atol=1e-5)
+        assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
+        np.testing.assert_allclose(m1, m0, atol=2e-4 * float(np.abs(m0).max()) + 1e-12)
+        for name in sorted(g0):
+            if "moving_" in name:
+                continue
+            scale = float(np.abs(g0[name]).max())
+            assert float(np.abs(g1[name] - g0[name]).max()) <= 2e-4 * scale + 1e-12, name
+    finally:
+        tr.close()
+        eng.close()

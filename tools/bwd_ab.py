@@ -20,6 +20,7 @@ def run(B, T, S, reps=3):
     lens = rng.integers(max(1, T // 2), T + 1, B).astype(np.int64)
     lens[0] = T
     memory = rng.uniform(-1, 1, (B, T, d.enc_units)).astype(np.float32)
+    ids = rng.integers(0, d.num_symbols, (B, T))
     tl = rng.integers(max(1, S * r // 2), S * r + 1, B)
     tl[0] = S * r
     sl = (tl + r - 1) // r
@@ -34,24 +35,46 @@ def run(B, T, S, reps=3):
     out = {}
     for opt in (0, 1):
         eng.set_option("bwd_persist", opt)
+        eng.set_option("enc_persist", opt)
+        if ENC:
+            memory, _ = tr.encoder_forward(ids, lens, drop_rate=0.5, seed=3)
         tr.decoder_forward(memory, lens, labels["mel"], prenet_drop_rate=0.5, seed=3)
         flat = torch.zeros(TR.flat_size(spec), dtype=torch.float32, device="cuda")
         n0 = eng.get_stat("bwd_persist_launches")
         dmem, losses = tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat)
         torch.cuda.synchronize()
         assert eng.get_stat("bwd_persist_launches") == n0 + opt, "persistent backward did not run"
+        te = 0.0
+        if ENC:
+            tr.encoder_backward(dmem, flat)
+            torch.cuda.synchronize()
+            assert eng.get_stat("bwd_persist_launches") == n0 + 2 * opt, "persistent encoder backward did not run"
+            grads_now = TR.unflatten(flat, spec)
+            tes = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                tr.encoder_forward(ids, lens, drop_rate=0.5, seed=3)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                tr.encoder_backward(dmem, flat)
+                torch.cuda.synchronize()
+                tes.append(((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
+            te = min(x[0] for x in tes), min(x[1] for x in tes)
+            print(f"    option {opt}: encoder forward {te[0]:.2f} ms, encoder backward {te[1]:.2f} ms")
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
             tr.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat)
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
-        out[opt] = (TR.unflatten(flat, spec), dmem.cpu().numpy(), min(ts))
+        out[opt] = (grads_now if ENC else TR.unflatten(flat, spec), dmem.cpu().numpy(), min(ts))
     g0, m0, t0 = out[0]
     g1, m1, t1 = out[1]
     worst = []
     for name in sorted(g0):
-        if not (name.startswith("decoder") or name.startswith("attention")):
+        if not ENC and not (name.startswith("decoder") or name.startswith("attention")):
+            continue
+        if "moving_" in name:
             continue
         scale = float(np.abs(g0[name]).max())
         err = float(np.abs(g1[name] - g0[name]).max())
@@ -67,7 +90,11 @@ def run(B, T, S, reps=3):
     return not bad
 
 
+ENC = False
 if __name__ == "__main__":
+    if sys.argv[1] == "enc":
+        ENC = True
+        del sys.argv[1]
     a = [int(x) for x in sys.argv[1:]]
     ok = True
     for i in range(0, len(a), 3):
