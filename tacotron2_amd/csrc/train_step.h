@@ -228,10 +228,20 @@ __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __res
 }
 
 // sum over the batch of per-row partial gradients part[b][n] -> out[n]
+// (the rows are added in increasing order; eight loads are in flight per round: a serial chain of dependent loads made the
+// tall, narrow sums -- 2048 partials of 128 columns -- take 0.4 ms each)
 __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ part, int B, long long n, float* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += part[(size_t)b * n + i];
+        int b = 0;
+        for (; b + 8 <= B; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(b + k) * n + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; b < B; ++b) s += part[(size_t)b * n + i];
         out[i] = s;
     }
 }
@@ -1514,7 +1524,21 @@ __global__ __launch_bounds__(256) void embedding_grad_kernel(const int* __restri
     __syncthreads();
     auto flush = [&]() {
         const int n = s_n;
-        for (int i = 0; i < n; ++i) {
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {                 // four rows in flight, added in list order
+            float v[4][CMAX];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* row = dx + (size_t)s_list[i + j] * C;
+#pragma unroll
+                for (int k = 0; k < CMAX; ++k) { const int c = tid + k * 256; v[j][k] = c < C ? row[c] : 0.f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < CMAX; ++k) acc[k] += v[j][k];
+        }
+        for (; i < n; ++i) {
             const float* row = dx + (size_t)s_list[i] * C;
 #pragma unroll
             for (int k = 0; k < CMAX; ++k) { const int c = tid + k * 256; if (c < C) acc[k] += row[c]; }
@@ -1994,6 +2018,10 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
         // data gradient: correlation of dy with the flipped, transposed kernel
         {
             const ConvLayer& Lc = et->convT[i];
+            if (k % 2 == 1) {                 // symmetric padding: the MFMA convolution of the forward pass serves (launch_conv)
+                T2_TRY(launch_conv(m, Lc, other, E, d_out, cin, Mtot, T, 0, nullptr, 0));
+                continue;
+            }
             ConvArgs a{};
             a.x = other; a.ldx = E; a.w = Lc.w; a.y = d_out; a.ldy = cin;
             a.Mtot = Mtot; a.T = T; a.Cin = E; a.N = cin; a.ktaps = k; a.pad_l = k - 1 - pad_l; a.act = 0;
