@@ -6,9 +6,12 @@
 // 4g..4g+3 of the three LSTM cells: the gradients of their cell / hidden states are carried in registers across steps, the
 // ZoneoutLSTMCell backward (modules.py:261-283, sampled masks from the counter-based generator) runs where the units live, and
 // the gate gradients dz [rows x 4H] are published to the exchange slab as frag16 operands.  The data-gradient products
-// d x = dz . W^T (K = 4H = 4096) are column-owner GEMMs: workgroup g multiplies the whole dz by ITS columns of W^T only --
-// exactly the columns whose result it consumes itself (its units' d h, its two context columns, its PreNet column), packed
-// densely by pack_bwd_tiles_kernel -- so a product's result never crosses workgroups.  A step is four all-to-all hops:
+// d x = dz . W^T (K = 4H = 4096) are 2-D decomposed: only the columns somebody consumes are computed (a workgroup's units' d h,
+// its two context columns, its PreNet column: 7..10 columns per owner, packed densely by pack_bwd_tiles2d_kernel); four
+// consecutive owners form a group, and workgroup (group, ks) multiplies K slice ks (1024 of the 4096 rows of W^T) by the
+// group's 28..40 columns -- a quarter of dz instead of all of it through every CU, and full MFMA tiles instead of one half-empty
+// tile.  The partial tiles go to the slab; every consumer of a product sits behind a later hop anyway and adds the four
+// partials when it loads them (cells: their own columns; attention: d ctx).  A step is four all-to-all hops:
 //   GEMM 2 (dz2 -> d y1 | d h2_prev) -> LSTM 2 backward of step t-1, LSTM 1 backward of step t  -> hop A ->
 //   GEMM 1 (dz1 -> d h_att | d ctx | d h1_prev), d ctx published                                 -> hop B ->
 //   attention backward (row split over C workgroups by encoder position, partial d q / d state)  -> hop C ->
@@ -20,6 +23,7 @@
 // plain tape buffers as the launch-per-phase backward writes, so the code after the loop is shared.
 #pragma once
 #include "persist.h"
+#include <type_traits>
 
 namespace pz {
 
@@ -38,7 +42,8 @@ struct BArgs {
     float *dq, *de_all, *dctx_all, *du_all, *f_all, *df_all, *dpre, *pva_part;
     long long dctx_row_ld;                     // floats between batch rows of dctx_all (S * 512)
     float* xs; unsigned xs_bytes;
-    unsigned oDZ2, oDZ1, oDZ0, oDCTX, oDQ, oDS; // byte offsets into xs; DZ2 and DS hold two step parities
+    unsigned oDZ2, oDZ1, oDZ0, oDCTX, oDQ, oDS; // byte offsets into xs; DZ2 and DS hold two step parities (oDCTX: unused)
+    unsigned oP2, oP1, oP0;                     // partial product tiles [256 workgroups][rows][4 NC]
     unsigned dz_bytes, dq_bytes;               // bytes of one dz operand / one d q partial operand
     unsigned* bar; int* err;
     int B, T, S, C, CH, F, KA, cumulative;
@@ -52,7 +57,7 @@ constexpr int DUS = 132;                                // LDS row stride of the
 
 __host__ __device__ inline int bwd_lds_floats(int MB, int T, int CH) {
     const int CHP = (CH + 15) & ~15, TP = (T + 3) & ~3;
-    return NWAVE * MB * 64 * 4 + 512 + 2 * TP + (CHP + 48) + 2 * CHP * 36 + CHP * DUS + 32 * 32 + 32 + 2 * UA + 2 * CHP + 32 + 16;
+    return NWAVE * 3 * MB * 64 * 4 + 512 + 2 * TP + (CHP + 48) + 2 * CHP * 36 + CHP * DUS + 32 * 33 + 32 + 2 * UA + 2 * CHP + 32 + 16;
 }
 
 // Source: plain [N][Kc] row-major (a TF kernel [inputs][outputs]: d x[n] = sum_k dz[k] W[n][k]).  Tile of workgroup g: column c
@@ -96,6 +101,64 @@ __device__ __forceinline__ void gemm_dz(f32x4 (&acc)[MB], rsrc_t rW, unsigned ws
     seg_mma<MB, 8>(acc, b1, xs, xoff + (unsigned)(24 * MB * 1024), l16);
 }
 
+
+// 2-D tiles: workgroup w = 4 group + ks holds k-blocks [64 ks, 64 ks + 64) x the 4 NC columns of owners 4 group .. 4 group + 3
+// (column cc = owner_local * NC + c).  Output [w][kb_local][kg][cc][j], k = 16 (64 ks + kb_local) + 4 kg + j.
+__global__ __launch_bounds__(256) void pack_bwd_tiles2d_kernel(const float* __restrict__ src, int Kc, TileMap mp, float* __restrict__ dst) {
+    const int NC4 = 4 * mp.NC;
+    const long long n4 = (long long)NWG * 64 * 4 * NC4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % NC4);
+        const int kg = (int)((i / NC4) & 3);
+        const int kbl = (int)((i / (4 * NC4)) & 63);
+        const int w = (int)(i / ((long long)4 * NC4 * 64));
+        const int g = (w & ~3) + cc / mp.NC, c = cc % mp.NC, ks = w & 3;
+        int s = 0;
+        for (int q = 1; q < mp.nseg; ++q) if (c >= mp.c0[q]) s = q;
+        const int n = mp.base[s] + mp.per_g[s] * g + (c - mp.c0[s]);
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)n * Kc + (64 * ks + kbl) * 16 + kg * 4);
+        reinterpret_cast<float4*>(dst)[i] = v;
+    }
+}
+
+// acc[ct][rb] += dz[rows, NKB k-blocks at xoff] . tile columns 16 ct ..: software-pipelined in pieces of two k-blocks (the
+// next piece's loads are in flight while a piece multiplies)
+template <int MB, int CT, int NKB>
+__device__ __forceinline__ void gemm2d_part(f32x4 (&acc)[CT][MB], rsrc_t rW, unsigned wsoff, unsigned kbs, const unsigned (&loff)[CT], rsrc_t xs,
+                                            unsigned xoff, unsigned l16) {
+    constexpr int STEP = MB == 4 ? 1 : 2, NP = NKB / STEP;      // 64 rows: one k-block per piece (register budget)
+    static_assert(NKB % STEP == 0, "whole pieces");
+    f32x4 av[2][STEP][MB], bv[2][STEP][CT];
+    auto load = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < STEP; ++i) {
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb) av[p & 1][i][rb] = ldx(xs, l16, xoff + (unsigned)(((p * STEP + i) * MB + rb) * 1024));
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bv[p & 1][i][ct] = ldw(rW, loff[ct], wsoff + (unsigned)(p * STEP + i) * kbs);
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    load(0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 1 < NP) load(p + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < STEP; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < MB; ++rb)
+                        acc[ct][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p & 1][i][rb][j], bv[p & 1][i][ct][j], acc[ct][rb], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+constexpr int CT2 = 2, CT1 = 3, CT0 = 2;              // MFMA column tiles of a group's 4 NC columns
+
 template <int MB>
 __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -105,16 +168,16 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     const int B = a.B, T = a.T, S = a.S, C = a.C, CH = a.CH;
     const int CHP = (CH + 15) & ~15, TP = (T + 3) & ~3, NIP = CH + 32;
     // ---- LDS carve ----
-    f32x4* red = reinterpret_cast<f32x4*>(smem);                 // [8][MB][64] float4
-    float* s_dctx = smem + NWAVE * MB * 64 * 4;                  // [512]
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                 // [8][3 column tiles][MB][64] float4
+    float* s_dctx = smem + NWAVE * 3 * MB * 64 * 4;              // [512]
     float* s_al = s_dctx + 512;                                  // [TP] alignments of the step
     float* s_gs = s_al + TP;                                     // [TP] d / d attention state after the step (carried)
     float* s_sp = s_gs + TP;                                     // [CHP + 48] attention state before the step, with the conv halo
     float* s_f = s_sp + CHP + 48;                                // [CHP][36]
     float* s_df = s_f + CHP * 36;                                // [CHP][36]
     float* s_du = s_df + CHP * 36;                               // [CHP][DUS]
-    float* s_cw = s_du + CHP * DUS;                              // [32 taps][32 filters]
-    float* s_cb = s_cw + 32 * 32;                                // [32]
+    float* s_cw = s_du + CHP * DUS;                              // [32 taps][33]: 32 filters, odd stride (conflict-free by tap and by filter)
+    float* s_cb = s_cw + 32 * 33;                                // [32]
     float* s_q = s_cb + 32;                                      // [128]
     float* s_dq = s_q + UA;                                      // [128]
     float* s_de = s_dq + UA;                                     // [CHP]
@@ -139,7 +202,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     if (tid == 0) s_flag[0] = 0;
     for (int i = tid; i < 32 * 32; i += NT) {
         const int j = i >> 5, f = i & 31;
-        s_cw[i] = (j < a.KA && f < a.F) ? a.conv_w[j * a.F + f] : 0.f;
+        s_cw[j * 33 + f] = (j < a.KA && f < a.F) ? a.conv_w[j * a.F + f] : 0.f;
     }
     if (tid < 32) s_cb[tid] = tid < a.F ? a.conv_b[tid] : 0.f;
     for (int i = tid; i < TP; i += NT) s_gs[i] = 0.f;
@@ -175,7 +238,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     // carried gradients of this thread's (row, unit): cell state, the part of d h_prev that bypasses the cell, and the parts
     // of next step's d state that this workgroup's own product columns produced
     float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, ghp0 = 0.f, ghp1 = 0.f, ghp2 = 0.f;
-    float dh2p = 0.f, dh1p = 0.f, dhAp = 0.f, dctxp = 0.f;
+    float dh2p = 0.f, dh1p = 0.f, dhAp = 0.f;
 
     auto colsum = [&](int c) -> float {
         const int rb = erow >> 4, rr = erow & 15;
@@ -241,40 +304,70 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     };
     __syncthreads();
 
-    f32x4 acc2[MB];            // GEMM 2 of the step ahead, accumulated piecewise in the hop gaps
+    // ---- 2-D products: this workgroup = (group of four owners, K slice) ----
+    const int ks = wg & 3, grp = wg >> 2, own_j = wg & 3;        // as an owner, this workgroup is member own_j of its group
+    // reduce the waves' partial tiles and publish this workgroup's [rows][4 NC] partial product
+    auto publish_tiles = [&](auto& accv, auto CTc, unsigned oP, int NC4) {
+        constexpr int CT = decltype(CTc)::value;
 #pragma unroll
-    for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // k-blocks [k0, k0 + NKB) of this wave's 32 of GEMM 2 over dz2(tt)
-    auto gemm2_part8 = [&](int tt, int k0) {
-        f32x4 b[8];
-        wloadc<8>(b, rW2, (unsigned)((wg * KBZ + wave * 32 + k0) * 64 * NC2), (unsigned)((kg * NC2 + min(c16, NC2 - 1)) * 16), 64u * NC2);
-        seg_mma<MB, 8>(acc2, b, xs, a.oDZ2 + (unsigned)(tt & 1) * a.dz_bytes + (unsigned)((wave * 32 + k0) * MB * 1024), l16);
-    };
-    auto gemm2_part4 = [&](int tt, int k0) {
-        f32x4 b[4];
-        wloadc<4>(b, rW2, (unsigned)((wg * KBZ + wave * 32 + k0) * 64 * NC2), (unsigned)((kg * NC2 + min(c16, NC2 - 1)) * 16), 64u * NC2);
-        seg_mma<MB, 4>(acc2, b, xs, a.oDZ2 + (unsigned)(tt & 1) * a.dz_bytes + (unsigned)((wave * 32 + k0) * MB * 1024), l16);
-    };
-    // GEMM 0 of step tt (d [prenet out | ctx_prev | h_att_prev] = dz_att(tt) . W0^T) and what this workgroup keeps of it
-    auto gemm0 = [&](int tt) {
-        float xpv = 0.f;
-        if (tid < MB * 64 && eown && euu == 2) xpv = a.xp_last[((size_t)tt * B + erow) * 256 + wg];
-        zero_acc();
-        gemm_dz<MB>(acc, rW0, (unsigned)((wg * KBZ + wave * 32) * 64 * NC0), 64u * NC0, (unsigned)((kg * NC0 + min(c16, NC0 - 1)) * 16), xs,
-                    a.oDZ0 + (unsigned)(wave * 32 * MB * 1024), l16);
-        put_red(acc);
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb) red[((wave * CT + ct) * MB + rb) * 64 + lane] = accv[ct][rb];
         __syncthreads();
-        fresh();
-        if (tid < MB * 64) {
-            dhAp = colsum(euu);
-            if (euu < 2) dctxp = colsum(4 + euu);
-            if (euu == 2 && eown) {
-                // PreNet backward through dropout(relu(.)) (modules.py:88-91): d pre = (y != 0) ? d y / keep : 0
-                const float v = colsum(6);
-                a.dpre[((size_t)tt * B + erow) * 256 + wg] = xpv != 0.f ? v * a.inv_keep : 0.f;
+        for (int idx = tid; idx < MB * 16 * CT * 16; idx += NT) {
+            const int row = idx / (CT * 16), cc = idx - row * (CT * 16);
+            if (cc < NC4) {
+                const int ct = cc >> 4, c = cc & 15, rb = row >> 4, rr = row & 15;
+                const int reg = rr & 3, lbase = (rr >> 2) * 16;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) sum += red[((w * CT + ct) * MB + rb) * 64 + lbase + c][reg];
+                st4(xs, oP + (unsigned)(((wg * MB * 16 + row) * NC4 + cc) * 4), sum);
             }
         }
         __syncthreads();          // the next product overwrites the reduction tiles
+    };
+    // column c of this owner's product: the sum of the group's four K-slice partials
+    auto pread = [&](unsigned oP, int NC, int c) -> float {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ld4(xs, oP + (unsigned)(((((grp * 4 + k) * MB * 16) + erow) * 4 * NC + own_j * NC + c) * 4));
+        return (v[0] + v[1]) + (v[2] + v[3]);
+    };
+    unsigned loff2[CT2], loff1[CT1], loff0[CT0];
+#pragma unroll
+    for (int ct = 0; ct < CT2; ++ct) loff2[ct] = (unsigned)((kg * 4 * NC2 + min(16 * ct + c16, 4 * NC2 - 1)) * 16);
+#pragma unroll
+    for (int ct = 0; ct < CT1; ++ct) loff1[ct] = (unsigned)((kg * 4 * NC1 + min(16 * ct + c16, 4 * NC1 - 1)) * 16);
+#pragma unroll
+    for (int ct = 0; ct < CT0; ++ct) loff0[ct] = (unsigned)((kg * 4 * NC0 + min(16 * ct + c16, 4 * NC0 - 1)) * 16);
+    f32x4 acc2[CT2][MB];       // GEMM 2 of the step ahead, accumulated piecewise in the hop gaps
+#pragma unroll
+    for (int ct = 0; ct < CT2; ++ct)
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) acc2[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // k-blocks [k0, k0 + 4) of this wave's 8 of GEMM 2's K slice over dz2(tt)
+    auto gemm2_part = [&](int tt, int k0) {
+        gemm2d_part<MB, CT2, 4>(acc2, rW2, (unsigned)((wg * 64 + wave * 8 + k0) * 256 * NC2), 256u * NC2, loff2, xs,
+                                a.oDZ2 + (unsigned)(tt & 1) * a.dz_bytes + (unsigned)((ks * 64 + wave * 8 + k0) * MB * 1024), l16);
+    };
+    auto gemm2_publish = [&]() {
+        publish_tiles(acc2, std::integral_constant<int, CT2>{}, a.oP2, 4 * NC2);
+#pragma unroll
+        for (int ct = 0; ct < CT2; ++ct)
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb) acc2[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // GEMM 0 of a step (d [prenet out | ctx_prev | h_att_prev] = dz_att . W0^T): this workgroup's partial tile
+    auto gemm0 = [&]() {
+        f32x4 acc0[CT0][MB];
+#pragma unroll
+        for (int ct = 0; ct < CT0; ++ct)
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb) acc0[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm2d_part<MB, CT0, 8>(acc0, rW0, (unsigned)((wg * 64 + wave * 8) * 256 * NC0), 256u * NC0, loff0, xs,
+                                a.oDZ0 + (unsigned)((ks * 64 + wave * 8) * MB * 1024), l16);
+        publish_tiles(acc0, std::integral_constant<int, CT0>{}, a.oP0, 4 * NC0);
     };
     // ---- attention backward, part 1 (hop gap): everything that does not need d ctx of the step ----
     float pre[4][4];
@@ -346,7 +439,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
                 float fa[4] = {cb, cb, cb, cb};
 #pragma unroll
                 for (int j = 0; j < 32; ++j) {
-                    const float wj = s_cw[j * 32 + f];
+                    const float wj = s_cw[j * 33 + f];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[i] = fmaf(wj, win[i + j], fa[i]);
                 }
@@ -374,8 +467,21 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     // ---- attention backward, part 2 (after hop B): train_step.h attention_bwd_kernel's arithmetic from d ctx on ----
     auto att_main = [&](int t) {
         const size_t tb = (size_t)t * B + ab;
-        const float dcx = ld4(xs, a.oDCTX + (unsigned)((ab * EW + tid) * 4));
+        // d context of step t: LSTM 1's input part (GEMM 1 of this step) + the attention LSTM's input part of step t + 1
+        // (GEMM 0 of step t + 1; its buffer is still zero at the last step), four K-slice partials each
+        float dcx;
+        {
+            const int og = tid >> 1, ogrp = og >> 2, oj = og & 3, e2 = tid & 1;
+            float v1[4], v0[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v1[k] = ld4(xs, a.oP1 + (unsigned)(((((ogrp * 4 + k) * MB * 16) + ab) * 4 * NC1 + oj * NC1 + 8 + e2) * 4));
+                v0[k] = ld4(xs, a.oP0 + (unsigned)(((((ogrp * 4 + k) * MB * 16) + ab) * 4 * NC0 + oj * NC0 + 4 + e2) * 4));
+            }
+            dcx = ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v0[0] + v0[1]) + (v0[2] + v0[3]));
+        }
         s_dctx[tid] = dcx;
+        if (ac == 0) a.dctx_all[(size_t)ab * a.dctx_row_ld + (size_t)t * EW + tid] = dcx;
         // softmax-backward dot: d ctx . ctx_t + a . d state
         float part = fmaf(dcx, ctx_v, part_gs);
 #pragma unroll
@@ -444,6 +550,10 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         __syncthreads();
         // this chunk's partial d q as a frag16 operand of the query-layer product
         if (tid < UA / 4) st16(xs, a.oDQ + (unsigned)ac * a.dq_bytes + frag_off16(ab, tid, MB), *reinterpret_cast<const f32x4*>(s_dq + 4 * tid));
+    };
+    // ---- attention backward, part 3 (gap of hop D): what only the next step and the tape need ----
+    auto att_tail = [&](int t) {
+        const size_t tb = (size_t)t * B + ab;
         // d f = d u . Wloc^T on the matrix pipe: wave w -> positions 16 (w >> 1) .., filters 16 (w & 1) ..
         {
             const int r = wave >> 1, ct = wave & 1;
@@ -477,7 +587,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
                 const int ja = max(0, i - a.KA + 1), jb = min(n_pos - 1, i);
                 for (int j = ja; j <= jb; ++j)
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) s = fmaf(s_cw[(i - j) * 32 + cg + 4 * c], s_df[j * 36 + cg + 4 * c], s);
+                    for (int c = 0; c < 8; ++c) s = fmaf(s_cw[(i - j) * 33 + cg + 4 * c], s_df[j * 36 + cg + 4 * c], s);
             }
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
             if (i < NIP && cg == 0) st4(xs, a.oDS + (unsigned)(((((t & 1) * B + ab) * C + ac) * NIP + i) * 4), s);
@@ -492,7 +602,9 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     }
     hop_arrive(a.bar); ++epoch;
     if (!hop_wait(a.bar, 32u * epoch, s_flag)) alive = false;
-    if (alive) { gemm2_part8(S - 1, 0); gemm2_part8(S - 1, 8); gemm2_part8(S - 1, 16); gemm2_part8(S - 1, 24); }
+    if (alive) { gemm2_part(S - 1, 0); gemm2_part(S - 1, 4); gemm2_publish(); }
+    hop_arrive(a.bar); ++epoch;
+    if (alive && !hop_wait(a.bar, 32u * epoch, s_flag)) alive = false;
     TapeRow r1{}, r2{};
     float dy2p = 0.f;
     if (tid < MB * 64) {
@@ -505,49 +617,38 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
 #endif
     for (int t = S - 1; alive && t >= 0; --t) {
         fresh();
-        // ================= GEMM 2 of this step is complete (accumulated in the previous step's gaps): cell backwards =================
-        put_red(acc2);
-#pragma unroll
-        for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ================= GEMM 2 of this step and GEMM 1 of step t + 1 are complete and published: cell backwards =================
         TapeRow r0{};
-        if (tid < MB * 64) r0 = tape_load(0, t);
-        __syncthreads();
         if (tid < MB * 64) {
-            const float dy1 = colsum(euu);
-            dh2p = colsum(4 + euu);
+            r0 = tape_load(0, t);
+            const float dy1 = pread(a.oP2, NC2, euu);
+            dh2p = pread(a.oP2, NC2, 4 + euu);
+            dh1p = pread(a.oP1, NC1, 4 + euu);               // GEMM 1 of step t + 1 (zero at the last step)
             if (t > 0) cell_bwd(2, t - 1, r2, dy2p, ghp2 + dh2p, gc2, ghp2, a.oDZ2 + (unsigned)((t - 1) & 1) * a.dz_bytes);
             cell_bwd(1, t, r1, dy1, ghp1 + dh1p, gc1, ghp1, a.oDZ1);
         }
         PZ_STAMP(1); hop_arrive(a.bar); ++epoch; fresh();
-        // gap A: GEMM 0 of step t + 1 (its results are first needed behind this hop: d ctx_prev below, d h_att_prev in the query phase)
-        if (t < S - 1) gemm0(t + 1);
+        // gap A: GEMM 0 of step t + 1 (its consumers -- d ctx in the attention, d h_att_prev in the query phase -- sit behind hop B)
+        if (t < S - 1) { gemm0(); fresh(); }
         PZ_STAMP(0);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
         fresh(); PZ_STAMP(2);
 
-        // ================= GEMM 1: d [h_att | ctx | h1_prev] = dz1(t) . W1^T =================
-        zero_acc();
-        gemm_dz<MB>(acc, rW1, (unsigned)((wg * KBZ + wave * 32) * 64 * NC1), 64u * NC1, (unsigned)((kg * NC1 + min(c16, NC1 - 1)) * 16), xs,
-                    a.oDZ1 + (unsigned)(wave * 32 * MB * 1024), l16);
-        put_red(acc);
-        __syncthreads();
-        fresh();
-        float dhA1 = 0.f;
-        if (tid < MB * 64) {
-            dhA1 = colsum(euu);
-            dh1p = colsum(4 + euu);
-            if (euu < 2) {
-                // d context of step t: LSTM 1's input part + the attention LSTM's input part of step t + 1
-                const float dc = colsum(8 + euu) + dctxp;
-                if (eown) {
-                    st4(xs, a.oDCTX + (unsigned)((erow * EW + wg * 2 + euu) * 4), dc);
-                    a.dctx_all[(size_t)erow * a.dctx_row_ld + (size_t)t * EW + wg * 2 + euu] = dc;
-                }
-            }
+        // ================= GEMM 1: d [h_att | h1_prev | ctx] = dz1(t) . W1^T, this workgroup's partial tile =================
+        {
+            f32x4 acc1[CT1][MB];
+#pragma unroll
+            for (int ct = 0; ct < CT1; ++ct)
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) acc1[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm2d_part<MB, CT1, 8>(acc1, rW1, (unsigned)((wg * 64 + wave * 8) * 256 * NC1), 256u * NC1, loff1, xs,
+                                    a.oDZ1 + (unsigned)((ks * 64 + wave * 8) * MB * 1024), l16);
+            publish_tiles(acc1, std::integral_constant<int, CT1>{}, a.oP1, 4 * NC1);
         }
+        fresh();
         PZ_STAMP(3); hop_arrive(a.bar); ++epoch; fresh();
-        // gap B: first part of GEMM 2 of step t - 1 (dz2(t - 1) was published before hop A), attention pre-work
-        if (t > 0) { gemm2_part8(t - 1, 0); gemm2_part4(t - 1, 8); fresh(); }
+        // gap B: first half of GEMM 2 of step t - 1 (dz2(t - 1) was published before hop A), attention pre-work
+        if (t > 0) { gemm2_part(t - 1, 0); fresh(); }
         // (dead values for the workgroups without an attention role: keeps these registers from being live around the loop)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -563,11 +664,18 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
         fresh(); PZ_STAMP(4);
 
+        // this owner's columns of GEMM 1 (step t) and GEMM 0 (step t + 1): in flight during the attention
+        float dhA1 = 0.f, dprev = 0.f;
+        if (tid < MB * 64) {
+            dhA1 = pread(a.oP1, NC1, euu);
+            dhAp = pread(a.oP0, NC0, euu);
+            if (euu == 2 && eown && t < S - 1) dprev = pread(a.oP0, NC0, 6);
+        }
         // ================= attention backward =================
         if (isAtt) { att_main(t); fresh(); }
         PZ_STAMP(5); hop_arrive(a.bar); ++epoch; fresh();
-        // gap C: second part of GEMM 2 of step t - 1
-        if (t > 0) { gemm2_part8(t - 1, 12); gemm2_part4(t - 1, 20); fresh(); }
+        // gap C: second half of GEMM 2 of step t - 1, its partial tile published (read at the top of the next step, behind hop D)
+        if (t > 0) { gemm2_part(t - 1, 4); gemm2_publish(); fresh(); }
         const f32x4 bq = ldw(rWQ, (unsigned)((kg * NCQ + min(c16, NCQ - 1)) * 16), (unsigned)((wg * 8 + wave) * 64 * NCQ));
         PZ_STAMP(10);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
@@ -605,12 +713,17 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
             if (tid < MB * 64) {
                 const float dhq = colsum(euu);
                 cell_bwd(0, t, r0, dhA1 + dhq, ghp0 + dhAp, gc0, ghp0, a.oDZ0);
+                if (euu == 2 && eown && t < S - 1) {
+                    // PreNet backward of step t + 1 through dropout(relu(.)) (modules.py:88-91): d pre = (y != 0) ? d y / keep : 0
+                    const size_t pi = ((size_t)(t + 1) * B + erow) * 256 + wg;
+                    a.dpre[pi] = a.xp_last[pi] != 0.f ? dprev * a.inv_keep : 0.f;
+                }
             }
         }
         PZ_STAMP(7); hop_arrive(a.bar); ++epoch; fresh();
-        // gap D: last part of GEMM 2 of step t - 1
-        if (t > 0) { gemm2_part8(t - 1, 24); fresh(); }
-        // tape rows of the next step's LSTM 2 / LSTM 1 backwards: in flight across the hop
+        // gap D: the attention's d f / partial d state_prev (read by the next step's pre-work, behind hop A) and tape rows;
+        // tape rows of the next step's LSTM 2 / LSTM 1 backwards, in flight across the hop
+        if (isAtt) { att_tail(t); fresh(); }
         if (tid < MB * 64 && t > 0) {
             r2 = tape_load(2, t - 2); r1 = tape_load(1, t - 1);
             dy2p = (eown && t > 1) ? a.dy2_all[((size_t)(t - 2) * B + erow) * (NWG * 4) + wg * 4 + euu] : 0.f;
@@ -620,7 +733,17 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         fresh(); PZ_STAMP(8);
     }
     // the last product: d prenet of step 0
-    if (alive) gemm0(0);
+    if (alive) {
+        gemm0();
+        hop_arrive(a.bar); ++epoch;
+        if (hop_wait(a.bar, 32u * epoch, s_flag)) {
+            fresh();
+            if (tid < MB * 64 && euu == 2 && eown) {
+                const size_t pi = (size_t)erow * 256 + wg;
+                a.dpre[pi] = a.xp_last[pi] != 0.f ? pread(a.oP0, NC0, 6) * a.inv_keep : 0.f;
+            }
+        } else alive = false;
+    }
 #ifdef PZ_STAMPS
     if (tid == 0) {
 #pragma unroll

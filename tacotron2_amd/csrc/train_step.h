@@ -657,7 +657,7 @@ struct t2_trainer {
     // persistent backward recurrence (persist_bwd.h): column-owner tiles of the transposed kernels, exchange slab, counters
     float* pzb_w[4] = {};               // LSTM 2, LSTM 1, attention LSTM, query layer
     char* pzb_slab = nullptr; size_t pzb_slab_bytes = 0;
-    unsigned pzb_off[6] = {}, pzb_dz_bytes = 0, pzb_dq_bytes = 0, pzb_xs_bytes = 0;
+    unsigned pzb_off[9] = {}, pzb_dz_bytes = 0, pzb_dq_bytes = 0, pzb_xs_bytes = 0;
     unsigned* pzb_bar = nullptr; float* pzb_pva = nullptr;
     void* bslab = nullptr; size_t bslab_bytes = 0;
     float *dY = nullptr, *dYf = nullptr, *dz[3] = {}, *dzf[3] = {}, *dq = nullptr, *dqf = nullptr;
@@ -717,8 +717,9 @@ static int pzb_pack(t2_trainer* tr, int which, const float* w_dev) {
     const pz::TileMap mp = pzb_map(which);
     const int Kc = which == 3 ? pz::UA : pz::KBZ * 16;
     const long long n4 = (long long)pzb_tile_bytes(which) / 16;
-    hipLaunchKernelGGL(pz::pack_bwd_tiles_kernel, dim3((unsigned)std::min<long long>(4096, (n4 + 255) / 256)), dim3(256), 0, tr->m->ctx->stream,
-                       w_dev, Kc, pz::NWG, mp, tr->pzb_w[which]);
+    const dim3 pgrid((unsigned)std::min<long long>(4096, (n4 + 255) / 256));
+    if (which == 3) hipLaunchKernelGGL(pz::pack_bwd_tiles_kernel, pgrid, dim3(256), 0, tr->m->ctx->stream, w_dev, Kc, pz::NWG, mp, tr->pzb_w[which]);
+    else hipLaunchKernelGGL(pz::pack_bwd_tiles2d_kernel, pgrid, dim3(256), 0, tr->m->ctx->stream, w_dev, Kc, mp, tr->pzb_w[which]);
     HIP_TRY(hipGetLastError());
     return T2_OK;
 }
@@ -752,6 +753,9 @@ static int pzb_setup(t2_trainer* tr) {
     tr->pzb_off[3] = carve((size_t)MB * 16 * pz::EW * 4);
     tr->pzb_off[4] = carve((size_t)C * tr->pzb_dq_bytes);
     tr->pzb_off[5] = carve(2 * (size_t)B * C * (CH + 32) * 4);
+    tr->pzb_off[6] = carve((size_t)pz::NWG * MB * 16 * 4 * pz::NC2 * 4);          // partial product tiles of GEMM 2, 1, 0
+    tr->pzb_off[7] = carve((size_t)pz::NWG * MB * 16 * 4 * pz::NC1 * 4);
+    tr->pzb_off[8] = carve((size_t)pz::NWG * MB * 16 * 4 * pz::NC0 * 4);
     tr->pzb_xs_bytes = (unsigned)off;
     const size_t o_bar = carve((size_t)(pz::NSHARD + 1) * 32 * 4);
     tr->pzb_slab_bytes = off;
@@ -785,6 +789,7 @@ static int pzb_launch(t2_trainer* tr) {
     a.dpre = tr->dpre[np - 1]; a.pva_part = tr->pzb_pva; a.dctx_row_ld = (long long)S * pz::EW;
     a.xs = (float*)tr->pzb_slab; a.xs_bytes = tr->pzb_xs_bytes;
     a.oDZ2 = tr->pzb_off[0]; a.oDZ1 = tr->pzb_off[1]; a.oDZ0 = tr->pzb_off[2]; a.oDCTX = tr->pzb_off[3]; a.oDQ = tr->pzb_off[4]; a.oDS = tr->pzb_off[5];
+    a.oP2 = tr->pzb_off[6]; a.oP1 = tr->pzb_off[7]; a.oP0 = tr->pzb_off[8];
     a.dz_bytes = tr->pzb_dz_bytes; a.dq_bytes = tr->pzb_dq_bytes;
     a.bar = tr->pzb_bar; a.err = (int*)(tr->pzb_bar + pz::NSHARD * 32);
     a.B = B; a.T = T; a.S = S; a.C = persist_chunks(B); a.CH = (T + a.C - 1) / a.C;
