@@ -413,12 +413,12 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
                     const int p = min(p0 + 16 * r + 4 * kg + g, T - 1);
                     pre[r][g] = r < NRT ? keys_b[(size_t)p * UA] : 0.f;
                 }
-            const float* vals = a.values + ((size_t)ab * T + p0) * EW;
+            const float* vals = a.values + (size_t)ab * T * EW;
 #pragma unroll
             for (int jj = 0; jj < VN; ++jj) {
-                const int j = min(wave + jj * NWAVE, max(n_pos - 1, 0));
+                const int jp = min(p0 + wave + jj * NWAVE, T - 1);      // rows past the chunk are loaded (in bounds) and not used
 #pragma unroll
-                for (int i = 0; i < 8; ++i) vv[jj][i] = vals[(size_t)j * EW + lane + 64 * i];
+                for (int i = 0; i < 8; ++i) vv[jj][i] = vals[(size_t)jp * EW + lane + 64 * i];
             }
         }
         __syncthreads();

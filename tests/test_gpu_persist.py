@@ -230,7 +230,7 @@ def test_persistent_encoder_bilstm_against_oracle_and_launch_schedule(B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T,S", [(1, 9, 3), (20, 77, 7), (64, 140, 5)])
+@pytest.mark.parametrize("B,T,S", [(1, 9, 3), (3, 2, 1), (20, 77, 7), (16, 200, 3), (64, 140, 5)])
 def test_persistent_backward_matches_launch_per_phase(B, T, S):
     """The training backward's reverse-time recurrences as persistent launches (csrc/persist_bwd.h: decoder cell stack +
     attention, and the encoder BiLSTM; option bwd_persist) and the encoder's training forward on pz::encoder_kernel
@@ -276,12 +276,12 @@ def test_persistent_backward_matches_launch_per_phase(B, T, S):
         g1, m1, mem1, l1 = out[1]
         np.testing.assert_allclose(mem1, mem0, atol=1e-5)
         assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
-        np.testing.assert_allclose(m1, m0, atol=2e-4 * float(np.abs(m0).max()) + 1e-12)
+        np.testing.assert_allclose(m1, m0, atol=2e-4 * float(np.abs(m0).max()) + 1e-9)
         for name in sorted(g0):
             if "moving_" in name:
                 continue
             scale = float(np.abs(g0[name]).max())
-            assert float(np.abs(g1[name] - g0[name]).max()) <= 2e-4 * scale + 1e-12, name
+            assert float(np.abs(g1[name] - g0[name]).max()) <= 2e-4 * scale + 1e-9, name
     finally:
         tr.close()
         eng.close()

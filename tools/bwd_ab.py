@@ -84,7 +84,7 @@ def run(B, T, S, reps=3):
     print(f"B={B} T={T} S={S}: backward {t0:.2f} ms (launch per phase) -> {t1:.2f} ms (persistent); worst relative differences:")
     for rel, name, err, scale in worst[:6]:
         print(f"    {name:55s} rel {rel:.2e} (abs {err:.3e}, scale {scale:.3e})")
-    bad = [x for x in worst if x[0] > 2e-4]
+    bad = [x for x in worst if x[2] > 2e-4 * x[3] + 1e-7]       # (T_in = 1: the attention gradients are exactly 0 in one schedule, 1e-9 in the other)
     tr.close()
     eng.close()
     return not bad
