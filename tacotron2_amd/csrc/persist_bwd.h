@@ -488,6 +488,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) s_rd[wave] = part;
         __syncthreads();
+        PZ_STAMP(12);
         // d alignments: da_j = d ctx . values_j + d state_j; wave w takes positions w, w + 8, ...
         {
             float dv[8];
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
             if (tid < n_pos) a.de_all[tb * T + p0 + tid] = de;
         }
         __syncthreads();
+        PZ_STAMP(13);
         // d u = d e * v * (1 - tanh^2), d v_a += d e * tanh, d q = sum over positions of d u
         {
             const float q_l = s_q[wave * 16 + c16];
@@ -579,6 +581,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
             }
         }
         __syncthreads();
+        PZ_STAMP(14);
         // partial d state_prev over the chunk + conv halo: ds[i] <-> position p0 - pad_l + i
         {
             const int i = tid >> 2, cg = tid & 3;
@@ -724,6 +727,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         // gap D: the attention's d f / partial d state_prev (read by the next step's pre-work, behind hop A) and tape rows;
         // tape rows of the next step's LSTM 2 / LSTM 1 backwards, in flight across the hop
         if (isAtt) { att_tail(t); fresh(); }
+        PZ_STAMP(15);
         if (tid < MB * 64 && t > 0) {
             r2 = tape_load(2, t - 2); r1 = tape_load(1, t - 1);
             dy2p = (eown && t > 1) ? a.dy2_all[((size_t)(t - 2) * B + erow) * (NWG * 4) + wg * 4 + euu] : 0.f;

@@ -246,6 +246,57 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
     }
 }
 
+
+// d (location convolution kernel)[k][f] = sum over all (step, row) pairs and positions j of state_prev[j - pad_l + k] * df[j][f]
+// (tacotron_v2.py:128-130 backward; taps outside [0, T) read zero).  Block = one (tap, filter) pair per thread; the blocks
+// stride over the S * B tape rows and stage a row's attention state (with the halo) and its df tile in LDS, 128 positions at a
+// time; part[block][K][F] is then summed in block order (batch_sum_kernel): deterministic.
+#define T2_LCW_POS 128
+__global__ __launch_bounds__(1024) void loc_conv_wgrad_kernel(const float* __restrict__ state_prev, const float* __restrict__ df, long long n_rows,
+                                                               int T, int K, int F, float* __restrict__ part) {
+    __shared__ float s_sp[T2_LCW_POS + 32];
+    __shared__ float s_dfl[T2_LCW_POS * 33];
+    const int tid = threadIdx.x, k = tid >> 5, f = tid & 31, pad_l = (K - 1) / 2;
+    float acc = 0.f;
+    for (long long r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const float* sp = state_prev + r * T;
+        const float* dr = df + r * (long long)T * F;
+        for (int j0 = 0; j0 < T; j0 += T2_LCW_POS) {
+            const int nj = min(T2_LCW_POS, T - j0);
+            __syncthreads();
+            for (int i = tid; i < nj + K - 1; i += 1024) { const int p = j0 - pad_l + i; s_sp[i] = (p >= 0 && p < T) ? sp[p] : 0.f; }
+            for (int i = tid; i < nj * F; i += 1024) { const int j = i / F, c = i - j * F; s_dfl[j * 33 + c] = dr[(long long)j0 * F + i]; }
+            __syncthreads();
+            if (k < K && f < F) {
+#pragma unroll 4
+                for (int j = 0; j < nj; ++j) acc = fmaf(s_sp[j + k], s_dfl[j * 33 + f], acc);
+            }
+        }
+    }
+    if (k < K && f < F) part[(size_t)blockIdx.x * K * F + k * F + f] = acc;
+}
+
+// d values[b][j][:] = sum_t a_t[b][j] * d ctx_t[b][:] (AttentionWrapper._compute_attention backward): block = (row b, 16 positions),
+// thread = context column; the step loop keeps four steps of loads in flight, steps are added in order
+__global__ __launch_bounds__(512) void dvalues_kernel(const float* __restrict__ hist, const float* __restrict__ dctx, int B, int T, int S, int E,
+                                                      float* __restrict__ dvalues) {
+    const int b = blockIdx.y, j0 = blockIdx.x * 16, nj = min(16, T - j0);
+    for (int e = threadIdx.x; e < E; e += 512) {
+        float acc[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.f;
+        const float* dc = dctx + (size_t)b * S * E + e;
+        for (int t = 0; t < S; ++t) {
+            const float d = dc[(size_t)t * E];
+            const float* ar = hist + ((size_t)t * B + b) * T + j0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc[jj] = fmaf(jj < nj ? ar[jj] : 0.f, d, acc[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) if (jj < nj) dvalues[((size_t)b * T + j0 + jj) * E + e] = acc[jj];
+    }
+}
+
 // dmemory = (dvalues + dkeys . Wmem^T is added by a GEMM beforehand) masked by the sequence lengths (values = memory * mask)
 __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, const int* __restrict__ lens, int B, int T, int E) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)B * T * E; i += (long long)gridDim.x * blockDim.x) {
@@ -1338,7 +1389,13 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_layer/kernel", &g));
         T2_TRY(bwd_wgrad(tr, tr->f_all, F, F, tr->du_all, U, U, rows, g, U));
         T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/kernel", &g));
-        {   // [K][1][F] = im2col(state_prev)^T . df, taps reaching outside a row's [0, T) read zero
+        if (K <= 32 && F <= 32) {
+            // [K][1][F] = im2col(state_prev)^T . df on the dedicated kernel (the generic weight-gradient GEMM took 0.8 ms here)
+            const int nblk = 256;
+            if (!tr->wg_part) HIP_TRY(hipMalloc((void**)&tr->wg_part, (size_t)T2_WG_PART_FLOATS * 4));
+            hipLaunchKernelGGL(loc_conv_wgrad_kernel, dim3(nblk), dim3(1024), 0, st, tp.state_prev, tr->df_all, (long long)SB, T, K, F, tr->wg_part);
+            hipLaunchKernelGGL(batch_sum_kernel, dim3(ceil_div(K * F, 256)), dim3(256), 0, st, tr->wg_part, nblk, (long long)K * F, g);
+        } else {   // [K][1][F] = im2col(state_prev)^T . df, taps reaching outside a row's [0, T) read zero
             ConvArgs a{};
             a.x = tp.state_prev; a.ldx = 1; a.w = tr->df_all; a.y = g; a.ldy = F;
             a.Mtot = K; a.T = T; a.Cin = 1; a.N = F; a.ktaps = K; a.pad_l = (K - 1) / 2; a.act = 0; a.trans_a = 1; a.red = (int)rows;
@@ -1348,8 +1405,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/bias", &g));
         T2_TRY(col_sum(tr, tr->df_all, rows, F, g));
         // d values[b][j][:] = sum_t a_t[b][j] * dctx_t[b][:]: one [T x S] . [S x E] product per row
-        for (int b = 0; b < B; ++b)
-            T2_TRY(bwd_wgrad(tr, s->o_hist + (size_t)b * T, B * T, T, tr->dctx_all + (size_t)b * S * E, E, E, S, tr->dvalues + (size_t)b * T * E, E));
+        hipLaunchKernelGGL(dvalues_kernel, dim3(ceil_div(T, 16), B), dim3(512), 0, st, s->o_hist, tr->dctx_all, B, T, S, E, tr->dvalues);
     }
     // PreNets: inputs of layer 0 are the teacher-forced frames (go frame at t = 0)
     {

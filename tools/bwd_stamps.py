@@ -33,10 +33,10 @@ out = np.zeros((256, 24), np.uint64)
 eng.lib.t2_debug_stamps.argtypes = [C.c_void_p]
 assert eng.lib.t2_debug_stamps(out.ctypes.data_as(C.c_void_p)) == 0
 us = out.astype(np.float64) * 0.01 / S
-names = ["arrive A + gap A (GEMM0)", "cells L2,L1", "WAIT A", "GEMM1+dctx", "WAIT B", "attention main", "WAIT C", "query+cell att", "WAIT D", "arrive B + gap B (GEMM2a, att pre)", "arrive C + gap C (GEMM2b)", "arrive D + gap D (GEMM2c)"]
+names = ["arrive A + gap A (GEMM0)", "cells L2,L1", "WAIT A", "GEMM1+dctx", "WAIT B", "attention main", "WAIT C", "query+cell att", "WAIT D", "arrive B + gap B (GEMM2a, att pre)", "arrive C + gap C (GEMM2b)", "gap D rest (tape prefetch)", "att main: dctx+dot", "att main: da+de", "att tail: df (+arrive D)", "att tail: ds"]
 print("B=%d T=%d S=%d ; us per step: mean over workgroups / min / max / wg0 / wg255" % (B, T, S))
 for i, nm in enumerate(names):
     c = us[:, i]
     print("%2d %-36s %7.2f %7.2f %7.2f %7.2f %7.2f" % (i, nm, c.mean(), c.min(), c.max(), c[0], c[255]))
-print("sum (mean) %.2f" % us[:, :12].sum(axis=1).mean())
+print("sum (mean) %.2f" % us[:, :16].sum(axis=1).mean())
 tr.close(); eng.close()
