@@ -358,15 +358,24 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
 #pragma unroll
             for (int rb = 0; rb < MB; ++rb) acc2[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // GEMM 0 of a step (d [prenet out | ctx_prev | h_att_prev] = dz_att . W0^T): this workgroup's partial tile
-    auto gemm0 = [&]() {
-        f32x4 acc0[CT0][MB];
+    // GEMM 0 of a step (d [prenet out | ctx_prev | h_att_prev] = dz_att . W0^T): this workgroup's partial tile, in two halves
+    // (the first runs before a hop's arrive and overlaps the drain of the stores just issued, the second in the hop's gap)
+    f32x4 acc0[CT0][MB];
+    auto gemm0_half0 = [&]() {
 #pragma unroll
         for (int ct = 0; ct < CT0; ++ct)
 #pragma unroll
             for (int rb = 0; rb < MB; ++rb) acc0[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm2d_part<MB, CT0, 8>(acc0, rW0, (unsigned)((wg * 64 + wave * 8) * 256 * NC0), 256u * NC0, loff0, xs,
+        gemm2d_part<MB, CT0, 4>(acc0, rW0, (unsigned)((wg * 64 + wave * 8) * 256 * NC0), 256u * NC0, loff0, xs,
                                 a.oDZ0 + (unsigned)((ks * 64 + wave * 8) * MB * 1024), l16);
+    };
+    // (64 rows: the accumulators would not survive the hop without spilling; both halves run in the gap)
+    // (16 rows: the step is hop-latency bound, work ahead of an arrive only delays it -- everything stays in the gaps)
+    auto gemm0_first = [&]() { if constexpr (MB == 2) gemm0_half0(); };
+    auto gemm0_second = [&]() {
+        if constexpr (MB != 2) gemm0_half0();
+        gemm2d_part<MB, CT0, 4>(acc0, rW0, (unsigned)((wg * 64 + wave * 8 + 4) * 256 * NC0), 256u * NC0, loff0, xs,
+                                a.oDZ0 + (unsigned)((ks * 64 + wave * 8 + 4) * MB * 1024), l16);
         publish_tiles(acc0, std::integral_constant<int, CT0>{}, a.oP0, 4 * NC0);
     };
     // ---- attention backward, part 1 (hop gap): everything that does not need d ctx of the step ----
@@ -553,8 +562,9 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
         // this chunk's partial d q as a frag16 operand of the query-layer product
         if (tid < UA / 4) st16(xs, a.oDQ + (unsigned)ac * a.dq_bytes + frag_off16(ab, tid, MB), *reinterpret_cast<const f32x4*>(s_dq + 4 * tid));
     };
-    // ---- attention backward, part 3 (gap of hop D): what only the next step and the tape need ----
-    auto att_tail = [&](int t) {
+    // ---- attention backward, part 3: what only the next step and the tape need (d f before hop D's arrive, over the drain of the
+    //      dz stores; the partial d state in the hop's gap) ----
+    auto att_df = [&](int t) {
         const size_t tb = (size_t)t * B + ab;
         // d f = d u . Wloc^T on the matrix pipe: wave w -> positions 16 (w >> 1) .., filters 16 (w & 1) ..
         {
@@ -580,8 +590,8 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
                 }
             }
         }
-        __syncthreads();
-        PZ_STAMP(14);
+    };
+    auto att_ds = [&](int t) {
         // partial d state_prev over the chunk + conv halo: ds[i] <-> position p0 - pad_l + i
         {
             const int i = tid >> 2, cg = tid & 3;
@@ -630,9 +640,11 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
             if (t > 0) cell_bwd(2, t - 1, r2, dy2p, ghp2 + dh2p, gc2, ghp2, a.oDZ2 + (unsigned)((t - 1) & 1) * a.dz_bytes);
             cell_bwd(1, t, r1, dy1, ghp1 + dh1p, gc1, ghp1, a.oDZ1);
         }
+        // GEMM 0 of step t + 1 (its consumers -- d ctx in the attention, d h_att_prev in the query phase -- sit behind hop B):
+        // first half here, over the drain of the dz stores; second half in the gap of hop A
+        if (t < S - 1) { gemm0_first(); fresh(); }
         PZ_STAMP(1); hop_arrive(a.bar); ++epoch; fresh();
-        // gap A: GEMM 0 of step t + 1 (its consumers -- d ctx in the attention, d h_att_prev in the query phase -- sit behind hop B)
-        if (t < S - 1) { gemm0(); fresh(); }
+        if (t < S - 1) { gemm0_second(); fresh(); }
         PZ_STAMP(0);
         if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
         fresh(); PZ_STAMP(2);
@@ -649,9 +661,11 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
             publish_tiles(acc1, std::integral_constant<int, CT1>{}, a.oP1, 4 * NC1);
         }
         fresh();
+        // first half of GEMM 2 of step t - 1 (dz2(t - 1) was published before hop A) over the drain of the partial-tile stores
+        if (MB >= 2 && t > 0) { gemm2_part(t - 1, 0); fresh(); }
         PZ_STAMP(3); hop_arrive(a.bar); ++epoch; fresh();
-        // gap B: first half of GEMM 2 of step t - 1 (dz2(t - 1) was published before hop A), attention pre-work
-        if (t > 0) { gemm2_part(t - 1, 0); fresh(); }
+        // gap B: attention pre-work
+        if (MB < 2 && t > 0) { gemm2_part(t - 1, 0); fresh(); }
         // (dead values for the workgroups without an attention role: keeps these registers from being live around the loop)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -723,10 +737,12 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
                 }
             }
         }
+        if (MB >= 2 && isAtt) { att_df(t); fresh(); }
         PZ_STAMP(7); hop_arrive(a.bar); ++epoch; fresh();
-        // gap D: the attention's d f / partial d state_prev (read by the next step's pre-work, behind hop A) and tape rows;
+        if (MB < 2 && isAtt) { att_df(t); __syncthreads(); fresh(); }
+        // gap D: the attention's partial d state_prev (read by the next step's pre-work, behind hop A);
         // tape rows of the next step's LSTM 2 / LSTM 1 backwards, in flight across the hop
-        if (isAtt) { att_tail(t); fresh(); }
+        if (isAtt) { att_ds(t); fresh(); }
         PZ_STAMP(15);
         if (tid < MB * 64 && t > 0) {
             r2 = tape_load(2, t - 2); r1 = tape_load(1, t - 1);
@@ -738,7 +754,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(BArgs a) {
     }
     // the last product: d prenet of step 0
     if (alive) {
-        gemm0();
+        gemm0_first(); gemm0_second();
         hop_arrive(a.bar); ++epoch;
         if (hop_wait(a.bar, 32u * epoch, s_flag)) {
             fresh();
