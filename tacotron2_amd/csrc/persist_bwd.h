@@ -12,15 +12,17 @@
 // group's 28..40 columns -- a quarter of dz instead of all of it through every CU, and full MFMA tiles instead of one half-empty
 // tile.  The partial tiles go to the slab; every consumer of a product sits behind a later hop anyway and adds the four
 // partials when it loads them (cells: their own columns; attention: d ctx).  A step is four all-to-all hops:
-//   GEMM 2 (dz2 -> d y1 | d h2_prev) -> LSTM 2 backward of step t-1, LSTM 1 backward of step t  -> hop A ->
-//   GEMM 1 (dz1 -> d h_att | d ctx | d h1_prev), d ctx published                                 -> hop B ->
+//   LSTM 2 backward of step t-1 and LSTM 1 backward of step t (dz2, dz1 published)               -> hop A ->
+//   GEMM 1 (dz1 -> d h_att | d h1_prev | d ctx partial tiles)                                    -> hop B ->
 //   attention backward (row split over C workgroups by encoder position, partial d q / d state)  -> hop C ->
-//   query-layer product (sum of the C partials), attention LSTM backward                          -> hop D ->
-//   GEMM 0 (dz_att -> d prenet | d ctx_prev | d h_att_prev).
-// LSTM 2's chain (dz2 of step t-1 needs only GEMM 2 of step t) runs one step ahead, so its operand is complete long before
-// GEMM 2 needs it.  Hand-off protocol: persist.h (sc1 stores, drain, barrier, one agent-scope add per workgroup; sc1 loads).
-// Everything the weight-gradient GEMMs after the loop read (dz, dq, du / f / df, d ctx, d prenet) is written to the same
-// plain tape buffers as the launch-per-phase backward writes, so the code after the loop is shared.
+//   query-layer product (sum of the C partial d q), attention LSTM backward (dz_att published)   -> hop D.
+// Everything else fills the time between a hop's arrive and wait: GEMM 0 of step t+1 (dz_att -> d prenet | d ctx_prev |
+// d h_att_prev) around hop A, GEMM 2 of step t-1 (dz2 -> d y1 | d h2_prev; LSTM 2's chain runs one step ahead: dz2 of step
+// t-1 needs only GEMM 2 of step t) around hops B and C, the attention's query-independent work in the gap of hop B, its
+// d f / partial d state_prev around hop D.  At 32 / 64 rows a piece of that work also runs just AHEAD of the arrive, over the
+// drain of the stores the phase issued.  Hand-off protocol: persist.h (sc1 stores, drain, barrier, one agent-scope add per
+// workgroup; sc1 loads).  Everything the weight-gradient GEMMs after the loop read (dz, dq, du / f / df, d ctx, d prenet) is
+// written to the same plain tape buffers as the launch-per-phase backward writes, so the code after the loop is shared.
 #pragma once
 #include "persist.h"
 #include <type_traits>
@@ -28,7 +30,7 @@
 namespace pz {
 
 struct BArgs {
-    const float *wT2, *wT1, *wT0, *wTQ;        // column-owner tiles of W^T: [256][KB][4][NC][4] (pack_bwd_tiles_kernel)
+    const float *wT2, *wT1, *wT0, *wTQ;        // tiles of W^T: 2-D [256][64][4][4 NC][4] (pack_bwd_tiles2d_kernel); query layer 1-D [256][8][4][NC][4]
     const float *conv_w, *conv_b, *wloc, *v_a;
     const float *keys, *values;                // [B][T][128], [B][T][512]
     const int* lens;

@@ -248,53 +248,70 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
 
 
 // d (location convolution kernel)[k][f] = sum over all (step, row) pairs and positions j of state_prev[j - pad_l + k] * df[j][f]
-// (tacotron_v2.py:128-130 backward; taps outside [0, T) read zero).  Block = one (tap, filter) pair per thread; the blocks
-// stride over the S * B tape rows and stage a row's attention state (with the halo) and its df tile in LDS, 128 positions at a
-// time; part[block][K][F] is then summed in block order (batch_sum_kernel): deterministic.
+// (tacotron_v2.py:128-130 backward; taps outside [0, T) read zero).  Thread = one filter x four consecutive taps: the attention
+// state slides through a four-register window, so a position costs two LDS reads for four FMAs.  The blocks stride over the
+// S * B tape rows and stage a row's attention state (with the halo) and its df tile in LDS, 128 positions at a time;
+// part[block][K][F] is then summed in block order (batch_sum_kernel): deterministic.
 #define T2_LCW_POS 128
-__global__ __launch_bounds__(1024) void loc_conv_wgrad_kernel(const float* __restrict__ state_prev, const float* __restrict__ df, long long n_rows,
-                                                               int T, int K, int F, float* __restrict__ part) {
-    __shared__ float s_sp[T2_LCW_POS + 32];
+__global__ __launch_bounds__(256) void loc_conv_wgrad_kernel(const float* __restrict__ state_prev, const float* __restrict__ df, long long n_rows,
+                                                              int T, int K, int F, float* __restrict__ part) {
+    __shared__ float s_sp[T2_LCW_POS + 36];
     __shared__ float s_dfl[T2_LCW_POS * 33];
-    const int tid = threadIdx.x, k = tid >> 5, f = tid & 31, pad_l = (K - 1) / 2;
-    float acc = 0.f;
+    const int tid = threadIdx.x, kq = tid >> 5, f = tid & 31, pad_l = (K - 1) / 2, k0 = 4 * kq;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (long long r = blockIdx.x; r < n_rows; r += gridDim.x) {
         const float* sp = state_prev + r * T;
         const float* dr = df + r * (long long)T * F;
         for (int j0 = 0; j0 < T; j0 += T2_LCW_POS) {
             const int nj = min(T2_LCW_POS, T - j0);
             __syncthreads();
-            for (int i = tid; i < nj + K - 1; i += 1024) { const int p = j0 - pad_l + i; s_sp[i] = (p >= 0 && p < T) ? sp[p] : 0.f; }
-            for (int i = tid; i < nj * F; i += 1024) { const int j = i / F, c = i - j * F; s_dfl[j * 33 + c] = dr[(long long)j0 * F + i]; }
+            for (int i = tid; i < nj + 35; i += 256) { const int p = j0 - pad_l + i; s_sp[i] = (p >= 0 && p < T) ? sp[p] : 0.f; }
+            for (int i = tid; i < nj * F; i += 256) { const int j = i / F, c = i - j * F; s_dfl[j * 33 + c] = dr[(long long)j0 * F + i]; }
             __syncthreads();
-            if (k < K && f < F) {
+            if (f < F) {
+                float w0 = s_sp[k0], w1 = s_sp[k0 + 1], w2 = s_sp[k0 + 2];
 #pragma unroll 4
-                for (int j = 0; j < nj; ++j) acc = fmaf(s_sp[j + k], s_dfl[j * 33 + f], acc);
+                for (int j = 0; j < nj; ++j) {
+                    const float w3 = s_sp[j + k0 + 3], dv = s_dfl[j * 33 + f];
+                    acc[0] = fmaf(w0, dv, acc[0]); acc[1] = fmaf(w1, dv, acc[1]); acc[2] = fmaf(w2, dv, acc[2]); acc[3] = fmaf(w3, dv, acc[3]);
+                    w0 = w1; w1 = w2; w2 = w3;
+                }
             }
         }
     }
-    if (k < K && f < F) part[(size_t)blockIdx.x * K * F + k * F + f] = acc;
+    if (f < F)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (k0 + q < K) part[(size_t)blockIdx.x * K * F + (k0 + q) * F + f] = acc[q];
 }
 
 // d values[b][j][:] = sum_t a_t[b][j] * d ctx_t[b][:] (AttentionWrapper._compute_attention backward): block = (row b, 16 positions),
-// thread = context column; the step loop keeps four steps of loads in flight, steps are added in order
+// thread = context column; the alignments of 64 steps x 16 positions are staged in LDS, steps are added in order
 __global__ __launch_bounds__(512) void dvalues_kernel(const float* __restrict__ hist, const float* __restrict__ dctx, int B, int T, int S, int E,
                                                       float* __restrict__ dvalues) {
-    const int b = blockIdx.y, j0 = blockIdx.x * 16, nj = min(16, T - j0);
-    for (int e = threadIdx.x; e < E; e += 512) {
-        float acc[16];
+    __shared__ float s_a[64 * 16];
+    const int b = blockIdx.y, j0 = blockIdx.x * 16, nj = min(16, T - j0), e = blockIdx.z * 512 + threadIdx.x;
+    float acc[16];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.f;
-        const float* dc = dctx + (size_t)b * S * E + e;
-        for (int t = 0; t < S; ++t) {
-            const float d = dc[(size_t)t * E];
-            const float* ar = hist + ((size_t)t * B + b) * T + j0;
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) acc[jj] = fmaf(jj < nj ? ar[jj] : 0.f, d, acc[jj]);
+    for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.f;
+    const float* dc = dctx + (size_t)b * S * E + e;
+    for (int t0 = 0; t0 < S; t0 += 64) {
+        const int nt = min(64, S - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 16; i += 512) {
+            const int tt = i >> 4, jj = i & 15;
+            s_a[i] = (tt < nt && jj < nj) ? hist[((size_t)(t0 + tt) * B + b) * T + j0 + jj] : 0.f;
         }
+        __syncthreads();
+        if (e < E)
+            for (int tt = 0; tt < nt; ++tt) {
+                const float d = dc[(size_t)(t0 + tt) * E];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) acc[jj] = fmaf(s_a[tt * 16 + jj], d, acc[jj]);
+            }
+    }
+    if (e < E)
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) if (jj < nj) dvalues[((size_t)b * T + j0 + jj) * E + e] = acc[jj];
-    }
 }
 
 // dmemory = (dvalues + dkeys . Wmem^T is added by a GEMM beforehand) masked by the sequence lengths (values = memory * mask)
@@ -1391,9 +1408,9 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/kernel", &g));
         if (K <= 32 && F <= 32) {
             // [K][1][F] = im2col(state_prev)^T . df on the dedicated kernel (the generic weight-gradient GEMM took 0.8 ms here)
-            const int nblk = 256;
+            const int nblk = 1024;
             if (!tr->wg_part) HIP_TRY(hipMalloc((void**)&tr->wg_part, (size_t)T2_WG_PART_FLOATS * 4));
-            hipLaunchKernelGGL(loc_conv_wgrad_kernel, dim3(nblk), dim3(1024), 0, st, tp.state_prev, tr->df_all, (long long)SB, T, K, F, tr->wg_part);
+            hipLaunchKernelGGL(loc_conv_wgrad_kernel, dim3(nblk), dim3(256), 0, st, tp.state_prev, tr->df_all, (long long)SB, T, K, F, tr->wg_part);
             hipLaunchKernelGGL(batch_sum_kernel, dim3(ceil_div(K * F, 256)), dim3(256), 0, st, tr->wg_part, nblk, (long long)K * F, g);
         } else {   // [K][1][F] = im2col(state_prev)^T . df, taps reaching outside a row's [0, T) read zero
             ConvArgs a{};
@@ -1405,7 +1422,7 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         T2_TRY(grad_dst(tr, flat_grads, "attention/location_features_convolution/bias", &g));
         T2_TRY(col_sum(tr, tr->df_all, rows, F, g));
         // d values[b][j][:] = sum_t a_t[b][j] * dctx_t[b][:]: one [T x S] . [S x E] product per row
-        hipLaunchKernelGGL(dvalues_kernel, dim3(ceil_div(T, 16), B), dim3(512), 0, st, s->o_hist, tr->dctx_all, B, T, S, E, tr->dvalues);
+        hipLaunchKernelGGL(dvalues_kernel, dim3(ceil_div(T, 16), B, ceil_div(E, 512)), dim3(512), 0, st, s->o_hist, tr->dctx_all, B, T, S, E, tr->dvalues);
     }
     // PreNets: inputs of layer 0 are the teacher-forced frames (go frame at t = 0)
     {
