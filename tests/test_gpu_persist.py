@@ -293,3 +293,57 @@ def test_persistent_backward_matches_launch_per_phase(B, T, S):
     finally:
         tr.close()
         eng.close()
+
+
+@pytest.mark.gpu
+def test_persistent_training_recurrences_after_parameter_refresh():
+    """t2_trainer_load_params rebuilds the persistent backward kernels' operands (2-D W^T tiles of the decoder LSTMs, the query
+    tile, the encoder's column-owner tiles) from the flat parameter buffer on the device: a trainer refreshed with new
+    parameters must produce the gradients of a trainer created from them."""
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.engine import Engine
+    d = PROFILE_P
+    w_old = init_weights(d, seed=5, perturb=True)
+    w_new = init_weights(d, seed=77, perturb=True)
+    B, T, S, r = 20, 61, 4, d.outputs_per_step
+    rng = np.random.default_rng(2)
+    lens = rng.integers(30, T + 1, B).astype(np.int64)
+    lens[0] = T
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    mel = rng.uniform(0, 1, (B, S * r, d.num_mels)).astype(np.float32)
+    done = np.zeros((B, S), np.float32)
+    done[:, -1] = 1
+    smask, bmask = np.ones((B, S * r), np.float32), np.ones((B, S), np.float32)
+    spec = TR.flatten_spec(w_old)
+
+    def step(eng, tr):
+        n0 = eng.get_stat("bwd_persist_launches")
+        memory, _ = tr.encoder_forward(ids, lens, drop_rate=0.5, seed=9)
+        tr.decoder_forward(memory, lens, mel, prenet_drop_rate=0.5, seed=9)
+        flat = torch.zeros(TR.flat_size(spec), dtype=torch.float32, device="cuda")
+        dmem, losses = tr.decoder_backward(done, smask, bmask, flat)
+        tr.encoder_backward(dmem, flat)
+        assert eng.get_stat("bwd_persist_launches") == n0 + 2
+        return TR.unflatten(flat, spec), float(losses[2])
+
+    eng_a = Engine(d, w_old)
+    tr_a = TR.Trainer(eng_a, B, T, S)
+    eng_b = Engine(d, w_new)
+    tr_b = TR.Trainer(eng_b, B, T, S)
+    try:
+        tr_a.bind_gradients(spec)
+        tr_b.bind_gradients(spec)
+        step(eng_a, tr_a)                                                     # builds the operands from the old weights
+        tr_a.load_params(torch.from_numpy(TR.flatten(w_new, spec)).cuda())    # ... and replaces them on the device
+        g_a, loss_a = step(eng_a, tr_a)
+        g_b, loss_b = step(eng_b, tr_b)
+        assert abs(loss_a - loss_b) <= 1e-5 * max(1.0, abs(loss_b))
+        for name in sorted(g_b):
+            if "moving_" in name:
+                continue
+            scale = float(np.abs(g_b[name]).max())
+            assert float(np.abs(g_a[name] - g_b[name]).max()) <= 2e-4 * scale + 1e-9, name
+    finally:
+        tr_a.close(); tr_b.close()
+        eng_a.close(); eng_b.close()
