@@ -44,17 +44,6 @@ def make_inputs(B, t_lo, t_hi, seed):
     return ids, lens.astype(np.int64)
 
 
-def _unused_lstm_algorithmic(d, B):
-    """Algorithmic FLOPs / bytes of ONE decoder-LSTM launch, averaged over the three launches of a
-    decoder step (attention LSTM, LSTM 1, LSTM 2) -- DESIGN.md "Roofline accounting"."""
-    P2, E, A, D = d.prenet_units[-1], d.enc_units, d.attention_lstm_units, d.decoder_lstm_units
-    ks = [(P2 + E + A, A), (A + E + D, D), (D + D, D)]
-    flops = np.mean([2.0 * B * k * 4 * h for k, h in ks])
-    # weights + bias read once, activations read once, c r/w, h state r + w, raw h w
-    byts = np.mean([4.0 * (k * 4 * h + 4 * h + B * k + B * h * 5) for k, h in ks])
-    return float(flops), float(byts)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +137,7 @@ def main():
         dt_max, frames_all = dt, float(frames)
 
     out = None
+    parity_failed = False
     if rank == 0:
         out = {
             "metric": "mel frames/sec (node), Tacotron2 decode B=64 at 1/2/4/8 GPUs; batch-1 RTF",
@@ -390,6 +380,29 @@ def main():
         out["parity_check"] = {"max_abs_mel_postnet_diff_B64x%d_frames" % (n_g * r): float(np.abs(post_g - post_cpu).max()),
                                "max_abs_mel_diff_first_20_steps": float(np.abs(got[:, :20 * r] - mel_o[:, :20 * r]).max()),
                                "max_abs_mel_diff_all_%d_free_running_steps" % sample_steps: float(np.abs(got - mel_o).max())}
+        # the same check where it can fail: Glorot-initialised attention weights give a uniform softmax
+        # that hides the attention score; weights.sharpen_attention gives peaked, moving alignments.  24 free-running steps of
+        # the same batch, alignments included.
+        from tacotron2_amd.weights import sharpen_attention
+        w_s = sharpen_attention(w)
+        eng_s = Engine(d, w_s, device=local_rank)
+        S_s = 24
+        mem_s = O.encoder_v2(d, w_s, O.embedding_lookup(ids, w_s["embedding"]), lens)
+        mel_s, stop_s, st_s = O.decoder_v2(d, w_s, mem_s, memory_sequence_length=lens, max_iters=S_s)
+        al_s = np.stack(st_s[0].alignment_history, 0)
+        g_mel, g_stop, g_al, n_s = eng_s.decode_free(eng_s.encode(ids, lens), lens, max_iters=S_s)
+        out["parity_check"]["sharp_attention_%d_steps" % S_s] = {
+            "alignment_peak_mean": float(al_s.max(-1).mean()), "steps_equal": bool(n_s == S_s),
+            "persistent_kernel": bool(eng_s.get_stat("persist_launches") > 0),
+            "max_abs_alignment_diff": float(np.abs(g_al.cpu().numpy() - al_s).max()),
+            "max_abs_mel_diff": float(np.abs(g_mel.cpu().numpy() - mel_s).max()),
+            "max_abs_stop_diff": float(np.abs(g_stop.cpu().numpy() - stop_s).max())}
+        eng_s.close()
+        pc, ps = out["parity_check"], out["parity_check"]["sharp_attention_%d_steps" % S_s]
+        flat_ok = all(v < 1e-5 for k, v in pc.items() if k.startswith("max_abs"))
+        sharp_ok = ps["steps_equal"] and all(v < 2e-4 for k, v in ps.items() if k.startswith("max_abs"))
+        pc["asserted"] = {"random_init_all_diffs_below": 1e-5, "sharp_attention_all_diffs_below": 2e-4, "pass": bool(flat_ok and sharp_ok)}
+        parity_failed = not (flat_ok and sharp_ok)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -397,6 +410,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if parity_failed:                     # the line above is printed first so that the numbers that failed are on record
+        raise SystemExit("bench.py: parity_check failed: %s" % json.dumps(out["parity_check"]))
 
 
 if __name__ == "__main__":

@@ -100,6 +100,24 @@ def init_weights(d: T2Dims, seed: int = 1234, perturb: bool = False) -> Dict[str
     return w
 
 
+SHARP_GAINS = {"attention/attention_variable": 30.0, "attention/memory_layer/kernel": 3.0, "attention/query_layer/kernel": 3.0,
+               "attention/location_features_convolution/kernel": 3.0, "attention/location_features_layer/kernel": 3.0}
+
+
+def sharpen_attention(w: Dict[str, np.ndarray], gains: Dict[str, float] = None) -> Dict[str, np.ndarray]:
+    """A copy of ``w`` whose location-sensitive attention (tacotron_v2.py:66-78,118-141) is as peaked as a trained
+    model's.  Glorot-initialised attention weights give energies of ~0.1, i.e. a near-uniform softmax over T_in
+    positions (alignment max ~1/T_in): every term of the score then moves the alignments by less than any usable
+    tolerance and a parity test cannot see it.  Scaling ``attention_variable`` and the memory / query / location
+    kernels makes the energies span tens of units: alignments peak at 0.5..1.0, the arg-max moves from step to step
+    with the cumulative location features, and dropping any one term changes the alignments by O(1)
+    (tests/test_oracle_sensitivity.py holds that property on the oracle)."""
+    out = dict(w)
+    for name, g in (SHARP_GAINS if gains is None else gains).items():
+        out[name] = (w[name] * np.float32(g)).astype(np.float32)
+    return out
+
+
 def check_weights(d: T2Dims, w: Dict[str, np.ndarray]) -> None:
     shapes = weight_shapes(d)
     for name, shape in shapes.items():

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import t2_oracle as O                      # noqa: E402
 from tacotron2_amd.hparams import PROFILE_P, PROFILE_TINY, T2Dims      # noqa: E402
-from tacotron2_amd.weights import init_weights         # noqa: E402
+from tacotron2_amd.weights import init_weights, sharpen_attention         # noqa: E402
 
 MID = T2Dims(num_symbols=64, num_mels=20, outputs_per_step=2, n_feed_frame=2, attention_kernel=31,
              attention_filters=32, embedding_dim=64, enc_conv_layers=3, enc_kernel=5, enc_units=64,
@@ -55,6 +55,21 @@ def cases():
     out["paper_b1_teacher"] = (PROFILE_P, None, {          # weights: init_weights(PROFILE_P, 1235), made lazily (150 MB)
         "ids": idp, "lens": np.array([100]),
         "targets": rng.uniform(0, 1, (1, 800, 80)).astype(np.float32), "mode": "teacher", "weight_seed": 1235})
+    # the same case with a PEAKED attention (weights.sharpen_attention): with Glorot-initialised attention weights the
+    # alignments are uniform to ~1e-3 and no tolerance can see the terms of the score (tests/test_oracle_sensitivity.py)
+    out["paper_sharp_b1_teacher"] = (PROFILE_P, None, dict(out["paper_b1_teacher"][2], sharp=True))
+    # BASELINE.json configs[2] shape: B = 64 free-running rows, ragged T_in in 60..140, peaked attention, the stop
+    # projection tuned so that the batch-coupled rule (helpers.py:90-94) fires at a step in [24, 40)
+    rng = np.random.default_rng(1234 + 2)
+    lens = rng.integers(60, 141, size=64).astype(np.int64)
+    lens[7] = 140
+    ids = np.zeros((64, 140), np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n - 1] = rng.integers(32, 91, size=n - 1)
+        ids[b, n - 1] = 1
+    out["paper_sharp_b64_free"] = (PROFILE_P.replace(max_iters=40), None, {
+        "ids": ids, "lens": lens, "mode": "free", "weight_seed": 1236, "sharp": True, "perturb": True,
+        "stop_gain": 25.0, "stop_window": (24, 40)})
     return out
 
 
@@ -86,10 +101,16 @@ def tune_stop(d, w, memory, lens, lo, hi, min_gap=4e-3):
 def materialize(name, case):
     d, w, inp = case
     if w is None:
-        w = init_weights(d, inp["weight_seed"])
+        w = init_weights(d, inp["weight_seed"], perturb=inp.get("perturb", False))
+    if inp.get("sharp"):
+        w = sharpen_attention(w)
+    if "stop_gain" in inp:      # a random-init stop logit drifts by ~5e-3 per step at profile P: too little for a margin
+        w = dict(w)
+        w["decoder/stop_token_projection/kernel"] = (w["decoder/stop_token_projection/kernel"] * inp["stop_gain"]).astype(np.float32)
     if inp["mode"] == "free":
         memory = O.encoder_v2(d, w, O.embedding_lookup(inp["ids"], w["embedding"]), inp["lens"])
-        w, _ = tune_stop(d, w, memory, inp["lens"], 15, 36)
+        lo, hi = inp.get("stop_window", (15, 36))
+        w, _ = tune_stop(d, w, memory, inp["lens"], lo, hi, min_gap=inp.get("min_gap", 4e-3))
     return d, w, inp
 
 
@@ -100,16 +121,24 @@ def run_oracle(d, w, inp):
 
 
 def main():
+    only = set(sys.argv[1:])
     for name, case in cases().items():
+        if only and name not in only:
+            continue
         d, w, inp = materialize(name, case)
         ref = run_oracle(d, w, inp)
         path = os.path.join(HERE, name + ".npz")
-        np.savez_compressed(path, memory=ref["memory"].astype(np.float32), mel=ref["mel"], stop=ref["stop"],
+        rows = np.arange(ref["memory"].shape[0])
+        if ref["memory"].nbytes > (4 << 20):        # B = 64 at profile P: 18 MB of encoder output; keep a sample of the rows
+            rows = np.array([0, 7, 31, 63])
+        np.savez_compressed(path, memory=ref["memory"][rows].astype(np.float32), memory_rows=rows, mel=ref["mel"], stop=ref["stop"],
                             alignment=ref["alignment"], mel_postnet=ref["mel_postnet"], steps=np.int64(ref["steps"]),
                             weights_checksum=np.float64(weights_checksum(w)),
                             stop_bias=w["decoder/stop_token_projection/bias"],
                             stop_kernel=w["decoder/stop_token_projection/kernel"])
-        print(name, "steps", ref["steps"], "->", path, os.path.getsize(path) // 1024, "KiB")
+        peak = np.transpose(ref["alignment"], (2, 0, 1)).max(-1)          # [S, B]
+        print(name, "steps", ref["steps"], "alignment peak mean %.3f min %.3f" % (peak.mean(), peak.min()),
+              "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -9,24 +9,18 @@ pytestmark = pytest.mark.gpu
 from oracle import t2_oracle as O
 from tacotron2_amd.hparams import PROFILE_P
 from tacotron2_amd.weights import init_weights
+from tests.paper_cases import paper_case, train_case
 
 ATOL = 1e-3
 
 
 @pytest.fixture(scope="module")
 def paper():
+    """Peaked, moving attention (weights.sharpen_attention): tests/test_oracle_sensitivity.py shows on the oracle that every
+    term of the attention score moves these alignments by >= 10 x the tolerances used below."""
     from tacotron2_amd.engine import Engine
-    d = PROFILE_P
-    w = init_weights(d, seed=77, perturb=True)
+    d, w, ids, lens = paper_case(77, 64, sharp=True, full_row=5)
     eng = Engine(d, w)
-    rng = np.random.default_rng(64)
-    B = 64
-    lens = rng.integers(60, 141, size=B).astype(np.int64)
-    lens[5] = 140
-    T = int(lens.max())
-    ids = np.zeros((B, T), np.int64)
-    for b, n in enumerate(lens):
-        ids[b, :n] = rng.integers(32, 91, size=n)
     yield d, w, eng, ids, lens
     eng.close()
 
@@ -153,20 +147,8 @@ def test_training_gradients_at_bench_shape_against_autograd():
     from oracle import torch_train as TT
     from tacotron2_amd import training as TR
     from tacotron2_amd.engine import Engine
-    d = PROFILE_P
-    w = init_weights(d, seed=5, perturb=True)
-    rng = np.random.default_rng(1)
-    B, T, S, r = 32, 140, 4, d.outputs_per_step
-    ids = rng.integers(0, d.num_symbols, (B, T))
-    lens = rng.integers(60, T + 1, B).astype(np.int64)
-    lens[0] = T
-    tl = rng.integers(S * r // 2, S * r + 1, B)
-    tl[0] = S * r
-    sl = (tl + r - 1) // r
-    labels = {"mel": rng.uniform(0, 1, (B, S * r, d.num_mels)).astype(np.float32),
-              "done": (np.arange(S)[None, :] >= (sl[:, None] - 1)).astype(np.float32),
-              "spec_loss_mask": (np.arange(S * r)[None, :] < tl[:, None]).astype(np.float32),
-              "binary_loss_mask": (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)}
+    B, T, S = 32, 140, 4
+    d, w, ids, lens, labels = train_case(B, T, S)          # peaked attention: attention gradients >= 1e-5
     ref = TT.train_forward_backward(d, w, ids, lens, labels, seed=3, prenet_drop_rate=0.5, encoder_drop_rate=0.5)
     eng = Engine(d, w)
     tr = TR.Trainer(eng, B, T, S)
@@ -187,7 +169,9 @@ def test_training_gradients_at_bench_shape_against_autograd():
     for name, g_ref in sorted(ref["grads"].items()):
         scale = float(np.abs(g_ref).max())
         err = float(np.abs(grads[name] - g_ref).max())
-        if err > 1e-3 * scale + 1e-6:
+        if "moving_" not in name:
+            assert scale >= 1e-6, (name, scale)          # the absolute floor below is <= 1e-3 of every tensor's scale
+        if err > 2e-3 * scale + 1e-9:
             bad.append((name, err, scale))
     assert not bad, bad
     tr.close()
