@@ -100,8 +100,8 @@ def init_weights(d: T2Dims, seed: int = 1234, perturb: bool = False) -> Dict[str
     return w
 
 
-SHARP_GAINS = {"attention/attention_variable": 30.0, "attention/memory_layer/kernel": 3.0, "attention/query_layer/kernel": 3.0,
-               "attention/location_features_convolution/kernel": 3.0, "attention/location_features_layer/kernel": 3.0}
+SHARP_GAINS = {"attention/attention_variable": 40.0, "attention/memory_layer/kernel": 3.0, "attention/query_layer/kernel": 3.0,
+               "attention/location_features_convolution/kernel": 1.5, "attention/location_features_layer/kernel": 1.5}
 
 
 def sharpen_attention(w: Dict[str, np.ndarray], gains: Dict[str, float] = None) -> Dict[str, np.ndarray]:
@@ -110,8 +110,12 @@ def sharpen_attention(w: Dict[str, np.ndarray], gains: Dict[str, float] = None) 
     positions (alignment max ~1/T_in): every term of the score then moves the alignments by less than any usable
     tolerance and a parity test cannot see it.  Scaling ``attention_variable`` and the memory / query / location
     kernels makes the energies span tens of units: alignments peak at 0.5..1.0, the arg-max moves from step to step
-    with the cumulative location features, and dropping any one term changes the alignments by O(1)
-    (tests/test_oracle_sensitivity.py holds that property on the oracle)."""
+    with the cumulative location features, and dropping any one term changes the alignments by O(0.1 .. 1)
+    (tests/test_oracle_sensitivity.py holds that property on the oracle).  The gains are chosen so that the recurrence
+    stays well conditioned: with 3 x 3 on the location path (instead of 1.5 x 1.5) the cumulative-state feedback
+    amplifies rounding noise ~3.5 x per decoder step (fp32 and fp64 runs of the ORACLE differ by 7e-4 after 7 steps),
+    and no tolerance means anything; with these gains the oracle's own fp32-vs-fp64 difference stays ~1e-5 over tens
+    of steps (same test file)."""
     out = dict(w)
     for name, g in (SHARP_GAINS if gains is None else gains).items():
         out[name] = (w[name] * np.float32(g)).astype(np.float32)

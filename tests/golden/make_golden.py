@@ -120,6 +120,24 @@ def run_oracle(d, w, inp):
     return O.tacotron2_forward(d, w, inp["ids"], inp["lens"], mode="predict")
 
 
+def fp64_noise(d, w, inp, ref):
+    """Conditioning record of a fixture: the oracle re-run in float64 (same code, O.F32 swapped) and the per-decoder-step
+    max |fp32 - fp64| of alignments, mel and stop.  A peaked attention with cumulative location feedback has windows in
+    which rounding noise is amplified ~100 x (and decays again); a test tolerance must sit above this floor there."""
+    O.F32 = np.float64
+    try:
+        r64 = run_oracle(d, {k: v.astype(np.float64) for k, v in w.items()}, inp)
+    finally:
+        O.F32 = np.float32
+    S = ref["steps"]
+    assert r64["steps"] == S
+    B, r = ref["mel"].shape[0], d.outputs_per_step
+    a = np.abs(ref["alignment"] - r64["alignment"]).max((0, 1))
+    m = np.abs(ref["mel"] - r64["mel"]).reshape(B, S, -1).max((0, 2))
+    st = np.abs(ref["stop"] - r64["stop"]).reshape(B, S).max(0)
+    return a.astype(np.float32), m.astype(np.float32), st.astype(np.float32)
+
+
 def main():
     only = set(sys.argv[1:])
     for name, case in cases().items():
@@ -128,6 +146,12 @@ def main():
         d, w, inp = materialize(name, case)
         ref = run_oracle(d, w, inp)
         path = os.path.join(HERE, name + ".npz")
+        extra = {}
+        if inp.get("sharp"):
+            a_n, m_n, s_n = fp64_noise(d, w, inp, ref)
+            extra = {"alignment_noise": a_n, "mel_noise": m_n, "stop_noise": s_n}
+            print("   fp32-vs-fp64 noise of the oracle: alignment max %.1e median %.1e, mel max %.1e, stop max %.1e"
+                  % (a_n.max(), np.median(a_n), m_n.max(), s_n.max()))
         rows = np.arange(ref["memory"].shape[0])
         if ref["memory"].nbytes > (4 << 20):        # B = 64 at profile P: 18 MB of encoder output; keep a sample of the rows
             rows = np.array([0, 7, 31, 63])
@@ -135,7 +159,7 @@ def main():
                             alignment=ref["alignment"], mel_postnet=ref["mel_postnet"], steps=np.int64(ref["steps"]),
                             weights_checksum=np.float64(weights_checksum(w)),
                             stop_bias=w["decoder/stop_token_projection/bias"],
-                            stop_kernel=w["decoder/stop_token_projection/kernel"])
+                            stop_kernel=w["decoder/stop_token_projection/kernel"], **extra)
         peak = np.transpose(ref["alignment"], (2, 0, 1)).max(-1)          # [S, B]
         print(name, "steps", ref["steps"], "alignment peak mean %.3f min %.3f" % (peak.mean(), peak.min()),
               "->", path, os.path.getsize(path) // 1024, "KiB")

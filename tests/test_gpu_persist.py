@@ -21,6 +21,10 @@ def paper(request):
     d, w, ids, lens = paper_case(91, 65, sharp=(request.param == "sharp"))
     eng = Engine(d, w)
     memory_o = O.encoder_v2(d, w, O.embedding_lookup(ids, w["embedding"]), lens)
+    # HIP-vs-HIP comparisons (two schedules of the same fp32 arithmetic, different summation orders): with a peaked attention
+    # the recurrence amplifies rounding differences to ~1e-5 within tens of steps (the oracle's own fp32-vs-fp64 difference
+    # on these weights, weights.sharpen_attention), with the near-uniform one they stay ~1e-7
+    eng.twin_atol = (1e-4, 1e-4) if request.param == "sharp" else (1e-4, 1e-5)          # (mel / stop, alignments)
     yield d, w, eng, memory_o, lens
     eng.close()
 
@@ -60,9 +64,9 @@ def test_persistent_equals_launch_schedule(paper, B):
     eng.set_option("persist", 1)
     mel1, stop1, align1, n1 = eng.decode_free(mem, lens[:B], max_iters=S, min_iters=100)
     assert n0 == n1 == S
-    np.testing.assert_allclose(_np(mel1), mel0, atol=1e-4)
-    np.testing.assert_allclose(_np(stop1), stop0, atol=1e-4)
-    np.testing.assert_allclose(_np(align1), align0, atol=1e-5)
+    np.testing.assert_allclose(_np(mel1), mel0, atol=eng.twin_atol[0])
+    np.testing.assert_allclose(_np(stop1), stop0, atol=eng.twin_atol[0])
+    np.testing.assert_allclose(_np(align1), align0, atol=eng.twin_atol[1])
 
 
 @pytest.mark.parametrize("B", [1, 64])
@@ -135,9 +139,9 @@ def test_persistent_teacher_forced_against_oracle_and_launch_schedule(paper, B):
     eng.set_option("persist", 0)
     mel0, stop0, align0 = eng.decode_teacher(mem, lens[:B], target, teacher_forcing=True)
     eng.set_option("persist", 1)
-    np.testing.assert_allclose(mel1, _np(mel0), atol=1e-4)
-    np.testing.assert_allclose(stop1, _np(stop0), atol=1e-4)
-    np.testing.assert_allclose(align1, _np(align0), atol=1e-5)
+    np.testing.assert_allclose(mel1, _np(mel0), atol=eng.twin_atol[0])
+    np.testing.assert_allclose(stop1, _np(stop0), atol=eng.twin_atol[0])
+    np.testing.assert_allclose(align1, _np(align0), atol=eng.twin_atol[1])
 
 
 def test_persistent_decode_after_a_device_side_parameter_refresh():
