@@ -55,7 +55,7 @@ def test_hip_matches_golden(name):
         # per decoder step (make_golden.fp64_noise: up to 8.6e-4 in one window of the 400-step case, ~5e-6 elsewhere) and the
         # tolerance of a step is ATOL + 4 x that floor.  Measured on MI355X: the HIP error is 1.1 .. 1.7 x the floor in the window.
         peak = np.transpose(gold["alignment"], (2, 0, 1)).max(-1)
-        assert peak.max() > 0.9 and peak.mean() > 0.4 and len(set(gold["alignment"][0].argmax(0).tolist())) > 3
+        assert peak.max() > 0.8 and peak.mean() > 0.4 and len(set(gold["alignment"][0].argmax(0).tolist())) >= 3
         S = int(gold["steps"])
         err = np.abs(_np(align) - gold["alignment"]).max((0, 1))
         assert (err <= ATOL + 4 * gold["alignment_noise"]).all(), (name, "alignment", float(err.max()))
