@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -136,6 +137,13 @@ struct t2_model {
     unsigned long long n_bwd_persist = 0;
     int opt_bwd_splitk = 1;             // training backward: K = 4H data-gradient GEMMs split in two halves over the grid (train_step.h)
     int opt_persist = 1;                // free-running decodes of the paper-size dimension class run as ONE persistent launch (persist.h)
+    // a persistent launch whose hand-off waits ran out of time (its workgroups were not all resident: another process holds
+    // part of the GPU) is re-run with the launch-per-phase schedule; the next persist_holdoff decodes skip the persistent kernels
+    long long n_persist_timeouts = 0;   // stat "persist_timeouts"
+    int persist_holdoff = 0;
+    int opt_inject_timeout = 0;         // tests: the next N persistent launches get their error word set after the launch
+    // arguments of the free-running decode in flight (t2_decode_free_launch -> t2_decode_free_finish may have to re-run it)
+    int pend_max_iters = 0, pend_min_iters = 0;
 };
 
 struct t2_state {
@@ -178,6 +186,49 @@ struct t2_state {
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------
+// Kernels whose workgroups wait for each other (persist.h, persist_bwd.h) need ALL their workgroups resident at once.  One
+// such kernel owns the chip (one workgroup per CU), but two of them dispatched at the same moment from two streams could
+// each get part of the CUs and spin until the hand-off timeout.  Within this process they are therefore serialised per
+// device ON THE DEVICE: every such launch waits (hipStreamWaitEvent, no host synchronisation) for the previous one's
+// completion event when that ran on another stream.  Other processes on the same GPU cannot be seen from here: that case
+// is caught by the kernels' bounded waits and the launch-per-phase re-run (persist_timed_out).
+// ------------------------------------------------------------------------------------------------
+struct XwgGateDev { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool armed = false; };
+static std::mutex g_xwg_mu;
+static XwgGateDev g_xwg[64];
+struct XwgGate {                 // RAII: begin() before the launch, the destructor records the launch's completion event
+    t2_ctx* c = nullptr;
+    bool held = false;
+    int begin(t2_ctx* ctx) {
+        c = ctx;
+        g_xwg_mu.lock();
+        held = true;
+        XwgGateDev& g = g_xwg[c->device & 63];
+        if (!g.ev) HIP_TRY(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+        if (g.armed && g.last != c->stream) HIP_TRY(hipStreamWaitEvent(c->stream, g.ev, 0));
+        return T2_OK;
+    }
+    ~XwgGate() {
+        if (!held) return;
+        XwgGateDev& g = g_xwg[c->device & 63];
+        if (g.ev && hipEventRecord(g.ev, c->stream) == hipSuccess) { g.last = c->stream; g.armed = true; }
+        g_xwg_mu.unlock();
+    }
+};
+
+struct LensArg { int v[64]; };
+__global__ void set_lens_kernel(LensArg a, int* __restrict__ lens, int B) {
+    if ((int)threadIdx.x < B) lens[threadIdx.x] = a.v[threadIdx.x];
+}
+__global__ void set_ctl_kernel(int* __restrict__ ctl, int max_steps, int min_iters, int stop_enabled) {
+    if (threadIdx.x < 8) ctl[threadIdx.x] = threadIdx.x == 2 ? max_steps : threadIdx.x == 3 ? min_iters : threadIdx.x == 4 ? stop_enabled : 0;
+}
+
+// tests: option inject_timeout = N marks the next N persistent launches as timed out (sets the word the kernel would set)
+static int inject_timeout(t2_model* m, int* err_word);
+static void note_persist_timeout(t2_model* m);
 
 static inline void launch_lstm_splitk(int MB, int n_wg4, hipStream_t st, const SkinnyCore& c, const LstmEpi& e, unsigned* tickets,
                                       unsigned long long* slabs) {
@@ -427,7 +478,8 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
         m->opt_lstm_only = value;
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
-    else if (!strcmp(name, "persist")) m->opt_persist = value;
+    else if (!strcmp(name, "persist")) { m->opt_persist = value; m->persist_holdoff = 0; }
+    else if (!strcmp(name, "inject_timeout")) m->opt_inject_timeout = value;
     else if (!strcmp(name, "bwd_splitk")) m->opt_bwd_splitk = value;
     else if (!strcmp(name, "bwd_persist")) m->opt_bwd_persist = value;
     else if (!strcmp(name, "conv_mi")) m->opt_conv_mi = value;
@@ -982,7 +1034,7 @@ static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, con
     HIP_TRY(hipMemcpyAsync(ctl, h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, st));
     const int hsz = MB * 16 * KPh;
     // the whole recurrence as ONE launch (persist.h encoder_kernel): paper-size class only (512 inputs, 256 units per direction)
-    const bool enc_persist = m->opt_enc_persist && Cx == 512 && He == 256 && KPh == 256 && m->n_cu >= 2 * pz::ENC_G &&
+    const bool enc_persist = m->opt_enc_persist && m->persist_holdoff == 0 && Cx == 512 && He == 256 && KPh == 256 && m->n_cu >= 2 * pz::ENC_G &&
                              m->enc_lstm[0].n_wg == pz::ENC_G && m->enc_lstm[0].kbtot == 48 && 2LL * T * per_step_c * 4 < 0x7fffffffLL;
     if (enc_persist) {
         pz::EArgs a{};
@@ -993,16 +1045,26 @@ static int encode_impl(t2_model* m, const int64_t* ids, const float* emb_in, con
         a.lens = d_lens; a.out = memory_out; a.B = B; a.T = T;
         a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
         const dim3 grid(2 * pz::ENC_G), blk(pz::NT);
-        if (MB == 1) hipLaunchKernelGGL(pz::encoder_kernel<1>, grid, blk, 0, st, a);
-        else if (MB == 2) hipLaunchKernelGGL(pz::encoder_kernel<2>, grid, blk, 0, st, a);
-        else hipLaunchKernelGGL(pz::encoder_kernel<4>, grid, blk, 0, st, a);
-        HIP_TRY(hipGetLastError());
+        {
+            XwgGate gate;
+            T2_TRY(gate.begin(m->ctx));
+            if (MB == 1) hipLaunchKernelGGL(pz::encoder_kernel<1>, grid, blk, 0, st, a);
+            else if (MB == 2) hipLaunchKernelGGL(pz::encoder_kernel<2>, grid, blk, 0, st, a);
+            else hipLaunchKernelGGL(pz::encoder_kernel<4>, grid, blk, 0, st, a);
+            HIP_TRY(hipGetLastError());
+        }
+        T2_TRY(inject_timeout(m, a.err));
+        ++m->n_enc_persist;
+        // the error word decides between "done" and "run it again launch per step": one host synchronisation per encode
         int h_err = 0;
         HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (h_err) return fail(T2_EHIP, "persistent encoder: a hand-off wait ran out of time (workgroups not co-resident?); outputs are invalid");
-        ++m->n_enc_persist;
-        return T2_OK;
+        if (!h_err) return T2_OK;
+        // a hand-off wait ran out of time (the 128 workgroups were not all resident): same recurrence, one launch per step
+        note_persist_timeout(m);
+        HIP_TRY(hipMemsetAsync(ws + o_zero, 0, zero_bytes, st));
+        HIP_TRY(hipMemsetAsync(memory_out, 0, (size_t)Mtot * E * 4, st));
+        HIP_TRY(hipMemcpyAsync(ctl, h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, st));
     }
     for (int s = 0; s < T; ++s) {
         SkinnyCore c{};
@@ -1189,14 +1251,14 @@ static int state_init(t2_state* s, const float* memory, const int64_t* lens) {
     const t2_dims& d = m->d;
     hipStream_t st = m->ctx->stream;
     const int B = s->B, T = s->T, E = d.enc_units;
-    std::vector<int> h_lens(B);
+    LensArg la{};                        // B <= 64 (check_batch): the lengths travel as a kernel argument, no host round trip
+    if (B > 64) return fail(T2_EINVAL, "internal: batch of %d rows", B);
     for (int b = 0; b < B; ++b) {
         const int64_t l = lens ? lens[b] : T;
         if (l < 1 || l > T) return fail(T2_EINVAL, "memory_sequence_length %lld outside 1..%d", (long long)l, T);
-        h_lens[b] = (int)l;
+        la.v[b] = (int)l;
     }
-    HIP_TRY(hipMemcpyAsync(s->lens, h_lens.data(), B * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));   // h_lens is a host temporary
+    hipLaunchKernelGGL(set_lens_kernel, dim3(1), dim3(64), 0, st, la, s->lens, B);
     const long long n = (long long)B * T * E;
     hipLaunchKernelGGL(mask_memory_kernel, dim3((unsigned)std::min<long long>(2048, (n + 255) / 256)), dim3(256), 0, st,
                        memory, s->lens, s->values, B, T, E);
@@ -1207,10 +1269,8 @@ static int state_init(t2_state* s, const float* memory, const int64_t* lens) {
 static int state_zero(t2_state* s, int max_steps, int min_iters, int stop_enabled) {
     hipStream_t st = s->m->ctx->stream;
     HIP_TRY(hipMemsetAsync(s->slab, 0, s->slab_bytes, st));
-    int* h = s->m->h_ctl;
-    HIP_TRY(hipStreamSynchronize(st));   // pinned mirror may still be in use by an earlier copy
-    h[0] = 0; h[1] = 0; h[2] = max_steps; h[3] = min_iters; h[4] = stop_enabled; h[5] = h[6] = h[7] = 0;
-    HIP_TRY(hipMemcpyAsync(s->ctl, h, 8 * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(64), 0, st, s->ctl, max_steps, min_iters, stop_enabled);
+    HIP_TRY(hipGetLastError());
     return T2_OK;
 }
 
@@ -1772,13 +1832,14 @@ static int run_chunk(t2_state* s, int mode) {
 // Free-running decode (the helper feeds the model's own output back: helpers.py:86, :135-136) as ONE persistent launch.
 static inline bool persist_mode(const t2_state* s) {
     const t2_model* m = s->m;
-    return m->opt_persist && s->pz_xs != nullptr && m->proj_fused_ok && m->opt_projfuse && !m->opt_lstm_only;
+    return m->opt_persist && m->persist_holdoff == 0 && s->pz_xs != nullptr && m->proj_fused_ok && m->opt_projfuse && !m->opt_lstm_only;
 }
 // Teacher-forced decode as one persistent launch: PreNets of all steps before it (teacher_prenets), projections after it
 // (teacher_projection); needs neither the composed projection nor the stop rule.
 static inline bool persist_mode_teacher(const t2_state* s) {
     const t2_model* m = s->m;
-    return m->opt_persist && m->opt_tfproj && s->pz_xs != nullptr && s->tf_frag != nullptr && s->y_all != nullptr && !m->opt_lstm_only;
+    return m->opt_persist && m->persist_holdoff == 0 && m->opt_tfproj && s->pz_xs != nullptr && s->tf_frag != nullptr && s->y_all != nullptr &&
+           !m->opt_lstm_only;
 }
 struct TrainTape;
 static void persist_fill_tape(pz::PTape& tp, const TrainTape* tape);
@@ -1823,6 +1884,8 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     const size_t lds = persist_lds_bytes(s->B, s->T);
     const dim3 grid(pz::NWG), blk(pz::NT);
     const int mode = teacher ? (tape ? 2 : 1) : 0;        // pz::decode_kernel's MODE
+    XwgGate gate;
+    T2_TRY(gate.begin(m->ctx));
 #define T2_PZ_LAUNCH(MBv) do { \
         if (mode == 0) hipLaunchKernelGGL((pz::decode_kernel<MBv, 0>), grid, blk, lds, st, a, x); \
         else if (mode == 1) hipLaunchKernelGGL((pz::decode_kernel<MBv, 1>), grid, blk, lds, st, a, x); \
@@ -1833,6 +1896,28 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
 #undef T2_PZ_LAUNCH
     HIP_TRY(hipGetLastError());
     ++m->n_persist;
+    return inject_timeout(m, s->ctl + 5);
+}
+
+static int inject_timeout(t2_model* m, int* err_word) {
+    if (m->opt_inject_timeout <= 0) return T2_OK;
+    --m->opt_inject_timeout;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)err_word, 1, 1, m->ctx->stream));
+    return T2_OK;
+}
+
+// After a persistent launch: did one of its hand-off waits run out of time (ctl[5] / ctl[6], set by every workgroup that gave
+// up)?  Synchronises the stream.  A timeout is counted and switches the next 16 decodes of this model to the launch-per-phase
+// schedule; the caller re-runs the decode it just tried with that schedule, so no invalid buffer is ever handed back.
+static void note_persist_timeout(t2_model* m) { ++m->n_persist_timeouts; m->persist_holdoff = 16; }
+static inline void holdoff_tick(t2_model* m) { if (m->persist_holdoff > 0) --m->persist_holdoff; }
+static int persist_timed_out(t2_state* s, bool* timed_out) {
+    hipStream_t st = s->m->ctx->stream;
+    int* h = s->m->h_ctl;
+    HIP_TRY(hipMemcpyAsync(h, s->ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *timed_out = h[5] != 0 || h[6] != 0;
+    if (*timed_out) note_persist_timeout(s->m);
     return T2_OK;
 }
 
@@ -1852,24 +1937,32 @@ extern "C" int t2_decode_teacher(t2_model* m, const float* memory, const int64_t
     hipStream_t st = m->ctx->stream;
     const int S = T_out / r;
     t2_state* s = nullptr;
+    holdoff_tick(m);
     T2_TRY(get_loop_state(m, B, T_in, S, &s));
     T2_TRY(state_init(s, memory, lens));
-    T2_TRY(state_zero(s, S, 0, 0));
     HIP_TRY(hipMemcpyAsync(s->i_targets, targets, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
     const int mode = teacher_forcing ? 0 : 1;
-    if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
-    if (teacher_forcing && m->opt_tfproj) T2_TRY(teacher_projection_buffers(s, true));
-    const bool persist_tf = teacher_forcing && persist_mode_teacher(s);
-    const bool persist = persist_tf || (!teacher_forcing && persist_mode(s));
-    m->last_loop = s; m->last_persist = persist;
-    if (persist) T2_TRY(persist_decode(s, S, 0, 0, persist_tf));
-    else T2_TRY(decode_prologue(s, mode));
-    const bool deferred = persist_tf || (!persist && loop_io(s, mode).defer_proj != 0);
-    for (int done = 0; !persist && done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
-    if (deferred) T2_TRY(teacher_projection(s, s->y_all, s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
-    HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(align, s->o_hist, (size_t)S * B * T_in * 4, hipMemcpyDeviceToDevice, st));
+    // one pass of the loop; a persistent launch that timed out is followed by a second pass on the launch-per-phase schedule
+    for (int pass = 0; pass < 2; ++pass) {
+        T2_TRY(state_zero(s, S, 0, 0));
+        if (teacher_forcing) T2_TRY(teacher_prenets(s, 0.f, 0));
+        if (teacher_forcing && m->opt_tfproj) T2_TRY(teacher_projection_buffers(s, true));
+        const bool persist_tf = teacher_forcing && persist_mode_teacher(s);
+        const bool persist = persist_tf || (!teacher_forcing && persist_mode(s));
+        m->last_loop = s; m->last_persist = persist;
+        if (persist) T2_TRY(persist_decode(s, S, 0, 0, persist_tf));
+        else T2_TRY(decode_prologue(s, mode));
+        const bool deferred = persist_tf || (!persist && loop_io(s, mode).defer_proj != 0);
+        for (int done = 0; !persist && done < S; done += m->opt_chunk) T2_TRY(run_chunk(s, mode));
+        if (deferred) T2_TRY(teacher_projection(s, s->y_all, s->o_mel, (long long)s->cap * r * M, s->o_stop, s->cap));
+        HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * T_out * M * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(align, s->o_hist, (size_t)S * B * T_in * 4, hipMemcpyDeviceToDevice, st));
+        if (!persist) break;
+        bool timed_out = false;
+        T2_TRY(persist_timed_out(s, &timed_out));          // the one host synchronisation of this call (persistent schedule only)
+        if (!timed_out) break;
+    }
     return T2_OK;
 }
 
@@ -1882,6 +1975,7 @@ static int free_prepare(t2_model* m, const float* memory, const int64_t* lens, i
     if (m->pending) return fail(T2_ESTATE, "a free-running decode is already in flight; call t2_decode_free_finish");
     HIP_TRY(hipSetDevice(m->ctx->device));
     t2_state* s = nullptr;
+    holdoff_tick(m);
     T2_TRY(get_loop_state(m, B, T_in, max_iters, &s));
     T2_TRY(state_init(s, memory, lens));
     T2_TRY(state_zero(s, max_iters, min_iters, 1));
@@ -1900,51 +1994,22 @@ static int free_copy_out(t2_state* s, float* mel, float* stop, float* align) {
     return T2_OK;
 }
 
-static int read_steps(t2_state* s, int* steps_out) {
+static int read_steps(t2_state* s, int* steps_out, bool* timed_out) {
     hipStream_t st = s->m->ctx->stream;
     int* h = s->m->h_ctl;
     HIP_TRY(hipMemcpyAsync(h, s->ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *steps_out = h[CTL_FINAL] != 0 ? h[CTL_FINAL] : h[CTL_MAX];
-    if (h[5] != 0 || h[6] != 0) return fail(T2_EHIP, "persistent decoder: a hop timed out (workgroups not co-resident?); outputs are invalid");
+    *timed_out = h[5] != 0 || h[6] != 0;
+    if (*timed_out) note_persist_timeout(s->m);
     return T2_OK;
 }
 
-extern "C" int t2_decode_free_launch(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
-                                     int max_iters, int min_iters, float* mel, float* stop, float* align) {
-    t2_state* s = nullptr;
-    T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
-    if (persist_mode(s)) T2_TRY(persist_decode(s, max_iters, min_iters, 1));
-    else {
-        T2_TRY(decode_prologue(s, 1));
-        for (int done = 0; done < max_iters; done += m->opt_chunk) T2_TRY(run_chunk(s, 1));
-    }
-    T2_TRY(free_copy_out(s, mel, stop, align));
-    m->pending = s;
-    return T2_OK;
-}
-
-extern "C" int t2_decode_free_finish(t2_model* m, int* steps_out) {
-    if (!m || !steps_out) return fail(T2_EINVAL, "null argument");
-    if (!m->pending) return fail(T2_ESTATE, "no free-running decode in flight");
-    t2_state* s = m->pending;
-    m->pending = nullptr;
-    return read_steps(s, steps_out);
-}
-
-extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
-                              int max_iters, int min_iters, float* mel, float* stop, float* align, int* steps_out) {
-    if (!steps_out) return fail(T2_EINVAL, "steps_out is null");
-    t2_state* s = nullptr;
-    T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
-    if (persist_mode(s)) {
-        T2_TRY(persist_decode(s, max_iters, min_iters, 1));
-        T2_TRY(free_copy_out(s, mel, stop, align));
-        return read_steps(s, steps_out);
-    }
+// The free-running loop on the launch-per-phase schedule: hipGraph chunks enqueued two ahead of the host's view of the finished
+// flag (chunks after the stop step are no-ops on the device, so over-enqueueing is harmless and the host never stalls the GPU).
+static int free_loop_launches(t2_state* s, int max_iters, float* mel, float* stop, float* align, int* steps_out) {
+    t2_model* m = s->m;
     hipStream_t st = m->ctx->stream;
-    // chunks are enqueued two ahead of the host's view of the finished flag: chunks after the stop
-    // step are no-ops on the device, so over-enqueueing is harmless and the host never stalls the GPU.
     hipEvent_t* ev = m->flag_ev;          // created once per model (t2_model_finalize), as is the pinned mirror
     int* h_flag = m->h_flag;
     int rc = decode_prologue(s, 1), n = 0;
@@ -1959,10 +2024,61 @@ extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* l
         hipMemcpyAsync(h_flag + (n & 1) * 8, s->ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, st);
         hipEventRecord(ev[n & 1], st);
     }
+    bool unused = false;
     if (rc == T2_OK) rc = free_copy_out(s, mel, stop, align);
-    if (rc == T2_OK) rc = read_steps(s, steps_out);
+    if (rc == T2_OK) rc = read_steps(s, steps_out, &unused);
     hipStreamSynchronize(st);
     return rc;
+}
+
+// A persistent free-running decode whose hand-off waits ran out of time: the same decode again, launch per phase (the
+// attention constructor's side effects -- values, keys, lengths -- are still in the state; only the loop state is re-zeroed).
+static int free_rerun_after_timeout(t2_state* s, int max_iters, int min_iters, float* mel, float* stop, float* align, int* steps_out) {
+    T2_TRY(state_zero(s, max_iters, min_iters, 1));
+    s->m->last_persist = false;
+    return free_loop_launches(s, max_iters, mel, stop, align, steps_out);
+}
+
+extern "C" int t2_decode_free_launch(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
+                                     int max_iters, int min_iters, float* mel, float* stop, float* align) {
+    t2_state* s = nullptr;
+    T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
+    if (persist_mode(s)) T2_TRY(persist_decode(s, max_iters, min_iters, 1));
+    else {
+        T2_TRY(decode_prologue(s, 1));
+        for (int done = 0; done < max_iters; done += m->opt_chunk) T2_TRY(run_chunk(s, 1));
+    }
+    T2_TRY(free_copy_out(s, mel, stop, align));
+    m->pending = s;
+    m->pend_mel = mel; m->pend_stop = stop; m->pend_align = align; m->pend_max_iters = max_iters; m->pend_min_iters = min_iters;
+    return T2_OK;
+}
+
+extern "C" int t2_decode_free_finish(t2_model* m, int* steps_out) {
+    if (!m || !steps_out) return fail(T2_EINVAL, "null argument");
+    if (!m->pending) return fail(T2_ESTATE, "no free-running decode in flight");
+    t2_state* s = m->pending;
+    m->pending = nullptr;
+    bool timed_out = false;
+    T2_TRY(read_steps(s, steps_out, &timed_out));
+    if (timed_out) return free_rerun_after_timeout(s, m->pend_max_iters, m->pend_min_iters, m->pend_mel, m->pend_stop, m->pend_align, steps_out);
+    return T2_OK;
+}
+
+extern "C" int t2_decode_free(t2_model* m, const float* memory, const int64_t* lens, int B, int T_in,
+                              int max_iters, int min_iters, float* mel, float* stop, float* align, int* steps_out) {
+    if (!steps_out) return fail(T2_EINVAL, "steps_out is null");
+    t2_state* s = nullptr;
+    T2_TRY(free_prepare(m, memory, lens, B, T_in, max_iters, min_iters, mel, stop, align, &s));
+    if (persist_mode(s)) {
+        T2_TRY(persist_decode(s, max_iters, min_iters, 1));
+        T2_TRY(free_copy_out(s, mel, stop, align));
+        bool timed_out = false;
+        T2_TRY(read_steps(s, steps_out, &timed_out));
+        if (timed_out) return free_rerun_after_timeout(s, max_iters, min_iters, mel, stop, align, steps_out);
+        return T2_OK;
+    }
+    return free_loop_launches(s, max_iters, mel, stop, align, steps_out);
 }
 
 #ifdef PZ_STAMPS
@@ -1975,6 +2091,7 @@ extern "C" int t2_debug_stamps(unsigned long long* out) {     // diagnostic buil
 extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
     if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "persist_launches")) { *out = (double)m->n_persist; return T2_OK; }
+    if (!strcmp(name, "persist_timeouts")) { *out = (double)m->n_persist_timeouts; return T2_OK; }
     if (!strcmp(name, "enc_persist_launches")) { *out = (double)m->n_enc_persist; return T2_OK; }
     if (!strcmp(name, "bwd_persist_launches")) { *out = (double)m->n_bwd_persist; return T2_OK; }
     if (!strcmp(name, "lstm_launches")) { *out = (double)(g_timer.used / 2); return T2_OK; }

@@ -838,7 +838,7 @@ static int pzb_setup(t2_trainer* tr) {
     return T2_OK;
 }
 // the whole reverse-time recurrence as one launch; fills the same tape buffers as the launch-per-phase loop
-static int pzb_launch(t2_trainer* tr) {
+static int pzb_launch(t2_trainer* tr, bool* timed_out) {
     t2_model* m = tr->m;
     const t2_dims& d = m->d;
     hipStream_t st = m->ctx->stream;
@@ -866,16 +866,24 @@ static int pzb_launch(t2_trainer* tr) {
     a.inv_keep = 1.0f / (1.0f - tp.prenet_drop_rate);
     const size_t lds = (size_t)pz::bwd_lds_floats(MB, T, a.CH) * 4;
     const dim3 grid(pz::NWG), blk(pz::NT);
-    if (MB == 1) hipLaunchKernelGGL((pz::backward_kernel<1>), grid, blk, lds, st, a);
-    else if (MB == 2) hipLaunchKernelGGL((pz::backward_kernel<2>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((pz::backward_kernel<4>), grid, blk, lds, st, a);
-    HIP_TRY(hipGetLastError());
+    {
+        XwgGate gate;
+        T2_TRY(gate.begin(m->ctx));
+        if (MB == 1) hipLaunchKernelGGL((pz::backward_kernel<1>), grid, blk, lds, st, a);
+        else if (MB == 2) hipLaunchKernelGGL((pz::backward_kernel<2>), grid, blk, lds, st, a);
+        else hipLaunchKernelGGL((pz::backward_kernel<4>), grid, blk, lds, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    T2_TRY(inject_timeout(m, a.err));
     ++m->n_bwd_persist;
-    // a hop that ran out of time leaves garbage gradients: fail loudly (the caller reads the loss after this call anyway)
+    // a hop that ran out of time leaves garbage gradients: the caller then runs the launch-per-phase recurrence instead (it
+    // rewrites every tape buffer this kernel touched); the caller reads the loss after this call anyway, so the
+    // synchronisation costs nothing extra
     int h_err = 0;
     HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (h_err) return fail(T2_EHIP, "persistent backward: a grid-wide hop timed out");
+    *timed_out = h_err != 0;
+    if (h_err) note_persist_timeout(m);
     return T2_OK;
 }
 
@@ -949,10 +957,13 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     hipStream_t st = m->ctx->stream;
     const int B = tr->B, T_in = tr->T, S = tr->S, M = d.num_mels, r = d.outputs_per_step;
     t2_state* s = tr->state;
+    holdoff_tick(m);
     T2_TRY(state_init(s, memory, lens));
-    T2_TRY(state_zero(s, S, 0, 0));
     HIP_TRY(hipMemcpyAsync(s->i_targets, targets, (size_t)B * S * r * M * 4, hipMemcpyDeviceToDevice, st));
     tr->tape.seed = seed; tr->tape.prenet_drop_rate = prenet_drop_rate;
+    // one pass; a persistent launch whose hand-off waits ran out of time is followed by a second pass, one launch per phase
+    for (int pass = 0; pass < 2; ++pass) {
+    T2_TRY(state_zero(s, S, 0, 0));
     // TrainingHelper feeds known frames, so the PreNets of all S steps run as batched GEMMs over S*B rows (tape rows
     // xp[i][t][b][:]), followed by the sampled dropout; the last layer also lands as the per-step frag16 operands.
     T2_TRY(teacher_prenets(s, prenet_drop_rate, seed, tr->tape.xp));
@@ -962,8 +973,8 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     io.y_all = nullptr;                            // the tape keeps LSTM 2's raw output of every step (hraw[2])
     io.slot_hint = 1;                              // the control block's base stays 0: step t runs as step_off = t
     // the whole teacher-forced recurrence as ONE persistent launch (persist.h, teacher mode + tape), else one launch per phase
-    const bool persist = m->opt_persist && m->opt_tfproj && s->pz_xs != nullptr && s->tf_frag != nullptr && s->proj_tmp != nullptr &&
-                         !m->opt_lstm_only && tr->tape.hraw[2] != nullptr;
+    const bool persist = m->opt_persist && m->persist_holdoff == 0 && m->opt_tfproj && s->pz_xs != nullptr && s->tf_frag != nullptr &&
+                         s->proj_tmp != nullptr && !m->opt_lstm_only && tr->tape.hraw[2] != nullptr;
     m->last_loop = s; m->last_persist = persist;   // t2_decode_final_state reads the trainer's state until the trainer goes
     if (persist) T2_TRY(persist_decode(s, S, 0, 0, true, &tr->tape));
     else {
@@ -976,6 +987,11 @@ extern "C" int t2_train_decoder_forward(t2_trainer* tr, const float* memory, con
     HIP_TRY(hipMemcpyAsync(mel, s->o_mel, (size_t)B * S * r * M * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(stop, s->o_stop, (size_t)B * S * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(align, s->o_hist, (size_t)S * B * T_in * 4, hipMemcpyDeviceToDevice, st));
+    if (!persist) break;
+    bool timed_out = false;
+    T2_TRY(persist_timed_out(s, &timed_out));      // the backward pass must not consume a tape a timed-out launch left behind
+    if (!timed_out) break;
+    }
     tr->have_forward = true;
     return T2_OK;
 }
@@ -1282,9 +1298,13 @@ extern "C" int t2_train_decoder_backward(t2_trainer* tr, const float* done, cons
         return a;
     };
     // the reverse-time recurrence: ONE persistent launch at the paper-size class (persist_bwd.h), else 5 launches per step
-    const bool pzb = m->opt_bwd_persist && tr->pzb_slab != nullptr;
-    if (pzb) T2_TRY(pzb_launch(tr));
-    else hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * D), dim3(256), 0, st,
+    bool pzb = m->opt_bwd_persist && m->persist_holdoff == 0 && tr->pzb_slab != nullptr;
+    if (pzb) {
+        bool timed_out = false;
+        T2_TRY(pzb_launch(tr, &timed_out));
+        if (timed_out) pzb = false;
+    }
+    if (!pzb) hipLaunchKernelGGL(lstm_bwd_kernel, grid1((long long)B * D), dim3(256), 0, st,
                             lstm_args_at(2, S - 1, 1, tr->dy2_all + (size_t)(S - 1) * B * D, D, nullptr, 0, dzf2[(S - 1) & 1]));
     for (int t = S - 1; !pzb && t >= 0; --t) {
         const int first = (t == S - 1) ? 1 : 0;
@@ -1782,7 +1802,7 @@ static int train_encoder_forward_impl(t2_trainer* tr, const int64_t* ids, const 
     HIP_TRY(hipStreamSynchronize(st));
     const int hsz = MB * 16 * KPh;
     // the whole recurrence as ONE launch (persist.h encoder_kernel, training instantiation) at the paper-size class
-    const bool enc_persist = m->opt_enc_persist && Cx == 512 && He == 256 && KPh == 256 && m->n_cu >= 2 * pz::ENC_G &&
+    const bool enc_persist = m->opt_enc_persist && m->persist_holdoff == 0 && Cx == 512 && He == 256 && KPh == 256 && m->n_cu >= 2 * pz::ENC_G &&
                              m->enc_lstm[0].n_wg == pz::ENC_G && m->enc_lstm[0].kbtot == 48 && 2LL * T * (long long)per_step * 4 < 0x7fffffffLL;
     if (enc_persist) {
         HIP_TRY(hipMemsetAsync(et->pz_bar, 0, (size_t)(2 * pz::NSHARD * 32 + 64) * 4, st));
@@ -1798,17 +1818,26 @@ static int train_encoder_forward_impl(t2_trainer* tr, const int64_t* ids, const 
         a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
         a.seed = seed; a.stream = T2_STREAM_ZONE_ENC;
         const dim3 grid(2 * pz::ENC_G), blk(pz::NT);
-        if (MB == 1) hipLaunchKernelGGL((pz::encoder_kernel<1, true>), grid, blk, 0, st, a);
-        else if (MB == 2) hipLaunchKernelGGL((pz::encoder_kernel<2, true>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((pz::encoder_kernel<4, true>), grid, blk, 0, st, a);
-        HIP_TRY(hipGetLastError());
+        {
+            XwgGate gate;
+            T2_TRY(gate.begin(m->ctx));
+            if (MB == 1) hipLaunchKernelGGL((pz::encoder_kernel<1, true>), grid, blk, 0, st, a);
+            else if (MB == 2) hipLaunchKernelGGL((pz::encoder_kernel<2, true>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((pz::encoder_kernel<4, true>), grid, blk, 0, st, a);
+            HIP_TRY(hipGetLastError());
+        }
+        T2_TRY(inject_timeout(m, a.err));
+        ++m->n_enc_persist;
         int h_err = 0;
         HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (h_err) return fail(T2_EHIP, "persistent encoder (training): a hand-off wait ran out of time; outputs are invalid");
-        ++m->n_enc_persist;
-        et->have_forward = ids != nullptr;
-        return T2_OK;
+        if (!h_err) { et->have_forward = ids != nullptr; return T2_OK; }
+        // a hand-off wait ran out of time: the same recurrence again, one launch per step and direction
+        note_persist_timeout(m);
+        HIP_TRY(hipMemsetAsync(memory_out, 0, (size_t)Mtot * E * 4, st));
+        HIP_TRY(hipMemsetAsync(et->hfrag, 0, 2 * 2 * (size_t)MB * 16 * KPh * 4, st));
+        HIP_TRY(hipMemsetAsync(et->cst, 0, 2 * (size_t)MB * 16 * He * 4, st));
+        HIP_TRY(hipMemcpyAsync(et->ctl, h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, st));
     }
     for (int s = 0; s < T; ++s)
         for (int dir = 0; dir < 2; ++dir) {
@@ -2008,7 +2037,7 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
     HIP_TRY(hipMemsetAsync(et->dxa, 0, (size_t)Mtot * Cx * 4, st));
     const char* dirs[2] = {"fw", "bw"};
     // both directions' reverse-time recurrences as ONE persistent launch at the paper-size class (persist_bwd.h), else one launch per step
-    const bool pze = m->opt_bwd_persist && et->pze_slab != nullptr;
+    bool pze = m->opt_bwd_persist && m->persist_holdoff == 0 && et->pze_slab != nullptr;
     if (pze) {
         HIP_TRY(hipMemsetAsync(et->pze_slab, 0, et->pze_slab_bytes, st));
         pz::EBArgs a{};
@@ -2020,15 +2049,24 @@ extern "C" int t2_train_encoder_backward(t2_trainer* tr, const float* dmemory, f
         a.B = B; a.T = T; a.stream = T2_STREAM_ZONE_ENC; a.seed = et->seed;
         a.zc = d.zoneout_cell; a.zh = d.zoneout_output; a.fb = d.forget_bias;
         const dim3 grid(2 * pz::ENC_G), blk(pz::NT);
-        if (MB == 1) hipLaunchKernelGGL((pz::encoder_bwd_kernel<1>), grid, blk, 0, st, a);
-        else if (MB == 2) hipLaunchKernelGGL((pz::encoder_bwd_kernel<2>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((pz::encoder_bwd_kernel<4>), grid, blk, 0, st, a);
-        HIP_TRY(hipGetLastError());
+        {
+            XwgGate gate;
+            T2_TRY(gate.begin(m->ctx));
+            if (MB == 1) hipLaunchKernelGGL((pz::encoder_bwd_kernel<1>), grid, blk, 0, st, a);
+            else if (MB == 2) hipLaunchKernelGGL((pz::encoder_bwd_kernel<2>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((pz::encoder_bwd_kernel<4>), grid, blk, 0, st, a);
+            HIP_TRY(hipGetLastError());
+        }
+        T2_TRY(inject_timeout(m, a.err));
         ++m->n_bwd_persist;
         int h_err = 0;
         HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (h_err) return fail(T2_EHIP, "persistent encoder backward: a hand-off wait ran out of time");
+        if (h_err) {                       // a hand-off wait ran out of time: the launch-per-step recurrence below runs instead
+            note_persist_timeout(m);
+            HIP_TRY(hipMemsetAsync(et->dxa, 0, (size_t)Mtot * Cx * 4, st));
+            pze = false;
+        }
     }
     for (int dir = 0; dir < 2; ++dir) {
         hipLaunchKernelGGL(seq_gather_kernel, grid1((long long)T * B * Cx), dim3(256), 0, st, et->x[L], et->lens, et->xs, B, T, Cx, dir);
