@@ -15,7 +15,22 @@
  *    weights and workspaces inside its handles.
  *  - all floating point is IEEE fp32; ids / lengths are int64 (util/tfrecord.py:108-109).
  *  - a handle is not thread-safe; use one ctx per GPU per thread.  All work is enqueued on the
- *    ctx's stream; only t2_decode_free() synchronises (to return steps_out).
+ *    ctx's stream.  Host synchronisation: t2_decode_free() / t2_decode_free_finish() (to return
+ *    steps_out); and every call that runs a persistent kernel (below) waits for it once, to read
+ *    its error word: t2_encode*, t2_decode_teacher, t2_train_* at the paper-size dimension
+ *    class.  Everything else (state set-up, t2_postnet, t2_decode_step, the launch-per-phase
+ *    schedules of other sizes) only enqueues.
+ *  - Persistent kernels.  At the paper-size dimension class the decoder loop, the encoder BiLSTM
+ *    and the training recurrences each run as ONE launch whose workgroups hand data to each other
+ *    (csrc/persist.h, persist_bwd.h).  That needs all of them resident at once, i.e. the whole
+ *    GPU.  (a) Within a process the library serialises such launches per GPU on the device
+ *    (stream-wait on the previous one's completion event), whatever streams / threads / engines
+ *    issue them.  (b) Every wait inside them is bounded (250 ms); if another PROCESS holds part
+ *    of the GPU and a wait runs out, the kernel raises an error word, and the call that reads it
+ *    re-runs the same work on the launch-per-phase schedule before it returns: results are
+ *    always valid, T2_OK is never returned over invalid buffers.  The event is counted
+ *    (t2_model_get_stat "persist_timeouts") and the model's next 16 decodes skip the persistent
+ *    kernels.  For full speed give the process the GPU to itself.
  *  - batch size B <= T2_MAX_BATCH per call (one reference batch: the stop rule of
  *    helpers.py:90-94 couples all rows of a batch, so a batch is never split internally).
  */

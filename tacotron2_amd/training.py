@@ -124,6 +124,11 @@ def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _rank(group=None) -> int:
+    import torch.distributed as dist
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
 def global_loss_counts(spec_loss_mask, binary_loss_mask, num_mels: int, group=None) -> torch.Tensor:
     """[count_nonzero(spec weights broadcast over num_mels), count_nonzero(stop weights)] of the WHOLE data-parallel batch
     (sum all-reduce over ranks): the denominators of tf.losses' SUM_BY_NONZERO_WEIGHTS for a single-device batch of all
@@ -219,6 +224,18 @@ class AdamOptimizer:
             pass
 
 
+def rank_seed(seed: int, rank: int, world: int) -> int:
+    """The mask seed of one data-parallel rank: ``seed`` itself on a single device, a 32-bit mix of (seed, rank) otherwise
+    (the same value feeds the forward kernels and the backward kernels that regenerate the masks)."""
+    if world <= 1:
+        return int(seed) & 0xFFFFFFFF
+    x = (int(seed) * 0x9E3779B1 + (int(rank) + 1) * 0x85EBCA6B) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    return x
+
+
 class Trainer:
     """One t2_trainer: the tape of a (B, T_in, S) teacher-forced training forward of an ``Engine``'s model and the
     workspaces of its backward pass (include/t2mi.h, "training step")."""
@@ -304,6 +321,9 @@ class Trainer:
 
     def load_params(self, flat_params: torch.Tensor):
         """Rebuild every device copy of the weights from the flat parameter buffer (after the optimizer step)."""
+        # the library keeps the POINTER: a trainer of the same model whose operands lag behind (another batch shape, EncoderV2's
+        # internal trainers) re-reads this buffer at its next backward pass -- keep the tensor alive with the model
+        self.engine._last_flat_params = flat_params
         with self.engine._ordered():
             _lib.check(self.engine.lib.t2_trainer_load_params(self._h, flat_params.data_ptr()))
 
@@ -328,9 +348,13 @@ class Trainer:
         differentiates sum_rank / count_total, the gradients are SUMMED (one all-reduce of the flat buffer, no 1/world) and the
         reported losses are sum of numerators / sum of counts -- N ranks x B rows give the gradient and the loss of one batch
         of N x B rows under SUM_BY_NONZERO_WEIGHTS.  What stays per replica, as SURVEY.md 8e says: batch-norm batch statistics;
-        the moving statistics are averaged over ranks so that every rank keeps identical parameters."""
+        the moving statistics are averaged over ranks so that every rank keeps identical parameters.  The dropout / zoneout
+        masks come from a counter-based generator keyed on (seed, stream, step, LOCAL row, column): every rank folds its rank
+        into the seed (``rank_seed``), otherwise row i of every rank would draw the same masks and the N x B rows would carry
+        only B independent noise patterns."""
         d = self.engine.dims
         world = _world(group)
+        seed = rank_seed(seed, _rank(group), world)
         flat_grads.zero_()
         counts = None
         if world > 1:

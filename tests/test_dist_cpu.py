@@ -154,3 +154,19 @@ def test_two_rank_training_step_is_loss_exact():
         np.testing.assert_allclose(r[1], g_full, atol=1e-6 * float(np.abs(g_full).max()) + 1e-9)
         assert abs(r[2] - full["loss"]) < 1e-6
         assert r[3][0] == float((labels["spec_loss_mask"] != 0).sum() * d.num_mels) and r[3][1] == float((labels["binary_loss_mask"] != 0).sum())
+
+
+def test_rank_seed_decorrelates_the_ranks_masks():
+    """the counter-based masks are keyed on the LOCAL row, so data-parallel ranks must not share the seed.
+    rank_seed is the identity on one device (single-device results stay reproducible from the caller's seed) and gives every
+    rank its own 32-bit seed otherwise; the oracle's masks drawn from those seeds are uncorrelated across ranks."""
+    from oracle import t2_oracle as O
+    from tacotron2_amd import training as TR
+    assert TR.rank_seed(1234, 0, 1) == 1234 and TR.rank_seed(-1, 0, 1) == 0xFFFFFFFF
+    seeds = {TR.rank_seed(7, r, 8) for r in range(8)}
+    assert len(seeds) == 8 and 7 not in seeds and all(0 <= s < 2 ** 32 for s in seeds)
+    assert TR.rank_seed(7, 3, 8) == TR.rank_seed(7, 3, 8) != TR.rank_seed(8, 3, 8)
+    u0 = O.rng_u01(TR.rank_seed(7, 0, 2), O.STREAM_PRENET, 0, 32, 256) >= 0.5
+    u1 = O.rng_u01(TR.rank_seed(7, 1, 2), O.STREAM_PRENET, 0, 32, 256) >= 0.5
+    agree = float((u0 == u1).mean())
+    assert 0.45 < agree < 0.55, agree                      # identical seeds would give 1.0

@@ -334,3 +334,44 @@ def test_persistent_training_recurrences_after_parameter_refresh():
     finally:
         tr_a.close(); tr_b.close()
         eng_a.close(); eng_b.close()
+
+
+@pytest.mark.parametrize("B,T,eligible", [(1, 9, True), (3, 2, True), (20, 77, True), (1, 590, True), (64, 256, True), (64, 260, False),
+                                          (16, 257, False)])
+def test_persistent_forward_at_edge_shapes_against_oracle(B, T, eligible):
+    """Forward parity where the attention split has corner cases: chunks with fewer than 16 or zero positions
+    (T < 16 C), T not a multiple of 4, the longest eligible inputs (ceil(T / C) = 64 and the LDS plan's limit), and just past
+    the eligibility edge, where the decode must take the launch-per-phase schedule (persist_launches does not advance).
+    Free-running and teacher-forced, against the oracle; peaked attention."""
+    from tacotron2_amd.engine import Engine
+    from tacotron2_amd.weights import sharpen_attention
+    d = PROFILE_P
+    w = sharpen_attention(init_weights(d, seed=31, perturb=True))
+    rng = np.random.default_rng(B * 1000 + T)
+    lens = rng.integers(max(1, T // 2), T + 1, size=B).astype(np.int64)
+    lens[0] = T
+    if B > 2:
+        lens[1] = 1                                                   # a row with a single position
+    memory = rng.uniform(-1, 1, (B, T, d.enc_units)).astype(np.float32)
+    S = 4
+    eng = Engine(d, w)
+    try:
+        mel_o, stop_o, st = O.decoder_v2(d.replace(min_iters=100), w, memory, memory_sequence_length=lens, max_iters=S)
+        n0 = eng.get_stat("persist_launches")
+        mel, stop, align, n = eng.decode_free(memory, lens, max_iters=S, min_iters=100)
+        assert eng.get_stat("persist_launches") == n0 + (1 if eligible else 0)
+        assert n == S
+        np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
+        np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
+        np.testing.assert_allclose(_np(stop), stop_o, atol=2e-4)
+        target = rng.uniform(0, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
+        mel_o, stop_o, st = O.decoder_v2(d, w, memory, is_training=True, memory_sequence_length=lens, target=target)
+        mel, stop, align = eng.decode_teacher(memory, lens, target, teacher_forcing=True)
+        assert eng.get_stat("persist_launches") == n0 + (2 if eligible else 0)
+        np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=2e-4)
+        np.testing.assert_allclose(_np(mel), mel_o, atol=2e-4)
+        np.testing.assert_allclose(_np(stop), stop_o, atol=2e-4)
+        for b in range(B):                                            # masked positions get exactly zero weight
+            assert not _np(align)[:, b, lens[b]:].any()
+    finally:
+        eng.close()
