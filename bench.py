@@ -338,6 +338,41 @@ def main():
         except Exception as ex:                                      # never lose the headline line over the extra leg
             out["train_step"] = {"error": repr(ex)}
 
+    # ---- Tacotron v1 (BASELINE.json configs[4]): CBHG encoder + Bahdanau GRU decoder teacher-forced at B = 32, and the
+    # mel -> linear CBHG PostNet of train_postnet.py's model, reference hparams sizes (hparams.py:31-60); forward passes ----
+    if rank == 0 and world == 1 and not args.no_train:
+        try:
+            from tacotron2_amd.hparams import V1_PROFILE
+            from tacotron2_amd.tacotron_v1 import EngineV1
+            from tacotron2_amd.weights_v1 import init_weights_v1
+            d1 = V1_PROFILE
+            eng1 = EngineV1(d1, init_weights_v1(d1, 1234 + 5))
+            rng1 = np.random.default_rng(1234 + 5)
+            B1, Ti1, To1 = 32, 140, 800
+            lens1v = rng1.integers(60, Ti1 + 1, B1); lens1v[0] = Ti1
+            ids1v = rng1.integers(32, 91, (B1, Ti1))
+            tgt1v = torch.tensor(rng1.uniform(0, 1, (B1, To1, d1.num_mels)).astype(np.float32), device="cuda")
+
+            def v1_fwd():
+                return eng1.decode_teacher(eng1.encode(ids1v, None), lens1v, tgt1v, teacher_forcing=True)[0]
+
+            def timed(fn, reps=3):
+                res = fn(); torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(reps):
+                    res = fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t_) / reps, res
+            dt_f, mel1v = timed(v1_fwd)
+            dt_p, _ = timed(lambda: eng1.postnet(mel1v))
+            out["v1"] = {"workload": "BASELINE.json configs[4]: Tacotron v1 (tacotron_v1.py), reference hparams sizes, B=32, T_in<=140, "
+                                     "800 frames: EncoderV1 (CBHG) + teacher-forced DecoderV1 forward; mel -> linear CBHG PostNet forward",
+                         "teacher_forced_ms": dt_f * 1e3, "teacher_forced_mel_frames_per_s": B1 * To1 / dt_f,
+                         "postnet_ms": dt_p * 1e3, "postnet_spectrogram_frames_per_s": B1 * To1 / dt_p}
+            eng1.close()
+        except Exception as ex:
+            out["v1"] = {"error": repr(ex)}
+
     # ---- CPU baseline: the NumPy oracle on this box's host cores, bounded sample (N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import t2_oracle as O

@@ -101,6 +101,19 @@ def flatten_spec(weights: Dict[str, np.ndarray]) -> List[Tuple[str, Tuple[int, .
     return spec
 
 
+def decoder_prefix_end(spec) -> int:
+    """End offset of the attention/ + decoder/ variables in the flat buffer.  Names are sorted, so these come first and form
+    one contiguous prefix: the part of the gradient that is final when the decoder backward has run (its all-reduce is
+    started before the encoder backward, ``Trainer.train_step``)."""
+    end = 0
+    for name, shape, off, size in spec:
+        if not (name.startswith("attention/") or name.startswith("decoder/")):
+            break
+        assert 0 <= off - end < 4, "attention/ and decoder/ variables must form a contiguous prefix of the flat buffer"
+        end = off + size
+    return end
+
+
 def flat_size(spec) -> int:
     name, shape, off, size = spec[-1]
     return off + ((size + 3) & ~3)
@@ -139,6 +152,13 @@ def global_loss_counts(spec_loss_mask, binary_loss_mask, num_mels: int, group=No
     if _world(group) > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     return cnt
+
+
+def allreduce_sum_async(t: torch.Tensor, group=None):
+    """Start a SUM all-reduce of ``t`` (a contiguous view) and return its work handle; ``wait()`` orders the current stream
+    after it (backend "nccl" = RCCL: the collective runs on the communicator's stream, beside compute)."""
+    import torch.distributed as dist
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
 def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
@@ -363,9 +383,18 @@ class Trainer:
         memory, _ = self.encoder_forward(features["source"], features["source_length"], drop_rate=encoder_drop_rate, seed=seed)
         self.decoder_forward(memory, features["source_length"], labels["mel"], prenet_drop_rate=prenet_drop_rate, seed=seed)
         dmem, losses = self.decoder_backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], flat_grads)
+        # The flat buffer is sorted by variable name: attention/ and decoder/ gradients (27 M of the 32 M trained parameters) are
+        # one contiguous prefix and FINAL once the decoder backward has run -- their all-reduce starts now and runs beside the
+        # encoder backward (async collective on the communicator's own stream); the encoder / embedding suffix follows.
+        works = []
+        if world > 1:
+            cut = decoder_prefix_end(self._spec)
+            works.append(allreduce_sum_async(flat_grads[:cut], group))
         self.encoder_backward(dmem, flat_grads)
         if world > 1:
-            allreduce_sum(flat_grads, group)                                     # gradients of sum_rank / count_total: plain sum
+            works.append(allreduce_sum_async(flat_grads[cut:], group))           # gradients of sum_rank / count_total: plain sum
+            for wk in works:
+                wk.wait()
             m1, m2 = self.engine._f32(labels["spec_loss_mask"]), self.engine._f32(labels["binary_loss_mask"])
             own = torch.stack([(m1 != 0).sum().to(torch.float32) * float(d.num_mels), (m2 != 0).sum().to(torch.float32)])
             num = allreduce_sum(losses[:2] * own, group)                         # numerators: local ratio x local count

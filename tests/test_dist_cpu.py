@@ -106,7 +106,16 @@ def _dp_worker(rank, world, port, q):
                                     loss_counts=(float(counts[0]), float(counts[1])))
     names = sorted(ref["grads"])
     g = torch.tensor(np.concatenate([ref["grads"][k].reshape(-1) for k in names]))
-    TR.allreduce_sum(g)                                                    # the step's one gradient all-reduce: plain SUM
+    # the step's gradient all-reduce, plain SUM, in the two buckets Trainer.train_step uses: the attention/ + decoder/ prefix
+    # (final after the decoder backward; started asynchronously, it runs beside the encoder backward) and the rest
+    spec = TR.flatten_spec({k: ref["grads"][k] for k in names})
+    flat = torch.tensor(TR.flatten({k: ref["grads"][k] for k in names}, spec))
+    cut = TR.decoder_prefix_end(spec)
+    assert 0 < cut < flat.numel() and spec[0][0].startswith("attention/")
+    works = [TR.allreduce_sum_async(flat[:cut]), TR.allreduce_sum_async(flat[cut:])]
+    for wk in works:
+        wk.wait()
+    g = torch.cat([flat[off:off + size] for _, _, off, size in spec])
     loss = TR.allreduce_sum(torch.tensor([ref["loss"]], dtype=torch.float64))
     q.put((rank, g.numpy(), float(loss[0]), counts.numpy()))
     dist.barrier()
