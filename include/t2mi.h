@@ -158,6 +158,14 @@ int t2_state_get(t2_state* s, const char* name, float* out);
  * The state is advanced in place. */
 int t2_decode_step(t2_model* m, t2_state* s, const float* prev_frames, float* mel_r, float* stop);
 
+/* The same cell call with the reference's training-mode sampling: DecoderPreNetWrapper.call (rnn_wrappers.py:51-53) with the
+ * PreNets' dropout active (modules.py:90,96-98: is_training or apply_dropout_on_inference; rate prenet_drop_rate, 0 = off)
+ * and, when sample_zoneout != 0, ZoneoutLSTMCell's sampled branch (modules.py:274-276) in the three cells; masks come from
+ * the library's counter-based generator at (seed, stream, time = the state's step count, row, unit), i.e. the masks
+ * t2_train_decoder_forward draws at that step with the same seed (TensorFlow's random stream is not reproducible). */
+int t2_decode_step_train(t2_model* m, t2_state* s, const float* prev_frames, float prenet_drop_rate, int sample_zoneout,
+                         uint32_t seed, float* mel_r, float* stop);
+
 /* dynamic_decode(BasicDecoder(cell, TrainingHelper | ValidationHelper, zero_state)) as wired by
  * DecoderV1.call (tacotron_v1.py:134-152) for the V2 cell.  targets dev [B,T_out,M] (T_out % r == 0),
  * S = T_out / r steps for every row (helpers.py:154-156, :105,:133).

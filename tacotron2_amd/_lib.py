@@ -67,6 +67,7 @@ _SIGS = {
     "t2_state_destroy": (C.c_int, [_p]),
     "t2_state_get": (C.c_int, [_p, C.c_char_p, _p]),
     "t2_decode_step": (C.c_int, [_p, _p, _p, _p, _p]),
+    "t2_decode_step_train": (C.c_int, [_p, _p, _p, C.c_float, C.c_int, C.c_uint32, _p, _p]),
     "t2_decode_teacher": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "t2_decode_free": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]),
     "t2_decode_free_launch": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),

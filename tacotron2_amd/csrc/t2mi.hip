@@ -1372,6 +1372,7 @@ struct TrainTape {
     float* xp[T2_MAX_PRENET_LAYERS];          // PreNet outputs after dropout
     float *z[3], *cprev[3], *cnew[3], *hraw[3], *hstate[3];   // attention LSTM, LSTM 1, LSTM 2
     float *q, *state_prev, *ctx;              // attention: q + b_a, state before the step, context
+    int inference_zoneout;                    // 1: only the PreNet dropout is sampled (apply_dropout_on_inference, modules.py:96-98); the cells blend
 };
 
 static void persist_fill_tape(pz::PTape& tp, const TrainTape* tape) {
@@ -1495,7 +1496,7 @@ static int launch_step(t2_state* s, int step_off, const StepIO& io) {
     const bool att3 = hoist && m->opt_att3 && (MB == 1 || io.defer_proj) && !m->opt_lstm_only && !spread;   // deferred projection: its rider moves here
     const bool timing = m->opt_time_lstm && !m->opt_graph;
     auto taped = [&](LstmEpi& e, int layer, int stream) {
-        if (!io.train) return;
+        if (!io.train || io.train->inference_zoneout) return;
         e.train = 1; e.seed = io.train->seed; e.stream = stream;
         e.tp_z = io.train->z[layer]; e.tp_cprev = io.train->cprev[layer]; e.tp_cnew = io.train->cnew[layer];
         e.tp_hraw = io.train->hraw[layer]; e.tp_hstate = io.train->hstate[layer];
@@ -1662,13 +1663,30 @@ extern "C" int t2_decode_final_state(t2_model* m, const char* name, float* out) 
     return fail(T2_EINVAL, "unknown state tensor '%s'", name);
 }
 
+static int decode_step_impl(t2_model* m, t2_state* s, const float* prev_frames, float* mel_r, float* stop, const TrainTape* train);
 extern "C" int t2_decode_step(t2_model* m, t2_state* s, const float* prev_frames, float* mel_r, float* stop) {
+    return decode_step_impl(m, s, prev_frames, mel_r, stop, nullptr);
+}
+
+// One cell call with the training-mode sampling of the reference (rnn_wrappers.py:51-53 -> modules.py:90,96-98 PreNet dropout;
+// modules.py:274-276 ZoneoutLSTMCell's sampled branch): masks u01(seed, stream, time, row, unit) of the shared counter-based
+// generator, time = the state's step count -- the same masks t2_train_decoder_forward draws at that step.  Nothing is taped.
+extern "C" int t2_decode_step_train(t2_model* m, t2_state* s, const float* prev_frames, float prenet_drop_rate, int sample_zoneout,
+                                    uint32_t seed, float* mel_r, float* stop) {
+    if (!(prenet_drop_rate >= 0.f && prenet_drop_rate < 1.f)) return fail(T2_EINVAL, "drop rate must be in [0, 1)");
+    TrainTape tape{};
+    tape.seed = seed; tape.prenet_drop_rate = prenet_drop_rate; tape.inference_zoneout = sample_zoneout ? 0 : 1;
+    return decode_step_impl(m, s, prev_frames, mel_r, stop, &tape);       // the launches copy what they need: the tape may die here
+}
+
+static int decode_step_impl(t2_model* m, t2_state* s, const float* prev_frames, float* mel_r, float* stop, const TrainTape* train) {
     if (!m || !s || !prev_frames || !mel_r || !stop) return fail(T2_EINVAL, "null argument");
     if (s->m != m) return fail(T2_EINVAL, "state belongs to another model");
     HIP_TRY(hipSetDevice(m->ctx->device));
     const t2_dims& d = m->d;
     hipStream_t st = m->ctx->stream;
     StepIO io{};
+    io.train = train;
     io.feed_mode = 2; io.feed_src = prev_frames; io.feed_row_stride = d.num_mels * d.n_feed_frame; io.feed_t_stride = 0;
     io.mel = s->o_mel; io.mel_ld = d.num_mels * d.outputs_per_step; io.mel_t_stride = 0;
     io.stop = s->o_stop; io.stop_ld = 1; io.stop_t_mul = 0; io.hist = nullptr;

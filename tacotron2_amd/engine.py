@@ -253,6 +253,18 @@ class Engine:
             _lib.check(self.lib.t2_decode_step(self._model, state._h, prev.data_ptr(), mel.data_ptr(), stop.data_ptr()))
         return mel, stop
 
+    def decode_step_train(self, state: DecoderState, prev_frames, prenet_drop_rate: float, sample_zoneout: bool, seed: int):
+        """One cell call with sampled PreNet dropout / zoneout (t2_decode_step_train)."""
+        d = self.dims
+        prev = self._f32(prev_frames)
+        assert prev.shape == (state.B, d.num_mels * d.n_feed_frame)
+        mel = torch.empty((state.B, d.num_mels * d.outputs_per_step), dtype=torch.float32, device=self.device)
+        stop = torch.empty((state.B, 1), dtype=torch.float32, device=self.device)
+        with self._ordered():
+            _lib.check(self.lib.t2_decode_step_train(self._model, state._h, prev.data_ptr(), float(prenet_drop_rate), int(bool(sample_zoneout)),
+                                                     int(seed) & 0xFFFFFFFF, mel.data_ptr(), stop.data_ptr()))
+        return mel, stop
+
     def decode_teacher(self, memory, lens, targets, teacher_forcing=True):
         d = self.dims
         memory, targets = self._f32(memory), self._f32(targets)

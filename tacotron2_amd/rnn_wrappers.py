@@ -181,24 +181,50 @@ class AttentionRNN(_Delegating):
 
 
 class OutputProjectionWrapper(_Delegating):
-    """rnn_wrappers.py:147-186 (Tacotron-1 only).  The constructor check is kept here; the projection itself runs inside the
-    V1 decoder step of the HIP library (csrc/v1.h, v1_launch_step: a dense launch on [context | attention cell output]), reached
-    through tacotron_v1.DecoderV1."""
+    """rnn_wrappers.py:147-186 (Tacotron-1 only): ``cell`` followed by a linear projection (+ bias, + activation).  Inside
+    tacotron_v1.DecoderV1 the projection runs in the V1 decoder step of the HIP library (csrc/v1.h, v1_launch_step: a dense
+    launch on [context | attention cell output]); used on its own, ``call`` runs the wrapped cell and projects its output
+    with t2_dense.  ``weights`` = {"kernel": [cell output size, output_size], "bias": [output_size]} (TF names :166-172)."""
 
-    def __init__(self, cell, output_size, activation=None, use_bias=True, name=None, dtype=None):
+    _ACT = {None: 0, "relu": 1, "tanh": 2}
+
+    def __init__(self, cell, output_size, activation=None, use_bias=True, weights=None, name=None, dtype=None):
         if output_size < 1:
             raise ValueError("Parameter output_size must be > 0: %d." % output_size)
         self._cell = cell
         self._output_size = output_size
         self._activation = activation
         self._use_bias = use_bias
+        self.weights = weights
 
     @property
     def output_size(self):
         return self._output_size
 
     def call(self, inputs, state):
-        raise RuntimeError("OutputProjectionWrapper runs inside the V1 decoder step (tacotron_v1.DecoderV1 -> t2v1_decode_*)")
+        """rnn_wrappers.py:174-186: output, res_state = cell(inputs, state); tensordot(output, kernel) (+ bias) (activation)."""
+        from . import _lib
+        from .engine import shared_context
+        if self.weights is None:
+            raise ValueError("OutputProjectionWrapper called without weights")
+        output, res_state = self._cell(inputs, state)
+        ctx = shared_context(output.device.index if isinstance(output, torch.Tensor) and output.is_cuda else torch.cuda.current_device())
+        x = ctx.f32(output)
+        k = ctx.f32(self.weights["kernel"])
+        b = ctx.f32(self.weights["bias"]) if self._use_bias else None
+        if tuple(k.shape) != (x.shape[-1], self._output_size):
+            raise ValueError(f"kernel shape {tuple(k.shape)} does not fit the cell output ({x.shape[-1]}, {self._output_size})")
+        fused = self._activation if (self._activation is None or isinstance(self._activation, str)) else None
+        if fused not in self._ACT:
+            raise ValueError(f"activation {self._activation!r}: None, 'relu', 'tanh' or a callable on tensors")
+        rows = int(np.prod(x.shape[:-1]))
+        y = torch.empty(tuple(x.shape[:-1]) + (self._output_size,), dtype=torch.float32, device=ctx.device)
+        with ctx.ordered():
+            _lib.check(ctx.lib.t2_dense(ctx.handle, x.data_ptr(), k.data_ptr(), None if b is None else b.data_ptr(), rows, int(x.shape[-1]),
+                                        self._output_size, self._ACT[fused], y.data_ptr()))
+        if callable(self._activation):
+            y = self._activation(y)
+        return y, res_state
 
 
 class OutputAndStopTokenWrapper(_Delegating):
@@ -220,6 +246,7 @@ class OutputAndStopTokenWrapper(_Delegating):
         self._seed = seed
         self._num_mels = num_mels
         self._step_checked = False
+        self.mask_seed = seed          # seed of the sampled masks of single cell calls (``call`` with active dropout / zoneout)
 
     @property
     def output_size(self):
@@ -239,12 +266,6 @@ class OutputAndStopTokenWrapper(_Delegating):
         zh = {att.lstm._zoneout_outputs, lstms[0]._zoneout_outputs, lstms[1]._zoneout_outputs}
         if len(zc) != 1 or len(zh) != 1:
             raise NotImplementedError("one pair of zoneout factors per decoder is supported")
-        for c in (att.lstm, lstms[0], lstms[1]):
-            if not allow_sampling and c.is_training and (c._zoneout_cell > 0 or c._zoneout_outputs > 0):
-                raise NotImplementedError("training-mode zoneout sampling is built for DecoderV2.call's loop, not for single steps")
-        for p in att.prenets:
-            if not allow_sampling and p.dropout_enabled and p.drop_rate > 0:
-                raise NotImplementedError("active PreNet dropout is built for DecoderV2.call's loop, not for single steps")
         return T2Dims(num_symbols=2, embedding_dim=mech.values_depth, enc_conv_layers=0, enc_units=mech.values_depth,
                       prenet_units=tuple(p.out_units for p in att.prenets), attention_lstm_units=att.lstm.num_units,
                       decoder_lstm_units=lstms[0].num_units, attention_dim=mech.num_units,
@@ -271,11 +292,34 @@ class OutputAndStopTokenWrapper(_Delegating):
             raise ValueError("batch_size does not match the attention memory")
         return self.engine().new_state(mech.memory, mech.memory_sequence_length)
 
+    def sampling(self):
+        """(PreNet dropout rate, sampled zoneout?) of a single cell call: what the reference's flags switch on.  PreNet dropout
+        runs when ``is_training or apply_dropout_on_inference`` (modules.py:96-98), ZoneoutLSTMCell samples when ``is_training``
+        (modules.py:274-276).  The library draws one rate for all PreNet layers and one mode for the three cells."""
+        att = self._cell.attention_cell
+        active = [p for p in att.prenets if p.dropout_enabled and p.drop_rate > 0]
+        rates = {float(p.drop_rate) for p in active}
+        if active and (len(active) != len(att.prenets) or len(rates) != 1):
+            raise NotImplementedError("PreNet dropout: one rate, on all layers or on none")
+        cells = (att.lstm,) + tuple(self._cell.lstms)
+        zs = [bool(c.is_training and (c._zoneout_cell > 0 or c._zoneout_outputs > 0)) for c in cells]
+        if any(zs) and not all(zs):
+            raise NotImplementedError("zoneout sampling: all three cells in training mode or none")
+        return (rates.pop() if rates else 0.0), all(zs)
+
     def call(self, inputs, state):
+        """One OutputAndStopTokenWrapper.call (rnn_wrappers.py:105-109).  With active PreNet dropout / training-mode zoneout
+        (rnn_wrappers.py:51-53, modules.py:96-98,274-276) the step samples its masks from the library's counter-based generator
+        at (``mask_seed``, stream, the state's step count, row, unit): the masks DecoderV2.call's fused loop draws at that step."""
         if inputs.shape[-1] != self._n_feed_units:
             raise ValueError(f"decoder input width {inputs.shape[-1]} != n_feed_units {self._n_feed_units}")
         if not self._step_checked:
-            self.decoder_dims()                       # single steps: refuses active sampling
+            self.decoder_dims()
+            self._sampling = self.sampling()
             self._step_checked = True
-        mel_output, stop_token = self.engine().decode_step(real_state(state), inputs)
+        rate, sample_zoneout = self._sampling
+        if rate > 0 or sample_zoneout:
+            mel_output, stop_token = self.engine().decode_step_train(real_state(state), inputs, rate, sample_zoneout, self.mask_seed)
+        else:
+            mel_output, stop_token = self.engine().decode_step(real_state(state), inputs)
         return (mel_output, stop_token), state

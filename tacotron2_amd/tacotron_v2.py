@@ -292,6 +292,9 @@ class DecoderV2:
             state0 = cell.zero_state(B)
             hist = []
             base_call = cell.call
+            cell.mask_seed = self.seed                              # single cell calls sample with this call's seed (t2_decode_step_train)
+            if self._sampling(is_training):
+                self.seed = (self.seed + 1) & 0xFFFFFFFF
 
             def stepping(inputs, state):
                 out = base_call(inputs, state)

@@ -368,3 +368,33 @@ def test_postnet_v2_training_mode_against_autograd_oracle():
         np.testing.assert_allclose(_np(post_i(torch.from_numpy(mel).cuda())), O.postnet_v2(d, w, mel), atol=ATOL)
     finally:
         eng.close()
+
+
+def test_output_projection_wrapper_call_on_a_zoneout_cell():
+    """rnn_wrappers.py:174-186 on its own: output, state = cell(inputs, state); tensordot(output, kernel) + bias, activation
+    (missing #4): the wrapped cell runs on the library (t2_zoneout_lstm_cell), the projection on t2_dense."""
+    from tacotron2_amd.modules import ZoneoutLSTMCell
+    from tacotron2_amd.rnn_wrappers import OutputProjectionWrapper
+    rng = np.random.default_rng(21)
+    B, n_in, H, N = 6, 10, 12, 7
+    kernel = rng.normal(0, 0.3, (n_in + H, 4 * H)).astype(np.float32)
+    bias = rng.normal(0, 0.1, 4 * H).astype(np.float32)
+    pk = rng.normal(0, 0.3, (H, N)).astype(np.float32)
+    pb = rng.normal(0, 0.1, N).astype(np.float32)
+    for activation, use_bias, f in ((None, True, lambda v: v), ("tanh", True, np.tanh), ("relu", False, lambda v: np.maximum(v, 0)),
+                                    (torch.sigmoid, True, lambda v: 1 / (1 + np.exp(-v)))):
+        cell = OutputProjectionWrapper(ZoneoutLSTMCell(H, False, 0.1, 0.2, weights={"kernel": kernel, "bias": bias}), N,
+                                       activation=activation, use_bias=use_bias, weights={"kernel": pk, "bias": pb})
+        assert cell.output_size == N
+        state = cell.zero_state(B)
+        c_o, h_o = np.zeros((B, H), np.float32), np.zeros((B, H), np.float32)
+        for _ in range(3):
+            x = rng.uniform(-1, 1, (B, n_in)).astype(np.float32)
+            y, state = cell(torch.from_numpy(x).cuda(), state)
+            out_o, (c_o, h_o) = O.zoneout_lstm_cell(x, (c_o, h_o), kernel, bias, 0.1, 0.2)
+            want = f(out_o @ pk + (pb if use_bias else 0.0))
+            np.testing.assert_allclose(_np(y), want, atol=ATOL)
+            np.testing.assert_allclose(_np(state[1]), h_o, atol=ATOL)
+    with pytest.raises(ValueError):
+        OutputProjectionWrapper(ZoneoutLSTMCell(H, False, weights={"kernel": kernel, "bias": bias}), N, weights={"kernel": pk[:, :3], "bias": pb})(
+            torch.zeros(B, n_in).cuda(), cell.zero_state(B))
