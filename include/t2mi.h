@@ -345,6 +345,33 @@ int t2v1_decode_teacher(t2v1_model* m, const float* memory, const int64_t* lens,
 int t2v1_decode_free(t2v1_model* m, const float* memory, const int64_t* lens, int B, int T_in, int max_iters, int min_iters,
                      float* mel, float* stop, float* align, int* steps_out);
 
+/* ---- training step of the Tacotron-1 PostNet model (BASELINE.json configs[4] "train_postnet") -------
+ * TacotronV1PostNetModel.model_fn(mode=TRAIN) (tacotron/models.py:190-233): PostNet(is_training=True) (tacotron_v1.py:156-186)
+ * = CBHG with batch-statistics batch norm (modules.py:163-232, Conv1d.call :149-157) -> Dense(num_freq); the masked L1 loss
+ * (models.py:208-211, :265-274); the backward pass of all of it.  The optimizer block is t2_optim_* above; train_postnet.py:30-72
+ * is the caller.  The trainer reads every v1/postnet/ variable from ONE flat fp32 device buffer (TF layouts, where
+ * t2v1_postnet_trainer_bind says) and writes gradients to a buffer of the same layout, so an optimizer step on that buffer needs
+ * no refresh.  Built for post_net_cbhg_out_units == 256 (the published hparams; EINVAL otherwise).  One trainer per (B, T). */
+typedef struct t2v1_ptrainer t2v1_ptrainer;
+int t2v1_postnet_trainer_create(t2v1_model* m, int B, int T, t2v1_ptrainer** out);
+int t2v1_postnet_trainer_destroy(t2v1_ptrainer* tr);
+/* variable `name` starts `offset` floats into the flat parameter / gradient buffers (a multiple of 4) */
+int t2v1_postnet_trainer_bind(t2v1_ptrainer* tr, const char* name, int64_t offset);
+/* PostNet(is_training=True)(mel) (tacotron_v1.py:180-183; the CBHG gets no lengths): mel dev [B,T,num_mels], flat_params dev,
+ * spec_out dev [B,T,num_freq].  Leaves the tape of the backward pass and the batch statistics in the trainer. */
+int t2v1_postnet_train_forward(t2v1_ptrainer* tr, const float* flat_params, const float* mel, float* spec_out);
+/* Gradient of spec_loss(last forward, spec_target dev [B,T,num_freq], mask dev [B,T]) into flat_grads (dev; every trainable
+ * v1/postnet/ slice is written, nothing else); loss_out dev [3] = {sum, non-zero weight count, loss}.  glob_count: dev [1], the
+ * count of a larger data-parallel batch, or NULL (this batch's own).  Consumes the tape: ESTATE without a forward before it. */
+int t2v1_postnet_train_backward(t2v1_ptrainer* tr, const float* spec_target, const float* mask, const float* glob_count,
+                                float* flat_grads, float* loss_out);
+/* tf.layers.batch_normalization's UPDATE_OPS (models.py:229-232) of the ten batch norms, in place in flat_params, from the batch
+ * statistics of the last forward (Bessel-corrected variance). */
+int t2v1_postnet_trainer_update_moving_stats(t2v1_ptrainer* tr, float* flat_params, float momentum);
+/* Rebuild the model's inference copies of the PostNet (t2v1_postnet; model_fn EVAL / PREDICT, models.py:236-259) from the flat
+ * buffer, on the device. */
+int t2v1_postnet_trainer_export(t2v1_ptrainer* tr, const float* flat_params);
+
 /* ---- spectrogram -> waveform ------------------------------------------------------------
  * Audio.inv_spectrogram_tf (util/audio.py:55-59): inv_amp_tf (:51-53: clip to [0,1], de-normalise with min_level_db,
  * + ref_level_db, dB -> amplitude), ** power, then _griffin_lim_tf (:66-82): y = inverse_stft(S); `iters` times

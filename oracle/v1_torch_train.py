@@ -1,0 +1,132 @@
+"""CPU ORACLE for the training step of the Tacotron-1 PostNet model -- test infrastructure, NOT product code.
+
+A differentiable torch (float64, CPU) restatement of TacotronV1PostNetModel.model_fn(mode=TRAIN)'s forward
+(tacotron/models.py:190-211): PostNet(is_training=True) = CBHG (tacotron/modules.py:163-232: conv bank with batch-statistics
+batch norm, max-pool, two projections, residual, adjustment Dense, highway layers, bidirectional GRU over ALL positions -- the
+PostNet calls the CBHG without lengths, tacotron_v1.py:181) -> Dense(num_freq) (tacotron_v1.py:176,182), and the masked L1
+loss with SUM_BY_NONZERO_WEIGHTS (models.py:265-274).  Gradients come from torch.autograd: the checker of the hand-written HIP
+backward pass (csrc/v1_train.h).  TF op semantics as SURVEY.md Appendix A (GRUCell A2: the reset gate multiplies h before the
+candidate matmul; SAME padding of even kernels A3; batch norm A4).
+
+PARITY STATUS: parity unpinned at the TensorFlow boundary (see oracle/t2_oracle.py); the inference-mode forward of the same
+blocks is oracle/v1_oracle.py, and tests/test_oracle_v1.py checks this file's forward against it (batch statistics replaced by
+the moving ones) and its gradients by finite differences."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+DT = torch.float64
+
+
+def _t(x):
+    return torch.as_tensor(np.asarray(x), dtype=DT)
+
+
+def conv1d_bn(x, W, p, act, eps, stats, use_moving=False):
+    """Conv1d.call (modules.py:149-157): conv1d(SAME, no bias) -> batch norm (batch statistics over all B*T positions when
+    training) -> activation.  drop_rate is 0 inside the CBHG (modules.py:171-198 pass none)."""
+    k = W[f"{p}/kernel"]                                   # [K, Cin, Cout]
+    pad_l = (k.shape[0] - 1) // 2
+    xp = F.pad(x.transpose(1, 2), (pad_l, k.shape[0] - 1 - pad_l))
+    y = F.conv1d(xp, k.permute(2, 1, 0)).transpose(1, 2)
+    if use_moving:
+        mean, var = W[f"{p}/batch_normalization/moving_mean"], W[f"{p}/batch_normalization/moving_variance"]
+    else:
+        mean = y.mean(dim=(0, 1))
+        var = y.var(dim=(0, 1), unbiased=False)
+        stats[p] = (mean.detach(), var.detach())
+    y = (y - mean) / torch.sqrt(var + eps) * W[f"{p}/batch_normalization/gamma"] + W[f"{p}/batch_normalization/beta"]
+    if act is torch.relu:
+        return _relu(stats, y)
+    return act(y) if act is not None else y
+
+
+def _note_kink(stats, pre):
+    """Smallest |pre-activation| fed to a ReLU so far: how close the loss is to a kink of its piecewise-smooth surface.  An fp32
+    forward pass whose rounding lands an element on the other side of zero differentiates the neighbouring piece: both gradients
+    are then right for their own side, so gradient comparisons are made at points whose margin is well above fp32 rounding."""
+    stats["relu_margin"] = min(stats.get("relu_margin", float("inf")), float(pre.detach().abs().min()))
+
+
+class _ReluShift(torch.autograd.Function):
+    """relu whose DERIVATIVE is taken at z + shift: the gradient of the neighbouring smooth piece for every input within |shift|
+    of the kink (the forward value is the plain relu's)."""
+
+    @staticmethod
+    def forward(ctx, z, shift):
+        ctx.save_for_backward(z)
+        ctx.shift = shift
+        return z.clamp(min=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        return g * (z + ctx.shift > 0).to(g.dtype), None
+
+
+def _relu(stats, z):
+    _note_kink(stats, z)
+    shift = stats.get("relu_shift", 0.0)
+    return torch.relu(z) if shift == 0.0 else _ReluShift.apply(z, shift)
+
+
+def gru_seq(x, W, p, reverse):
+    """dynamic_rnn over tf.nn.rnn_cell.GRUCell, all T steps live (App. A2, A8)."""
+    B, T, _ = x.shape
+    wg, bg, wc, bc = W[f"{p}/gates/kernel"], W[f"{p}/gates/bias"], W[f"{p}/candidate/kernel"], W[f"{p}/candidate/bias"]
+    H = wc.shape[1]
+    h = torch.zeros(B, H, dtype=DT)
+    out = [None] * T
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        xt = x[:, t]
+        g = torch.sigmoid(torch.cat([xt, h], -1) @ wg + bg)
+        r, u = g[:, :H], g[:, H:]
+        c = torch.tanh(torch.cat([xt, r * h], -1) @ wc + bc)
+        h = u * h + (1.0 - u) * c
+        out[t] = h
+    return torch.stack(out, dim=1)
+
+
+def cbhg_train(W, p, x, max_filter_width, num_highway, eps, stats, use_moving=False):
+    """CBHG.call (modules.py:205-229), is_training=True, input_lengths=None."""
+    bank = torch.cat([conv1d_bn(x, W, f"{p}/conv1d_K{k}", torch.relu, eps, stats, use_moving) for k in range(1, max_filter_width + 1)], dim=-1)
+    pooled = torch.cat([torch.maximum(bank[:, :-1], bank[:, 1:]), bank[:, -1:]], dim=1)        # MaxPooling1D(2, 1, SAME), App. A3
+    p1 = conv1d_bn(pooled, W, f"{p}/proj1", torch.relu, eps, stats, use_moving)
+    p2 = conv1d_bn(p1, W, f"{p}/proj2", None, eps, stats, use_moving)
+    hw = p2 + x
+    if f"{p}/adjustment/kernel" in W:
+        hw = hw @ W[f"{p}/adjustment/kernel"] + W[f"{p}/adjustment/bias"]
+    for i in range(1, num_highway + 1):
+        hp = f"{p}/highway_{i}"
+        zh = hw @ W[f"{hp}/H/kernel"] + W[f"{hp}/H/bias"]
+        h = _relu(stats, zh)
+        t = torch.sigmoid(hw @ W[f"{hp}/T/kernel"] + W[f"{hp}/T/bias"])
+        hw = h * t + hw * (1.0 - t)
+    rp = f"{p}/bidirectional_rnn"
+    return torch.cat([gru_seq(hw, W, f"{rp}/fw/gru_cell", False), gru_seq(hw, W, f"{rp}/bw/gru_cell", True)], dim=-1)
+
+
+def postnet_train_forward_backward(d, w, mel, spec, spec_loss_mask, loss_count=None, use_moving=False, relu_shift=0.0):
+    """One training-mode forward + backward of the PostNet model.  Returns dict(loss, spec [B, T, num_freq], grads{name},
+    bn_stats{prefix: (mean, biased variance)}, relu_margin = smallest |ReLU input| of the pass).  relu_shift != 0: the gradient with every ReLU input within |relu_shift| of zero
+    differentiated on the other side (``_ReluShift``) -- the spread between shifts -s, 0, +s is how far the gradient can move when
+    fp32 rounding of the forward pass crosses such kinks.  loss_count: the denominator of a larger (data-parallel) batch."""
+    pre = "v1/postnet/"
+    W = {k: _t(v).clone().requires_grad_(not k.endswith(("moving_mean", "moving_variance"))) for k, v in w.items() if k.startswith(pre)}
+    stats = {"relu_shift": float(relu_shift)} if relu_shift else {}
+    y = cbhg_train(W, pre + "cbhg", _t(mel), d.post_net_max_filter_width, d.post_net_num_highway, d.bn_eps, stats, use_moving)
+    out = y @ W[pre + "linear/kernel"] + W[pre + "linear/bias"]
+    l1 = (out - _t(spec)).abs()
+    wb = _t(spec_loss_mask)[:, :, None].expand_as(l1)
+    n = (wb != 0).sum() if loss_count is None else loss_count
+    loss = (l1 * wb).sum() / n
+    loss.backward()
+    grads = {k: (v.grad.numpy().astype(np.float32) if v.grad is not None else np.zeros(tuple(v.shape), np.float32)) for k, v in W.items()}
+    f32 = lambda t: t.detach().numpy().astype(np.float32)
+    margin = stats.pop("relu_margin", float("inf"))
+    stats.pop("relu_shift", None)
+    return {"loss": float(loss.detach()), "spec": f32(out), "grads": grads, "bn_stats": {k: (f32(a), f32(b)) for k, (a, b) in stats.items()},
+            "relu_margin": margin}

@@ -84,6 +84,13 @@ _SIGS = {
     "t2v1_postnet": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "t2v1_decode_teacher": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "t2v1_decode_free": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]),
+    "t2v1_postnet_trainer_create": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(_p)]),
+    "t2v1_postnet_trainer_destroy": (C.c_int, [_p]),
+    "t2v1_postnet_trainer_bind": (C.c_int, [_p, C.c_char_p, C.c_int64]),
+    "t2v1_postnet_train_forward": (C.c_int, [_p, _p, _p, _p]),
+    "t2v1_postnet_train_backward": (C.c_int, [_p, _p, _p, _p, _p, _p]),
+    "t2v1_postnet_trainer_update_moving_stats": (C.c_int, [_p, _p, C.c_float]),
+    "t2v1_postnet_trainer_export": (C.c_int, [_p, _p]),
     "t2_trainer_create": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),
     "t2_trainer_destroy": (C.c_int, [_p]),
     "t2_train_decoder_forward": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_uint32, _p, _p, _p]),

@@ -1798,6 +1798,8 @@ struct GruSeqArgs {
     const int* lens;           // [B]
     float* out;                // [B][T][2H]: forward half | backward half
     int B, T;
+    float* tape_ru[2];         // training forward (csrc/v1_train.h): per direction [B*T][2H] gates r | u and [B*T][H] candidate c at
+    float* tape_c[2];          // every live position (the backward recurrence reads them); null: nothing is taped
 };
 
 template <int H>
@@ -1813,6 +1815,8 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
     const float* __restrict__ whg = a.whg[dir];
     const float* __restrict__ whc = a.whc[dir];
     const float* __restrict__ xz = a.xz[dir];
+    float* const tape_ru = a.tape_ru[dir];
+    float* const tape_c = a.tape_c[dir];
     float wg0[KS], wg1[KS], wc[KS];
     // MFMA step ks takes k = 16 (ks / 4) + 4 kg + ks % 4 from lane group kg: a lane's four k of one k-block are contiguous,
     // so the A operand of four steps is ONE 16-byte LDS read
@@ -1864,6 +1868,10 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
             const float s0 = sigmoidf_(g0[r] + xg0[r]), s1 = sigmoidf_(g1[r] + xg1[r]);
             if (cg0 < H) rhs[row][cg0] = s0 * hs[row][cg0]; else us[row][cg0 - H] = s0;
             if (cg1 < H) rhs[row][cg1] = s1 * hs[row][cg1]; else us[row][cg1 - H] = s1;
+            if (tape_ru != nullptr && t < len4[r]) {
+                float* tp = tape_ru + (size_t)(base4[r] + pos_of(r, t)) * 2 * H;
+                tp[cg0] = s0; tp[cg1] = s1;
+            }
         }
         __syncthreads();
         // ---- candidate and blend: c = tanh(x . Wc_x + bc + (r*h) . Wc_h);  h' = u*h + (1 - u)*c
@@ -1885,6 +1893,7 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
             const bool live = t < len4[r];
             hn4[r] = live ? u * hp + (1.0f - u) * cand : hp;
             if (live) a.out[(size_t)(base4[r] + pos_of(r, t)) * 2 * H + dir * H + cc] = hn4[r];
+            if (live && tape_c != nullptr) tape_c[(size_t)(base4[r] + pos_of(r, t)) * H + cc] = cand;
         }
         if (t + 1 < a.T) fetch(t + 1);
         // own columns only: no other wave reads them before the barrier (the gates of step t are done, the blend of the
@@ -1892,6 +1901,133 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) hs[4 * kg + r][cc] = hn4[r];
         __syncthreads();           // h of step t complete; every wave is past its reads of r*h
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reverse-time mirror of gru_seq_kernel: BPTT through the whole-sequence GRU of one direction (training step of the Tacotron-1
+// PostNet model, csrc/v1_train.h).  Same ownership: a workgroup walks 16 batch rows of one direction alone; the TRANSPOSED
+// recurrent halves of the two kernels stay in registers as MFMA B fragments (wave w owns hidden units 16 w .. 16 w + 15:
+// 32 registers of Wc_h^T, 64 of Wg_h^T); the gradient of the state is carried in registers (D layout of the MFMA).
+// TF GRUCell: [r | u] = sigmoid(zg), c = tanh(zc), zc = x.Wc_x + (r*h).Wc_h + bc, h' = u*h + (1 - u)*c.
+// Per step, last step first:  dh = d out[pos] + carry;  du = dh (h - c);  dc = dh (1 - u);  carry = dh u;
+//   dzc = dc (1 - c^2);  d(r*h) = dzc . Wc_h^T;  dr = d(r*h) h;  carry += d(r*h) r;  dzr = dr r (1 - r);  dzu = du u (1 - u);
+//   carry += [dzr | dzu] . Wg_h^T.   dzg = [dzr | dzu] and dzc are written per position: they are d(x . W_x + b), so every
+// weight / input gradient is a tape-wide GEMM afterwards.  Dead steps (t >= len) pass the carry through.
+// ------------------------------------------------------------------------------------------------
+struct GruSeqBwdArgs {
+    const float* dout;         // [B][T][2H] gradient of the concatenated outputs
+    const float* out;          // [B][T][2H] forward outputs (h of every live position)
+    const float* tape_ru[2];   // [B*T][2H] r | u
+    const float* tape_c[2];    // [B*T][H]
+    const float* whg[2];       // [H][2H] recurrent rows of the gates kernel
+    const float* whc[2];       // [H][H] recurrent rows of the candidate kernel
+    const int* lens;
+    float* dzg[2];             // [B*T][2H] (zeroed by the caller: dead positions stay zero)
+    float* dzc[2];             // [B*T][H]
+    int B, T;
+};
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdArgs a) {
+    static_assert(H == 128, "register plan: 8 waves x 16 hidden units");
+    constexpr int KC = H / 4, KG = 2 * H / 4, LDC = H + 4, LDG = 2 * H + 4;
+    __shared__ __attribute__((aligned(16))) float dzc_s[16][LDC];
+    __shared__ __attribute__((aligned(16))) float dzg_s[16][LDG];
+    const int dir = blockIdx.y, row0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kg = lane >> 4, c16 = lane & 15;
+    const int cc = wave * 16 + c16;                       // this lane's hidden unit
+    const float* __restrict__ whg = a.whg[dir];
+    const float* __restrict__ whc = a.whc[dir];
+    // B fragments of the transposed kernels: MFMA step ks takes k = 16 (ks / 4) + 4 kg + ks % 4; B[k][n = cc] = W[cc][k]
+    float wcT[KC], wgT[KG];
+#pragma unroll
+    for (int ks = 0; ks < KC; ++ks) wcT[ks] = whc[(size_t)cc * H + 16 * (ks >> 2) + 4 * kg + (ks & 3)];
+#pragma unroll
+    for (int ks = 0; ks < KG; ++ks) wgT[ks] = whg[(size_t)cc * 2 * H + 16 * (ks >> 2) + 4 * kg + (ks & 3)];
+    int len4[4];
+    long long base4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = row0 + 4 * kg + r;
+        len4[r] = b < a.B ? a.lens[b] : 0;
+        base4[r] = (long long)min(b, a.B - 1) * a.T;
+    }
+    auto pos_of = [&](int r, int t) { return dir ? len4[r] - 1 - t : t; };
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    float rr4[4], uu4[4], cn4[4], hp4[4], go4[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (t >= 0 && t < len4[r]) {
+                const size_t p = (size_t)(base4[r] + pos_of(r, t));
+                rr4[r] = a.tape_ru[dir][p * 2 * H + cc]; uu4[r] = a.tape_ru[dir][p * 2 * H + H + cc]; cn4[r] = a.tape_c[dir][p * H + cc];
+                go4[r] = a.dout[p * 2 * H + dir * H + cc];
+                hp4[r] = t > 0 ? a.out[(size_t)(base4[r] + pos_of(r, t - 1)) * 2 * H + dir * H + cc] : 0.f;
+            } else { rr4[r] = uu4[r] = cn4[r] = go4[r] = hp4[r] = 0.f; }
+        }
+    };
+    fetch(a.T - 1);
+    for (int t = a.T - 1; t >= 0; --t) {
+        float dh4[4], du4[4];
+        size_t p4[4];
+        bool live4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kg + r;
+            live4[r] = t < len4[r];
+            p4[r] = (size_t)(base4[r] + (live4[r] ? pos_of(r, t) : 0));
+            dh4[r] = live4[r] ? go4[r] + carry[r] : 0.f;
+            du4[r] = dh4[r] * (hp4[r] - cn4[r]);
+            const float dzc = dh4[r] * (1.0f - uu4[r]) * (1.0f - cn4[r] * cn4[r]);
+            const float dzu = du4[r] * uu4[r] * (1.0f - uu4[r]);
+            dzc_s[row][cc] = dzc;
+            dzg_s[row][H + cc] = dzu;
+            if (live4[r]) { a.dzc[dir][p4[r] * H + cc] = dzc; a.dzg[dir][p4[r] * 2 * H + H + cc] = dzu; }
+        }
+        __syncthreads();
+        // d(r*h) = dzc . Wc_h^T
+        f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;
+        {
+            f32x4 av[KC / 4];
+#pragma unroll
+            for (int kb = 0; kb < KC / 4; ++kb) av[kb] = *reinterpret_cast<const f32x4*>(&dzc_s[c16][16 * kb + 4 * kg]);
+#pragma unroll
+            for (int ks = 0; ks < KC; ks += 2) {
+                da = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][ks & 3], wcT[ks], da, 0, 0, 0);
+                db = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][(ks & 3) + 1], wcT[ks + 1], db, 0, 0, 0);
+            }
+            da += db;
+        }
+        float keep4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kg + r;
+            const float drh = da[r];
+            const float dzr = drh * hp4[r] * rr4[r] * (1.0f - rr4[r]);
+            keep4[r] = dh4[r] * uu4[r] + drh * rr4[r];
+            dzg_s[row][cc] = dzr;
+            if (live4[r]) a.dzg[dir][p4[r] * 2 * H + cc] = dzr;
+        }
+        __syncthreads();
+        // carry += [dzr | dzu] . Wg_h^T
+        f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = ga;
+        {
+            f32x4 av[KG / 4];
+#pragma unroll
+            for (int kb = 0; kb < KG / 4; ++kb) av[kb] = *reinterpret_cast<const f32x4*>(&dzg_s[c16][16 * kb + 4 * kg]);
+#pragma unroll
+            for (int ks = 0; ks < KG; ks += 2) {
+                ga = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][ks & 3], wgT[ks], ga, 0, 0, 0);
+                gb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][(ks & 3) + 1], wgT[ks + 1], gb, 0, 0, 0);
+            }
+            ga += gb;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) carry[r] = live4[r] ? keep4[r] + ga[r] : carry[r];
+        fetch(t - 1);
+        __syncthreads();           // every wave is past its reads of dzc_s / dzg_s before the next step rewrites them
     }
 }
 

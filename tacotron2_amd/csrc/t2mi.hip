@@ -2143,6 +2143,11 @@ extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
 #include "train_step.h"
 
 // ------------------------------------------------------------------------------------------------
+// training step of the Tacotron-1 PostNet model (BASELINE.json configs[4])
+// ------------------------------------------------------------------------------------------------
+#include "v1_train.h"
+
+// ------------------------------------------------------------------------------------------------
 // spectrogram -> waveform (Griffin-Lim)
 // ------------------------------------------------------------------------------------------------
 #include "vocoder.h"

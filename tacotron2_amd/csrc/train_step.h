@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const float mu = mean[c], is = invstd[c];
         for (int m = m0 + rl; m < m1; m += 4) {
             const size_t i = (size_t)m * C + c;
-            const float g = out[i] != 0.f ? d_out[i] * inv_keep : 0.f;
+            const float g = (!out || out[i] != 0.f) ? d_out[i] * inv_keep : 0.f;      // out == null: identity activation
             a += (double)g * (double)((y[i] - mu) * is);
             b += (double)g;
         }
@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float invM = 1.0f / (float)M;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M * C; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
-        const float g = out[i] != 0.f ? d_out[i] * inv_keep : 0.f;
+        const float g = (!out || out[i] != 0.f) ? d_out[i] * inv_keep : 0.f;
         const float xh = (y[i] - mean[c]) * invstd[c];
         dy[i] = gamma[c] * invstd[c] * (g - dbeta[c] * invM - xh * dgamma[c] * invM);
     }

@@ -227,21 +227,104 @@ class DecoderV1:
         return mel, stop, (SimpleNamespace(alignment_history=_AlignmentHistory(align)), None, None)
 
 
+class PostNetTrainer:
+    """One t2v1_ptrainer: tape + workspaces of PostNet(is_training=True) for a fixed (B, T) and of its backward pass
+    (include/t2mi.h, "Tacotron-1 PostNet training step").  The trainable state is ONE flat fp32 device buffer holding every
+    ``v1/postnet/`` variable in TF layout (``training.flatten_spec`` order); the kernels read it in place, so an optimizer step
+    needs no refresh.  ``export()`` rebuilds the engine's inference copies (PREDICT / EVAL) from the buffer."""
+
+    PREFIX = "v1/postnet/"
+
+    def __init__(self, engine: EngineV1, B: int, T: int, spec):
+        self.engine, self.B, self.T, self.spec = engine, int(B), int(T), spec
+        self._spec = spec
+        self._h = C.c_void_p()
+        _lib.check(engine.lib.t2v1_postnet_trainer_create(engine._model, self.B, self.T, C.byref(self._h)))
+        for name, shape, off, size in spec:
+            _lib.check(engine.lib.t2v1_postnet_trainer_bind(self._h, name.encode(), int(off)))
+
+    @classmethod
+    def postnet_weights(cls, weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+        return {k: v for k, v in weights.items() if k.startswith(cls.PREFIX)}
+
+    def _flat(self, t: torch.Tensor, what: str) -> torch.Tensor:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                and t.numel() == training.flat_size(self.spec)):
+            raise ValueError(f"{what} must be a contiguous fp32 device tensor of {training.flat_size(self.spec)} elements")
+        return t
+
+    def forward(self, flat_params: torch.Tensor, mel) -> torch.Tensor:
+        eng = self.engine
+        mel = eng._f32(mel)
+        if tuple(mel.shape) != (self.B, self.T, eng.dims.num_mels):
+            raise ValueError(f"mel {tuple(mel.shape)} does not match the trainer's (B, T, num_mels) = {(self.B, self.T, eng.dims.num_mels)}")
+        self._params = self._flat(flat_params, "flat_params")           # the library reads it again in backward
+        out = eng._out(self.B, self.T, eng.dims.num_freq)
+        with eng.context.ordered():
+            _lib.check(eng.lib.t2v1_postnet_train_forward(self._h, flat_params.data_ptr(), mel.data_ptr(), out.data_ptr()))
+        return out
+
+    def backward(self, spec_target, spec_loss_mask, flat_grads: torch.Tensor, loss_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Gradient of spec_loss(last forward, spec_target, mask) (models.py:208-211) into flat_grads; returns dev [3] =
+        (sum, non-zero weight count, loss).  loss_count: dev [1], the count of a larger data-parallel batch."""
+        eng = self.engine
+        y, m = eng._f32(spec_target), eng._f32(spec_loss_mask)
+        if tuple(y.shape) != (self.B, self.T, eng.dims.num_freq) or tuple(m.shape) != (self.B, self.T):
+            raise ValueError("label shapes do not match the trainer's (B, T)")
+        self._flat(flat_grads, "flat_grads")
+        cnt = None if loss_count is None else eng._f32(loss_count).reshape(1)
+        out = eng._out(3)
+        with eng.context.ordered():
+            _lib.check(eng.lib.t2v1_postnet_train_backward(self._h, y.data_ptr(), m.data_ptr(), None if cnt is None else cnt.data_ptr(),
+                                                           flat_grads.data_ptr(), out.data_ptr()))
+        return out
+
+    def update_moving_stats(self, flat_params: torch.Tensor, momentum: float = 0.99):
+        with self.engine.context.ordered():
+            _lib.check(self.engine.lib.t2v1_postnet_trainer_update_moving_stats(self._h, self._flat(flat_params, "flat_params").data_ptr(),
+                                                                                float(momentum)))
+
+    def export(self, flat_params: torch.Tensor):
+        with self.engine.context.ordered():
+            _lib.check(self.engine.lib.t2v1_postnet_trainer_export(self._h, self._flat(flat_params, "flat_params").data_ptr()))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.engine, "_model", None):
+            self.engine.lib.t2v1_postnet_trainer_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PostNet:
-    """tacotron_v1.py:156-186: CBHG on the mel spectrogram, then Dense(num_freq)."""
+    """tacotron_v1.py:156-186: CBHG on the mel spectrogram, then Dense(num_freq).  ``is_training=True`` (batch-statistics batch
+    norm, modules.py:149-157) needs the flat parameter buffer the training step owns: ``flat_params`` / ``spec`` (see
+    ``PostNetTrainer``); the call then leaves a tape for ``trainer.backward``."""
 
     def __init__(self, is_training, num_freq, cbhg_out_units=256, conv_channels=128, max_filter_width=8,
                  projection1_out_channels=256, projection2_out_channels=80, num_highway=4, engine: EngineV1 = None,
-                 name=None, dtype=None):
-        if is_training:
-            raise NotImplementedError("training-mode batch norm (batch statistics) is not built; inference arithmetic only")
-        self.num_freq, self._engine = num_freq, engine
+                 name=None, dtype=None, flat_params: Optional[torch.Tensor] = None, spec=None):
+        self.is_training, self.num_freq, self._engine = bool(is_training), num_freq, engine
+        self.flat_params, self.spec, self.trainer = flat_params, spec, None
+        if self.is_training and (flat_params is None or spec is None):
+            raise ValueError("PostNet(is_training=True) needs flat_params and spec (training.flatten_spec of the v1/postnet/ variables)")
 
     def __call__(self, inputs, **kwargs):
         return self.call(inputs)
 
     def call(self, inputs, **kwargs):
-        return self._engine.postnet(inputs)
+        if not self.is_training:
+            return self._engine.postnet(inputs)
+        B, T = int(inputs.shape[0]), int(inputs.shape[1])
+        if self.trainer is None or (self.trainer.B, self.trainer.T) != (B, T):
+            if self.trainer is not None:
+                self.trainer.close()
+            self.trainer = PostNetTrainer(self._engine, B, T, self.spec)
+        return self.trainer.forward(self.flat_params, inputs)
 
     def compute_output_shape(self, input_shape):
         return (input_shape[0], input_shape[1], self.num_freq)
@@ -299,17 +382,83 @@ class SingleSpeakerTacotronV1Model:
 
 class TacotronV1PostNetModel:
     """models.py:185-263.  ``audio``: a ``tacotron2_amd.audio.Audio`` (the reference's constructor argument, :185-187);
-    when given, PREDICT adds the Griffin-Lim waveform of the predicted spectrogram (:256)."""
+    when given, PREDICT adds the Griffin-Lim waveform of the predicted spectrogram (:256).
 
-    def __init__(self, params: V1Dims, engine: EngineV1, audio=None):
+    TRAIN (:213-234): ``model_fn`` runs one whole training step -- PostNet(is_training=True), L1 spec_loss, backward,
+    clip_by_global_norm(1.0) + Adam at the (decayed) learning rate, the batch-norm UPDATE_OPS -- on the model's flat parameter
+    buffer (``self.flat_params``, created from ``weights`` at the first TRAIN call) and returns {"loss", "global_step"}.
+    The engine's inference copies are refreshed lazily, at the next EVAL / PREDICT call."""
+
+    def __init__(self, params: V1Dims, engine: EngineV1, audio=None, weights: Optional[Dict[str, np.ndarray]] = None):
         self.params, self.engine, self.audio = params, engine, audio
-        self.post_net = PostNet(False, params.num_freq, params.post_net_cbhg_out_units, params.post_net_conv_channels,
-                                params.post_net_max_filter_width, params.post_net_projection1_out_channels,
-                                params.post_net_projection2_out_channels, params.post_net_num_highway, engine=engine)
+        self.post_net = self._make_post_net(False)
+        self._weights = weights
+        self.flat_params = self.flat_grads = self.optimizer = self._train_net = None
+        self.global_step, self._stale = 0, False
+
+    def _make_post_net(self, is_training, **kw):
+        p = self.params
+        return PostNet(is_training, p.num_freq, p.post_net_cbhg_out_units, p.post_net_conv_channels, p.post_net_max_filter_width,
+                       p.post_net_projection1_out_channels, p.post_net_projection2_out_channels, p.post_net_num_highway,
+                       engine=self.engine, **kw)
+
+    @staticmethod
+    def _hp(params, name, default):
+        if params is None:
+            return default
+        return params.get(name, default) if isinstance(params, dict) else getattr(params, name, default)
+
+    def _setup_training(self, params):
+        if self._weights is None:
+            raise ValueError("TacotronV1PostNetModel(weights=...) is needed for mode TRAIN (the initial values of the variables)")
+        w = PostNetTrainer.postnet_weights(self._weights)
+        self.spec = training.flatten_spec(w)
+        self.flat_params = torch.from_numpy(training.flatten(w, self.spec)).to(self.engine.device)
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        init = self._hp(params, "initial_learning_rate", 0.002)
+        lr = (lambda step: training.learning_rate_decay(init, step)) if self._hp(params, "decay_learning_rate", True) else init
+        self.optimizer = training.AdamOptimizer(self.engine, self.flat_params.numel(), lr, self._hp(params, "adam_beta1", 0.9),
+                                                self._hp(params, "adam_beta2", 0.999), self._hp(params, "adam_eps", 1e-8))
+        self._train_net = self._make_post_net(True, flat_params=self.flat_params, spec=self.spec)
+
+    def train_step(self, features, labels, params=None, group=None):
+        """One TRAIN step (models.py:204-234).  Data parallel (``group`` of world > 1): as ``training.Trainer.train_step`` --
+        the ranks sum their non-zero loss-weight counts first, each differentiates sum_rank / count_total, gradients are summed
+        by one all-reduce (RCCL), the moving statistics are averaged."""
+        if self.flat_params is None:
+            self._setup_training(params)
+        f = features if isinstance(features, dict) else features.__dict__
+        lab = labels if isinstance(labels, dict) else labels.__dict__
+        eng, net = self.engine, self._train_net
+        world = training._world(group)
+        self.flat_grads.zero_()
+        linear_output = net(f["mel"])
+        count = None
+        mask = eng._f32(lab["spec_loss_mask"])
+        if world > 1:
+            count = (mask != 0).sum().to(torch.float32).reshape(1) * float(self.params.num_freq)
+            training.allreduce_sum(count, group)
+        parts = net.trainer.backward(lab["spec"], mask, self.flat_grads, count)
+        loss = parts[2]
+        if world > 1:
+            training.allreduce_sum(self.flat_grads, group)
+            loss = training.allreduce_sum(parts[:1].clone(), group)[0] / count[0].clamp(min=1)
+        self.global_step = self.optimizer.apply_gradients(self.flat_grads, self.flat_params, global_step=self.global_step, clip_norm=1.0)
+        net.trainer.update_moving_stats(self.flat_params)
+        if world > 1:
+            training.Trainer._average_moving_stats(net.trainer, self.flat_params, group, world)
+        self._stale = True
+        return {"loss": loss, "global_step": self.global_step, "spec": linear_output}
+
+    def trained_weights(self) -> Dict[str, np.ndarray]:
+        return training.unflatten(self.flat_params, self.spec)
 
     def model_fn(self, features, labels=None, mode=ModeKeys.PREDICT, params=None):
         if mode == ModeKeys.TRAIN:
-            raise NotImplementedError("the training step (gradients) is not built yet")
+            return self.train_step(features, labels, params)
+        if self._stale:                                                  # predict with the trained variables
+            self._train_net.trainer.export(self.flat_params)
+            self._stale = False
         f = features if isinstance(features, dict) else features.__dict__
         linear_output = self.post_net(f["mel"])
         if mode == ModeKeys.EVAL:

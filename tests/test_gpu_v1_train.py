@@ -1,0 +1,201 @@
+"""GPU parity of the Tacotron-1 PostNet training step (BASELINE.json configs[4]; TacotronV1PostNetModel.model_fn(TRAIN),
+tacotron/models.py:190-233) through the C-ABI (t2v1_postnet_train_*) against the float64 torch restatement
+(oracle/v1_torch_train.py, gradients by autograd).  Tolerances: forward 1e-3 absolute (north_star); gradients
+2e-3 * max|reference gradient of that variable| + 1e-9, with the scale asserted non-degenerate, plus -- per element -- the
+oracle's own KINK SPREAD: the loss is piecewise smooth (ReLU after the batch norms and in the highway layers), and an fp32 forward
+pass can round a ReLU input onto the other side of zero, after which the hand-written backward correctly differentiates the
+neighbouring piece.  Measured: at (B, T) = (5, 23) one highway_3 input of 1.99e-6 (the smallest of the pass) flipped and moved
+its column of highway_3/H/kernel by 4.6e-3 of the scale, every other column agreeing to 1e-7.  The spread is the change of the
+oracle's gradient when every ReLU input within 1e-5 of zero is differentiated on its other side (relu_shift); it is zero for
+most elements and the test asserts that it stays a small correction."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import t2_oracle as O
+from oracle import v1_torch_train as VT
+from tacotron2_amd.hparams import V1_PROFILE
+from tacotron2_amd.weights_v1 import init_weights_v1
+
+ATOL = 1e-3
+KINK = 1e-5          # ReLU inputs this close to zero may be differentiated on either side (5x the flip that was observed)
+# the PostNet of the reference's hparams (hparams.py:52-58) on a narrower spectrogram: 128 GRU units per direction as published
+POST = V1_PROFILE.replace(num_freq=257)
+POST_NARROW = V1_PROFILE.replace(num_freq=64, post_net_conv_channels=32, post_net_max_filter_width=5, post_net_projection1_out_channels=64,
+                                 post_net_num_highway=2)
+# projection2 == GRU width: no adjustment layer (modules.py:216)
+POST_NOADJ = V1_PROFILE.replace(num_mels=128, num_freq=96, post_net_conv_channels=16, post_net_max_filter_width=3,
+                                post_net_projection1_out_channels=32, post_net_projection2_out_channels=128, post_net_num_highway=1)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _case(d, B, T, seed, ragged=True):
+    rng = np.random.default_rng(seed)
+    mel = rng.uniform(0, 1, (B, T, d.num_mels)).astype(np.float32)
+    spec = rng.uniform(0, 1, (B, T, d.num_freq)).astype(np.float32)
+    lens = rng.integers(max(1, T // 2), T + 1, size=B) if ragged else np.full(B, T)
+    lens[0] = T
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.float32)
+    return mel, spec, mask
+
+
+def _setup(d, seed=11):
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import EngineV1, PostNetTrainer
+    w = init_weights_v1(d, seed, perturb=True)
+    eng = EngineV1(d, w)
+    pw = PostNetTrainer.postnet_weights(w)
+    spec = TR.flatten_spec(pw)
+    flat = torch.tensor(TR.flatten(pw, spec), device="cuda")
+    return w, eng, pw, spec, flat
+
+
+@pytest.mark.parametrize("d,B,T", [(POST_NARROW, 3, 11), (POST_NARROW, 17, 9), (POST_NOADJ, 2, 7), (POST, 5, 23), (POST, 33, 40)])
+def test_postnet_training_forward_and_every_gradient_against_autograd(d, B, T):
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import PostNetTrainer
+    w, eng, pw, spec, flat = _setup(d)
+    mel, target, mask = _case(d, B, T, 100 * B + T)
+    ref = VT.postnet_train_forward_backward(d, w, mel, target, mask)
+    side = [VT.postnet_train_forward_backward(d, w, mel, target, mask, relu_shift=sh)["grads"] for sh in (KINK, -KINK)]
+    tr = PostNetTrainer(eng, B, T, spec)
+    out = tr.forward(flat, mel)
+    np.testing.assert_allclose(_np(out), ref["spec"], atol=ATOL)
+    grads = torch.full_like(flat, float("nan"))               # every trainable slice must be written
+    parts = _np(tr.backward(target, mask, grads))
+    assert abs(parts[2] - ref["loss"]) <= 2e-4 * max(1.0, abs(ref["loss"]))
+    assert parts[1] == mask.sum() * d.num_freq
+    got = TR.unflatten(grads, spec)
+    checked = 0
+    for name, g_ref in ref["grads"].items():
+        if name.endswith(("moving_mean", "moving_variance")):
+            continue
+        scale = float(np.abs(g_ref).max())
+        assert scale >= 1e-7, (name, scale)                   # a vanishing reference gradient would make the comparison vacuous
+        assert np.isfinite(got[name]).all(), name
+        spread = np.abs(side[0][name] - g_ref) + np.abs(side[1][name] - g_ref)
+        assert float(np.median(spread)) <= 5e-3 * scale and float(spread.max()) <= 0.1 * scale, (name, "kink spread too wide to test")
+        excess = np.abs(got[name] - g_ref) - (2e-3 * scale + 1e-9 + 1.5 * spread)
+        assert float(excess.max()) <= 0.0, (name, float(np.abs(got[name] - g_ref).max()), scale, float(spread.max()))
+        checked += 1
+    assert checked == sum(1 for n in pw if not n.endswith(("moving_mean", "moving_variance")))
+    # a second backward without a forward is refused (the tape is consumed)
+    with pytest.raises(Exception):
+        tr.backward(target, mask, grads)
+    tr.close()
+    eng.close()
+
+
+def test_postnet_training_data_parallel_count_scales_the_gradient():
+    """loss_count (the non-zero weight count of a larger data-parallel batch) replaces this batch's own count in the gradient."""
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import PostNetTrainer
+    d, B, T = POST_NARROW, 4, 9
+    w, eng, pw, spec, flat = _setup(d)
+    mel, target, mask = _case(d, B, T, 5)
+    tr = PostNetTrainer(eng, B, T, spec)
+    g1, g2 = torch.zeros_like(flat), torch.zeros_like(flat)
+    tr.forward(flat, mel)
+    own = float(_np(tr.backward(target, mask, g1))[1])
+    tr.forward(flat, mel)
+    tr.backward(target, mask, g2, loss_count=torch.tensor([2.5 * own], device="cuda"))
+    ref = VT.postnet_train_forward_backward(d, w, mel, target, mask, loss_count=2.5 * own)
+    got = TR.unflatten(g2, spec)
+    for name in ("v1/postnet/linear/kernel", "v1/postnet/cbhg/conv1d_K3/kernel", "v1/postnet/cbhg/bidirectional_rnn/bw/gru_cell/gates/kernel"):
+        scale = float(np.abs(ref["grads"][name]).max())
+        assert float(np.abs(got[name] - ref["grads"][name]).max()) <= 2e-3 * scale + 1e-9
+    torch.testing.assert_close(g1, g2 * 2.5, rtol=1e-5, atol=1e-5 * float(g1.abs().max()))
+    tr.close()
+    eng.close()
+
+
+def test_postnet_model_fn_train_loop_against_oracle_and_export():
+    """model_fn(TRAIN) three times (models.py:204-234: forward, L1 loss, clip_by_global_norm(1.0), Adam at the Noam rate,
+    UPDATE_OPS) against the oracle loop; then EVAL / PREDICT use the trained variables (device-side export = a fresh engine
+    built from the trained weights)."""
+    from tacotron2_amd.tacotron_v1 import EngineV1, ModeKeys, TacotronV1PostNetModel
+    d, B, T = POST_NARROW, 6, 13
+    w = init_weights_v1(d, 21, perturb=True)
+    eng = EngineV1(d, w)
+    model = TacotronV1PostNetModel(d, eng, weights=w)
+    hp = {"initial_learning_rate": 0.002, "decay_learning_rate": True, "adam_beta1": 0.9, "adam_beta2": 0.999, "adam_eps": 1e-8}
+    names = sorted(k for k in w if k.startswith("v1/postnet/"))
+    trainable = [k for k in names if not k.endswith(("moving_mean", "moving_variance"))]
+    w_ref = {k: w[k].copy() for k in names}
+    m_ref = {k: np.zeros_like(w[k]) for k in trainable}
+    v_ref = {k: np.zeros_like(w[k]) for k in trainable}
+    bn = ["v1/postnet/cbhg/conv1d_K%d" % k for k in range(1, d.post_net_max_filter_width + 1)] + ["v1/postnet/cbhg/proj1", "v1/postnet/cbhg/proj2"]
+    lrs = []
+    for it in range(3):
+        mel, target, mask = _case(d, B, T, 50 + it)
+        full = dict(w)
+        full.update(w_ref)
+        ref = VT.postnet_train_forward_backward(d, full, mel, target, mask)
+        res = model.model_fn({"mel": mel}, {"spec": target, "spec_loss_mask": mask}, ModeKeys.TRAIN, hp)
+        assert res["global_step"] == it + 1
+        assert abs(float(res["loss"]) - ref["loss"]) <= 2e-4 * max(1.0, abs(ref["loss"])), (it, float(res["loss"]), ref["loss"])
+        np.testing.assert_allclose(_np(res["spec"]), ref["spec"], atol=ATOL)
+        lr = O.learning_rate_decay(0.002, it)
+        lrs.append(lr)
+        clipped, _ = O.clip_by_global_norm([ref["grads"][k] for k in trainable], 1.0)
+        for k, g in zip(trainable, clipped):
+            w_ref[k], m_ref[k], v_ref[k] = O.adam_apply(w_ref[k], g, m_ref[k], v_ref[k], it + 1, lr)
+        n = B * T
+        for p in bn:                                             # UPDATE_OPS (App. A4: Bessel-corrected variance)
+            mu, var = ref["bn_stats"][p]
+            q = p + "/batch_normalization"
+            w_ref[q + "/moving_mean"] = (0.99 * w_ref[q + "/moving_mean"] + 0.01 * mu).astype(np.float32)
+            w_ref[q + "/moving_variance"] = (0.99 * w_ref[q + "/moving_variance"] + 0.01 * var * n / (n - 1)).astype(np.float32)
+    got = model.trained_weights()
+    for p in bn:
+        for s in ("/batch_normalization/moving_mean", "/batch_normalization/moving_variance"):
+            np.testing.assert_allclose(got[p + s], w_ref[p + s], rtol=1e-4, atol=1e-6)
+    tot = sum(lrs)
+    for k in ("v1/postnet/linear/kernel", "v1/postnet/cbhg/proj1/kernel", "v1/postnet/cbhg/conv1d_K2/kernel",
+              "v1/postnet/cbhg/bidirectional_rnn/fw/gru_cell/gates/kernel", "v1/postnet/cbhg/highway_1/T/kernel"):
+        assert float(np.abs(got[k] - w[k]).max()) <= 1.05 * tot
+        assert float(np.abs(got[k] - w[k]).max()) >= 0.5 * lrs[0]              # Adam's first step moves by lr wherever g != 0
+        np.testing.assert_allclose(got[k], w_ref[k], atol=0.25 * tot)
+    # EVAL after TRAIN: the inference copies are rebuilt from the trained variables
+    mel, target, mask = _case(d, B, T, 99)
+    ev = model.model_fn({"mel": mel}, {"spec": target, "spec_loss_mask": mask}, ModeKeys.EVAL)
+    full = dict(w)
+    full.update(got)
+    eng2 = EngineV1(d, full)
+    np.testing.assert_allclose(_np(ev["spec"]), _np(eng2.postnet(mel)), atol=2e-6, rtol=2e-6)
+    eng2.close()
+    eng.close()
+
+
+def test_postnet_trainer_argument_errors():
+    import torch
+    from tacotron2_amd.tacotron_v1 import EngineV1, PostNet, PostNetTrainer
+    from tacotron2_amd import training as TR
+    d = POST_NARROW
+    w, eng, pw, spec, flat = _setup(d)
+    tr = PostNetTrainer(eng, 2, 5, spec)
+    with pytest.raises(ValueError):
+        tr.forward(flat, np.zeros((2, 6, d.num_mels), np.float32))
+    with pytest.raises(ValueError):
+        tr.forward(flat[:-4], np.zeros((2, 5, d.num_mels), np.float32))
+    with pytest.raises(Exception):                                               # backward before any forward
+        tr.backward(np.zeros((2, 5, d.num_freq), np.float32), np.ones((2, 5), np.float32), torch.zeros_like(flat))
+    with pytest.raises(ValueError):
+        PostNet(True, d.num_freq, engine=eng)                                    # no parameter buffer
+    tr.close()
+    # a GRU width the whole-sequence kernels are not built for is refused, not mis-computed
+    d2 = V1_PROFILE.replace(num_freq=16, post_net_cbhg_out_units=64, post_net_conv_channels=8, post_net_max_filter_width=2,
+                            post_net_projection1_out_channels=16, post_net_num_highway=1)
+    w2 = init_weights_v1(d2, 3)
+    eng2 = EngineV1(d2, w2)
+    with pytest.raises(Exception):
+        PostNetTrainer(eng2, 2, 5, TR.flatten_spec(PostNetTrainer.postnet_weights(w2)))
+    eng2.close()
+    eng.close()

@@ -99,3 +99,43 @@ def test_v1_oracle_reproduces_committed_golden(name):
     assert int(ref["steps"]) == int(gold["steps"])
     for k in ("memory", "mel", "stop", "alignment", "spec"):
         np.testing.assert_allclose(ref[k], gold[k], atol=1e-5, err_msg=k)
+
+
+def test_postnet_training_oracle_forward_and_gradients():
+    """oracle/v1_torch_train.py (the fp64 autograd checker of the HIP backward pass of TacotronV1PostNetModel's training step):
+    (1) with the moving statistics in place of the batch statistics its forward is the inference PostNet of the NumPy oracle;
+    (2) its gradients agree with central finite differences of its own loss on a sample of parameters of every layer kind."""
+    from oracle import v1_torch_train as VT
+    from tacotron2_amd.hparams import V1Dims
+    from tacotron2_amd.weights_v1 import init_weights_v1
+    d = V1Dims(num_mels=6, num_freq=9, post_net_cbhg_out_units=8, post_net_conv_channels=5, post_net_max_filter_width=4,
+               post_net_projection1_out_channels=7, post_net_projection2_out_channels=6, post_net_num_highway=2)
+    w = init_weights_v1(d, 3, perturb=True)
+    rng = np.random.default_rng(1)
+    B, T = 2, 7
+    mel = rng.uniform(0, 1, (B, T, d.num_mels)).astype(np.float32)
+    spec = rng.uniform(0, 1, (B, T, d.num_freq)).astype(np.float32)
+    mask = (np.arange(T)[None, :] < np.array([7, 4])[:, None]).astype(np.float32)
+    inf = VT.postnet_train_forward_backward(d, w, mel, spec, mask, use_moving=True)
+    np.testing.assert_allclose(inf["spec"], V.postnet_v1(d, w, mel), atol=2e-5)
+    ref = VT.postnet_train_forward_backward(d, w, mel, spec, mask)
+    assert abs(ref["loss"] - float(np.sum(np.abs(ref["spec"] - spec) * mask[:, :, None]) / (mask.sum() * d.num_freq))) < 1e-6
+    names = ["v1/postnet/cbhg/conv1d_K4/kernel", "v1/postnet/cbhg/conv1d_K2/batch_normalization/gamma", "v1/postnet/cbhg/proj1/kernel",
+             "v1/postnet/cbhg/proj2/batch_normalization/beta", "v1/postnet/cbhg/adjustment/kernel", "v1/postnet/cbhg/highway_1/T/kernel",
+             "v1/postnet/cbhg/highway_2/H/bias", "v1/postnet/cbhg/bidirectional_rnn/fw/gru_cell/gates/kernel",
+             "v1/postnet/cbhg/bidirectional_rnn/bw/gru_cell/candidate/kernel", "v1/postnet/cbhg/bidirectional_rnn/bw/gru_cell/gates/bias",
+             "v1/postnet/linear/kernel"]
+    eps = 1e-4
+    for name in names:
+        flat = w[name].reshape(-1)
+        for idx in rng.choice(flat.size, size=min(3, flat.size), replace=False):
+            vals = []
+            for sgn in (1, -1):
+                w2 = dict(w)
+                a = w[name].astype(np.float64).copy().reshape(-1)
+                a[idx] += sgn * eps
+                w2[name] = a.reshape(w[name].shape)
+                vals.append(VT.postnet_train_forward_backward(d, w2, mel, spec, mask)["loss"])
+            fd = (vals[0] - vals[1]) / (2 * eps)
+            g = float(ref["grads"][name].reshape(-1)[idx])
+            assert abs(fd - g) <= 2e-3 * max(abs(fd), abs(g)) + 2e-6, (name, idx, fd, g)
