@@ -365,10 +365,22 @@ def main():
                 return (time.perf_counter() - t_) / reps, res
             dt_f, mel1v = timed(v1_fwd)
             dt_p, _ = timed(lambda: eng1.postnet(mel1v))
+            # TacotronV1PostNetModel.model_fn(TRAIN) (models.py:204-234; train_postnet.py): PostNet forward with batch statistics,
+            # L1 loss, backward, clip + Adam, moving statistics -- whole steps, batch_size 32 (hparams.py:63)
+            from tacotron2_amd.tacotron_v1 import ModeKeys, TacotronV1PostNetModel
+            w1 = init_weights_v1(d1, 1234 + 5)
+            pmodel = TacotronV1PostNetModel(d1, eng1, weights=w1)
+            spec1v = torch.tensor(rng1.uniform(0, 1, (B1, To1, d1.num_freq)).astype(np.float32), device="cuda")
+            lens_o = rng1.integers(To1 // 2, To1 + 1, B1); lens_o[0] = To1
+            msk1v = torch.tensor((np.arange(To1)[None, :] < lens_o[:, None]).astype(np.float32), device="cuda")
+            dt_pt, res_pt = timed(lambda: pmodel.model_fn({"mel": mel1v}, {"spec": spec1v, "spec_loss_mask": msk1v}, ModeKeys.TRAIN))
             out["v1"] = {"workload": "BASELINE.json configs[4]: Tacotron v1 (tacotron_v1.py), reference hparams sizes, B=32, T_in<=140, "
-                                     "800 frames: EncoderV1 (CBHG) + teacher-forced DecoderV1 forward; mel -> linear CBHG PostNet forward",
+                                     "800 frames: EncoderV1 (CBHG) + teacher-forced DecoderV1 forward; mel -> linear CBHG PostNet forward; "
+                                     "PostNet training step (forward, L1 loss, backward, clip + Adam, moving statistics)",
                          "teacher_forced_ms": dt_f * 1e3, "teacher_forced_mel_frames_per_s": B1 * To1 / dt_f,
-                         "postnet_ms": dt_p * 1e3, "postnet_spectrogram_frames_per_s": B1 * To1 / dt_p}
+                         "postnet_ms": dt_p * 1e3, "postnet_spectrogram_frames_per_s": B1 * To1 / dt_p,
+                         "postnet_train_step_ms": dt_pt * 1e3, "postnet_train_spectrogram_frames_per_s": B1 * To1 / dt_pt,
+                         "postnet_train_loss": float(res_pt["loss"])}
             eng1.close()
         except Exception as ex:
             out["v1"] = {"error": repr(ex)}

@@ -786,6 +786,8 @@ __device__ __forceinline__ float fast_tanhf(float x) {
     const float e = __expf(2.0f * x);
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// 1 / (1 + e^-x) on the hardware exp2 / rcp (about 1e-6 relative; e^-x = inf for x < -88 gives exactly 0)
+__device__ __forceinline__ float fast_sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 #ifdef T2_ATTN_STAMPS   // diagnostic builds (tools/attn_bench.hip) only
 __device__ unsigned long long* g_attn_stamps;
@@ -1840,13 +1842,14 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
     const int cg0 = (2 * wave) * 16 + c16, cg1 = cg0 + 16, cc = wave * 16 + c16;     // gate columns (r | u), candidate column
     auto pos_of = [&](int r, int t) { return dir ? len4[r] - 1 - t : t; };
     float xg0[4], xg1[4], xc[4];
+    // branch-free prefetch: dead steps (t >= len) read a clamped, valid position and their values are never used (the state is
+    // copied through).  A conditional load here made the compiler keep x in scratch memory and wait for every load at once.
     auto fetch = [&](int t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (t < len4[r]) {
-                const float* p = xz + (size_t)(base4[r] + pos_of(r, t)) * 3 * H;
-                xg0[r] = p[cg0]; xg1[r] = p[cg1]; xc[r] = p[2 * H + cc];
-            } else { xg0[r] = xg1[r] = xc[r] = 0.f; }
+            const int pos = min(max(pos_of(r, t), 0), a.T - 1);
+            const float* p = xz + (size_t)(base4[r] + pos) * 3 * H;
+            xg0[r] = p[cg0]; xg1[r] = p[cg1]; xc[r] = p[2 * H + cc];
         }
     };
     fetch(0);
@@ -1862,10 +1865,13 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
             g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][ks & 3], wg0[ks], g0, 0, 0, 0);
             g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks >> 2][ks & 3], wg1[ks], g1, 0, 0, 0);
         }
+        // all of the prefetched x is waited for HERE (the loads have had the whole gates phase): the vector-memory counter is
+        // in order, so a wait for xc placed after this step's stores would wait for those stores too
+        asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * kg + r;
-            const float s0 = sigmoidf_(g0[r] + xg0[r]), s1 = sigmoidf_(g1[r] + xg1[r]);
+            const float s0 = fast_sigmoidf(g0[r] + xg0[r]), s1 = fast_sigmoidf(g1[r] + xg1[r]);
             if (cg0 < H) rhs[row][cg0] = s0 * hs[row][cg0]; else us[row][cg0 - H] = s0;
             if (cg1 < H) rhs[row][cg1] = s1 * hs[row][cg1]; else us[row][cg1 - H] = s1;
             if (tape_ru != nullptr && t < len4[r]) {
@@ -1888,7 +1894,7 @@ __global__ __launch_bounds__(512) void gru_seq_kernel(GruSeqArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * kg + r;
-            const float cand = tanhf(ca[r] + xc[r]);
+            const float cand = fast_tanhf(ca[r] + xc[r]);
             const float u = us[row][cc], hp = hs[row][cc];
             const bool live = t < len4[r];
             hn4[r] = live ? u * hp + (1.0f - u) * cand : hp;
@@ -1956,20 +1962,29 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdArgs a) {
     }
     auto pos_of = [&](int r, int t) { return dir ? len4[r] - 1 - t : t; };
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
-    float rr4[4], uu4[4], cn4[4], hp4[4], go4[4];
+    float rr4[4], uu4[4], cn4[4], hp4[4], go4[4];          // step t
+    float nrr[4], nuu[4], ncn[4], nhp[4], ngo[4];          // step t - 1, in flight during step t
+    // branch-free prefetch (see gru_seq_kernel): clamped positions, then a select -- the tape of dead positions was never
+    // written, so its contents must not reach the arithmetic.  Issued right after the first phase of step t and consumed at
+    // the top of step t - 1: two MFMA phases hide the latency.
+    const float* __restrict__ tru = a.tape_ru[dir];
+    const float* __restrict__ tcn = a.tape_c[dir];
     auto fetch = [&](int t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (t >= 0 && t < len4[r]) {
-                const size_t p = (size_t)(base4[r] + pos_of(r, t));
-                rr4[r] = a.tape_ru[dir][p * 2 * H + cc]; uu4[r] = a.tape_ru[dir][p * 2 * H + H + cc]; cn4[r] = a.tape_c[dir][p * H + cc];
-                go4[r] = a.dout[p * 2 * H + dir * H + cc];
-                hp4[r] = t > 0 ? a.out[(size_t)(base4[r] + pos_of(r, t - 1)) * 2 * H + dir * H + cc] : 0.f;
-            } else { rr4[r] = uu4[r] = cn4[r] = go4[r] = hp4[r] = 0.f; }
+            const bool live = t >= 0 && t < len4[r];
+            const size_t p = (size_t)(base4[r] + min(max(pos_of(r, t), 0), a.T - 1));
+            const size_t pp = (size_t)(base4[r] + min(max(pos_of(r, t - 1), 0), a.T - 1));
+            const float v_r = tru[p * 2 * H + cc], v_u = tru[p * 2 * H + H + cc], v_c = tcn[p * H + cc];
+            const float v_g = a.dout[p * 2 * H + dir * H + cc], v_h = a.out[pp * 2 * H + dir * H + cc];
+            nrr[r] = live ? v_r : 0.f; nuu[r] = live ? v_u : 0.f; ncn[r] = live ? v_c : 0.f; ngo[r] = live ? v_g : 0.f;
+            nhp[r] = (live && t > 0) ? v_h : 0.f;
         }
     };
     fetch(a.T - 1);
     for (int t = a.T - 1; t >= 0; --t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rr4[r] = nrr[r]; uu4[r] = nuu[r]; cn4[r] = ncn[r]; hp4[r] = nhp[r]; go4[r] = ngo[r]; }
         float dh4[4], du4[4];
         size_t p4[4];
         bool live4[4];
@@ -1986,6 +2001,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdArgs a) {
             dzg_s[row][H + cc] = dzu;
             if (live4[r]) { a.dzc[dir][p4[r] * H + cc] = dzc; a.dzg[dir][p4[r] * 2 * H + H + cc] = dzu; }
         }
+        fetch(t - 1);
         __syncthreads();
         // d(r*h) = dzc . Wc_h^T
         f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;
@@ -2026,7 +2042,6 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) carry[r] = live4[r] ? keep4[r] + ga[r] : carry[r];
-        fetch(t - 1);
         __syncthreads();           // every wave is past its reads of dzc_s / dzg_s before the next step rewrites them
     }
 }
