@@ -175,11 +175,16 @@ def main():
             B * 4.0 * (T_in * (U_ + E_) + 3 * T_in + 2 * 2 * (A_ + 2 * D_) + M * d.n_feed_frame + M * r + 1)
         flops_launch, bytes_launch = step_flops * n_dec, step_bytes * n_dec
         achieved = flops_launch / (ms_dec * 1e-3) / 1e12
-        traffic = None
+        # `traffic` cannot be measured inside this process (PMC counters need rocprofv3 around it): it is the figure of the last
+        # committed counter passes of THIS kernel (tools/evidence.sh -> tools/collect_profiles.py -> profiles/traffic.json), and
+        # the line says which capture (commit, library hash) it quotes
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("r02_persistent_decode_b64", {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                ent = tj.get(tj.get("current", "r02_persistent_decode_b64"), {})
+                traffic, traffic_source = ent.get("hbm_bytes_per_launch"), ent.get("source")
             except Exception:
                 traffic = None
         # the launch-per-phase schedule of round 1 (6 launches per step, hipGraph chunks), same decode, for comparison
@@ -197,7 +202,7 @@ def main():
         out["roofline"] = {"kernel": "pz::decode_kernel<4, 0> (persistent free-running decoder: one launch = %d decoder steps of the B=%d batch)" % (n_dec, B)
                                      if persist_ran else "launch-per-phase schedule (persistent decoder not eligible)",
                            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                            "avg_launch_ms": ms_dec, "launches_timed": reps, "us_per_decoder_step": ms_dec * 1e3 / n_dec,
                            "algorithmic_flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": bytes_launch,
                            "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,

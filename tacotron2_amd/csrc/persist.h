@@ -166,6 +166,9 @@ __device__ __forceinline__ bool word_wait(unsigned* w, unsigned target, int* s_a
 // Every operand address is (descriptor, per-lane byte offset lane * 16 in ONE VGPR, wave-uniform byte offset in an SGPR):
 // the address arithmetic stays on the scalar unit and hipcc has no loop-invariant pointer VGPRs to keep (or spill).
 __device__ __forceinline__ f32x4 ldw(rsrc_t r, unsigned l16, unsigned soff) {       // weights: read-only, cached
+#ifdef PZ_NO_WEIGHT_STREAM   // diagnostic builds only (tools/build_noweights.sh): every weight load reads the slab's first KiB, which
+    soff = 0u;               // stays in L1 -- the step time without any weight traffic = the most on-chip weight residency could give
+#endif
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)l16, (int)soff, 0));
 }
 __device__ __forceinline__ f32x4 ldx(rsrc_t r, unsigned l16, unsigned soff) {       // exchange slab: sc1
