@@ -775,10 +775,15 @@ struct AttnArgs {
 __host__ __device__ inline int attn_upl(int U, int F) { return (F <= 32 && U <= 128) ? 2 : 4; }
 __host__ __device__ inline int attn_fmax(int F) { return F <= 32 ? 32 : 64; }
 
+// Positions whose location features are held in LDS at a time: inputs longer than this are swept in chunks (features of a
+// chunk, then its energies), so that only 8 bytes per encoder position scale with T_in (previous alignments, energies) and
+// the 120 KB budget reaches T_in of several thousand instead of ~600.
+#define T2_ATTN_CHUNK 256
 __host__ __device__ inline int attn_lds_floats(int T, int U, int F, int K) {
     const int FP = (F + 3) & ~3, KP = (K + 3) & ~3, UP = (U + 3) & ~3;
     const int FMAX = attn_fmax(F);
-    return ((T + KP + 16 + 3) & ~3) + KP * FP + ((T + 8) * FMAX) + ((T + 3) & ~3) + 17 * UP + 64 + 2048 + FMAX * 64 * attn_upl(U, F);
+    const int TC = T < T2_ATTN_CHUNK ? T : T2_ATTN_CHUNK;
+    return ((T + KP + 16 + 3) & ~3) + KP * FP + ((TC + 8) * FMAX) + ((T + 3) & ~3) + 17 * UP + 64 + 2048 + FMAX * 64 * attn_upl(U, F);
 }
 
 // tanh via v_exp_f32 / v_rcp_f32: abs error < 1e-6 (the energies feed a softmax; tolerance budget 1e-3)
@@ -829,8 +834,8 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
     constexpr int UW = 64 * UPL;                        // padded unit count of the register layout
     float* s_prev = smem;                               // [T + KP + 16]: index i <-> position i - pad_l
     float* s_cw = s_prev + ((T + KP + 16 + 3) & ~3);    // [KP][FP] conv kernel, zero padded
-    float* s_f = s_cw + KP * FP;                        // [T + 8][FMAX], columns >= F are zero
-    float* s_e = s_f + (T + 8) * FMAX;                  // [T]
+    float* s_f = s_cw + KP * FP;                        // [min(T, T2_ATTN_CHUNK) + 8][FMAX] of the current chunk, columns >= F are zero
+    float* s_e = s_f + (min(T, T2_ATTN_CHUNK) + 8) * FMAX;   // [T]
     float* s_q = s_e + ((T + 3) & ~3);                  // [16][UP] partial sums, then [16*UP ..] = q + b_a
     float* s_red = s_q + 17 * UP;                       // [64]
     float* s_ctx = s_red + 64;                          // [<= 2048] context partials
@@ -916,9 +921,11 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
     T2_STAMP(1);
     __syncthreads();
     T2_STAMP(2);
-    // ---- phase 1: location features f[t][c] = sum_j w[j][c] * prev[t + j - pad_l] + b[c]   (:128-130)
-    {
-        const int nblk = (T + 7) >> 3;
+    // ---- phase 1: location features f[t][c] = sum_j w[j][c] * prev[t + j - pad_l] + b[c]   (:128-130) of positions
+    // c0 .. c0 + cn - 1 (row t - c0 of s_f)
+    auto features = [&](int c0, int cn) {
+        const int nblk = (cn + 7) >> 3;
+        const float* s_prev_c = s_prev + c0;
         for (int item = tid; item < nblk * FMAX; item += T2_ATTN_THREADS) {
             const int c = item % FMAX, t0 = (item / FMAX) << 3;
             if (c >= F) {
@@ -931,13 +938,13 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
             for (int i = 0; i < 8; ++i) accv[i] = 0.f;
             float win[12];
             {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_prev + t0);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_prev + t0 + 4);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_prev_c + t0);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_prev_c + t0 + 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { win[i] = w0[i]; win[4 + i] = w1[i]; }
             }
             for (int j0 = 0; j0 < KP; j0 += 4) {
-                const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_prev + t0 + j0 + 8);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_prev_c + t0 + j0 + 8);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) win[8 + i] = w2[i];
 #pragma unroll
@@ -953,7 +960,9 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
 #pragma unroll
             for (int i = 0; i < 8; ++i) s_f[(t0 + i) * FMAX + c] = accv[i] + bc;
         }
-    }
+    };
+    const int cn0 = min(T, T2_ATTN_CHUNK);
+    features(0, cn0);
 #pragma unroll
     for (int k = 0; k < WLN; ++k) *reinterpret_cast<f32x4*>(s_wl + 4 * (tid + k * T2_ATTN_THREADS)) = wlreg[k];
     T2_STAMP(3);
@@ -988,10 +997,13 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         for (int i = 0; i < UPL; ++i) wl[c][i] = w[i];
     }
     T2_STAMP(4);
-    // ---- phase 2: energies   (:131-133, :66-78); one wave per position, 8 positions per batch
+    // ---- phase 2: energies   (:131-133, :66-78); one wave per position, 8 positions per batch (64 positions per sweep of
+    // the workgroup; T2_ATTN_CHUNK is a multiple of it, so a batch never straddles two feature chunks)
     {
+        static_assert(T2_ATTN_CHUNK % (8 * (T2_ATTN_THREADS / 64)) == 0 && T2_ATTN_CHUNK >= 16 * (T2_ATTN_THREADS / 64), "chunk = whole position batches");
 #pragma unroll
         for (int i = 0; i < UPL; ++i) { const int u = UPL * lane + i; kq[i] = (u < U) ? s_q[16 * UP + u] : 0.f; }
+        int c0 = 0;                                            // first position of the feature chunk in s_f
         auto energies = [&](const vecu (&kv)[8], int tb) {
             float part[8];
 #pragma unroll
@@ -1000,7 +1012,7 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
                 float pf[UPL];
 #pragma unroll
                 for (int i = 0; i < UPL; ++i) pf[i] = 0.f;
-                const float* ft = s_f + tt * FMAX;
+                const float* ft = s_f + (tt - c0) * FMAX;
 #pragma unroll
                 for (int c4 = 0; c4 < FMAX; c4 += 4) {
                     const f32x4 fv = *reinterpret_cast<const f32x4*>(ft + c4);
@@ -1046,9 +1058,20 @@ __global__ __launch_bounds__(T2_ATTN_THREADS) void attention_step_kernel(AttnArg
         };
         energies(kvA, wave);
         if (wave + 8 * NW < T) energies(kvB, wave + 8 * NW);
-        for (int tb = wave + 16 * NW; tb < T; tb += 8 * NW) {      // only if T > 128
+        for (int tb = wave + 16 * NW; tb < cn0; tb += 8 * NW) {    // only if T > 128
             load_keys(kvA, tb);
             energies(kvA, tb);
+        }
+        for (c0 = T2_ATTN_CHUNK; c0 < T; c0 += T2_ATTN_CHUNK) {    // long inputs: the next chunks' features, then their energies
+            const int cn = min(T - c0, T2_ATTN_CHUNK);
+            load_keys(kvA, c0 + wave);
+            __syncthreads();                                       // every wave is past its reads of the previous chunk's features
+            features(c0, cn);
+            __syncthreads();
+            for (int tb = c0 + wave; tb < c0 + cn; tb += 8 * NW) {
+                if (tb != c0 + wave) load_keys(kvA, tb);
+                energies(kvA, tb);
+            }
         }
     }
     T2_STAMP(5);

@@ -337,11 +337,14 @@ def test_persistent_training_recurrences_after_parameter_refresh():
 
 
 @pytest.mark.parametrize("B,T,eligible", [(1, 9, True), (3, 2, True), (20, 77, True), (1, 590, True), (64, 256, True), (64, 260, False),
-                                          (16, 257, True)])
+                                          (16, 257, True), (1, 1000, True), (2, 2000, False), (40, 700, False), (17, 3001, False)])
 def test_persistent_forward_at_edge_shapes_against_oracle(B, T, eligible):
     """Forward parity where the attention split has corner cases: chunks with fewer than 16 or zero positions
     (T < 16 C), T not a multiple of 4, the longest eligible inputs (ceil(T / C) = 64 and the LDS plan's limit), and just past
     the eligibility edge, where the decode must take the launch-per-phase schedule (persist_launches does not advance).
+    Long inputs (round 3; the reference has no length limit, tacotron_v2.py:118-141): T_in of 700 ... 3001 on the launch-per-phase
+    schedule, whose attention kernel sweeps the location features in chunks of 256 positions (whole and ragged last chunks,
+    one and several row blocks), and T_in = 1000 on the persistent kernel.
     Free-running and teacher-forced, against the oracle; peaked attention."""
     from tacotron2_amd.engine import Engine
     from tacotron2_amd.weights import sharpen_attention

@@ -68,7 +68,8 @@ def _labels(rng, B, S, r):
             "binary_loss_mask": (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)}
 
 
-@pytest.mark.parametrize("d,B,T,S", [(PROFILE_TINY, 3, 7, 5), (MID, 4, 13, 6), (MID, 18, 9, 4), (MID, 3, 37, 5), (MID_U128, 2, 50, 4)])
+@pytest.mark.parametrize("d,B,T,S", [(PROFILE_TINY, 3, 7, 5), (MID, 4, 13, 6), (MID, 18, 9, 4), (MID, 3, 37, 5), (MID_U128, 2, 50, 4),
+                                     (MID, 2, 700, 3)])               # long input: chunked location features in the forward
 def test_decoder_backward_against_autograd(d, B, T, S):
     """BPTT through the training-mode decoder: every decoder/ and attention/ gradient and d loss / d memory against
     torch.autograd on the float64 restatement with the same sampled masks."""

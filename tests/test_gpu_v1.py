@@ -100,7 +100,8 @@ def test_cbhg_and_postnet(name, B, T):
     np.testing.assert_allclose(_np(eng.cbhg(0, x, None)), ref, atol=ATOL)
 
 
-@pytest.mark.parametrize("name,B,T,S", [("tiny", 3, 7, 6), ("tiny", 20, 9, 5), ("mid", 5, 17, 19), ("ref", 2, 30, 24), ("ref", 33, 12, 6)])
+@pytest.mark.parametrize("name,B,T,S", [("tiny", 3, 7, 6), ("tiny", 20, 9, 5), ("mid", 5, 17, 19), ("ref", 2, 30, 24), ("ref", 33, 12, 6),
+                                        ("ref", 2, 1300, 3)])          # long input: the attention kernel's chunked sweep (6 chunks, ragged last)
 @pytest.mark.parametrize("teacher_forcing", [True, False])
 def test_decoder_v1_teacher_and_validation(name, B, T, S, teacher_forcing):
     d, w, eng = _engine(name)
