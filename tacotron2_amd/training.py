@@ -83,7 +83,7 @@ def allreduce_loss_parts(parts: torch.Tensor, group=None) -> torch.Tensor:
     import torch.distributed as dist
     nc = parts[:2].clone()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(nc, op=dist.ReduceOp.SUM, group=group)
+        allreduce_sum(nc, group)
     return torch.where(nc[1] > 0, nc[0] / nc[1].clamp(min=1), torch.zeros_like(nc[0]))
 
 
@@ -150,21 +150,41 @@ def global_loss_counts(spec_loss_mask, binary_loss_mask, num_mels: int, group=No
     m1, m2 = torch.as_tensor(spec_loss_mask), torch.as_tensor(binary_loss_mask)
     cnt = torch.stack([(m1 != 0).sum().to(torch.float32) * float(num_mels), (m2 != 0).sum().to(torch.float32)])
     if _world(group) > 1:
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        allreduce_sum(cnt, group)
     return cnt
+
+
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+def _via_host(t: torch.Tensor, group) -> bool:
+    """Device tensors under the gloo backend (rehearsals of the N > 1 path on a box without RCCL peers, e.g. several ranks
+    sharing one GPU) are reduced through a host copy; "nccl" (= RCCL) reduces them in place."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
 def allreduce_sum_async(t: torch.Tensor, group=None):
     """Start a SUM all-reduce of ``t`` (a contiguous view) and return its work handle; ``wait()`` orders the current stream
     after it (backend "nccl" = RCCL: the collective runs on the communicator's stream, beside compute)."""
     import torch.distributed as dist
+    if _via_host(t, group):
+        allreduce_sum(t, group)
+        return _DoneWork()
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
 def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     import torch.distributed as dist
     if _world(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if _via_host(t, group):
+            c = t.detach().cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -177,7 +197,7 @@ def allreduce_gradients(flat_grads: torch.Tensor, group=None) -> float:
         return 1.0
     world = dist.get_world_size(group)
     if world > 1:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+        allreduce_sum(flat_grads, group)
     return 1.0 / world
 
 

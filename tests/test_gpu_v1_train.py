@@ -199,3 +199,71 @@ def test_postnet_trainer_argument_errors():
         PostNetTrainer(eng2, 2, 5, TR.flatten_spec(PostNetTrainer.postnet_weights(w2)))
     eng2.close()
     eng.close()
+
+
+def _dp_rank(rank, world, port, q):
+    """One rank of the data-parallel PostNet training step: its half of the rows, the product's train_step(group=WORLD)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tacotron2_amd.tacotron_v1 import EngineV1, TacotronV1PostNetModel
+        d, w, mel, target, mask = _dp_case()
+        rows = slice(3 * rank, 3 * rank + 3)
+        eng = EngineV1(d, w)
+        model = TacotronV1PostNetModel(d, eng, weights=w)
+        res = model.train_step({"mel": mel[rows]}, {"spec": target[rows], "spec_loss_mask": mask[rows]},
+                               {"initial_learning_rate": 0.002, "decay_learning_rate": False}, group=dist.group.WORLD)
+        torch.cuda.synchronize()
+        q.put((rank, float(res["loss"]), _np(model.flat_grads), _np(model.flat_params)))
+        dist.barrier()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp_case():
+    d = POST_NARROW
+    w = init_weights_v1(d, 17, perturb=True)
+    mel, target, mask = _case(d, 6, 12, 77)
+    return d, w, mel, target, mask
+
+
+def test_postnet_training_step_two_ranks_share_the_loss_normalisation():
+    """Data parallel through the product's own path: two processes (gloo; both on this one GPU -- no kernel of
+    this step spans workgroups, so they may share it) run TacotronV1PostNetModel.train_step(group=...) on three rows each.
+    The ranks sum their non-zero weight counts first, each differentiates its numerator / the GLOBAL count, gradients are
+    summed: the summed gradient equals the sum of the oracle's per-rank gradients with that count, the loss is sum of numerators
+    / global count, and both ranks end with identical parameters (batch statistics stay per replica, the moving statistics
+    are averaged)."""
+    import socket
+    import torch.multiprocessing as mp
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import PostNetTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=110) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d, w, mel, target, mask = _dp_case()
+    count = float((mask != 0).sum() * d.num_freq)
+    refs = [VT.postnet_train_forward_backward(d, w, mel[3 * r:3 * r + 3], target[3 * r:3 * r + 3], mask[3 * r:3 * r + 3], loss_count=count)
+            for r in range(2)]
+    spec = TR.flatten_spec(PostNetTrainer.postnet_weights(w))
+    g_sum = TR.flatten({k: refs[0]["grads"][k] + refs[1]["grads"][k] for k in refs[0]["grads"]}, spec)
+    loss = refs[0]["loss"] + refs[1]["loss"]                      # each is its numerator / the global count
+    np.testing.assert_array_equal(res[0][3], res[1][3])           # identical replicas after the step
+    for r in res:
+        assert abs(r[1] - loss) <= 2e-4 * max(1.0, abs(loss))
+        for name, shape, off, size in spec:
+            if name.endswith(("moving_mean", "moving_variance")):
+                continue
+            scale = float(np.abs(g_sum[off:off + size]).max())
+            assert float(np.abs(r[2][off:off + size] - g_sum[off:off + size]).max()) <= 5e-3 * scale + 1e-9, name
