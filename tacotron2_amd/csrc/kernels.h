@@ -1280,6 +1280,7 @@ struct ConvArgs {
     int red;
     int splits;                    // > 1: split-K over gridDim.z; raw partial sums go to part[z][Mtot][N] (no epilogue), summed in
     float* part;                   //      split order by a second kernel (deterministic)
+    const float* wt;               // forward fast path: the kernel transposed, [N][ktaps*Cin] (null: not available)
 };
 
 #define CG_BM 128
@@ -1587,6 +1588,142 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
                 a.y[(size_t)m * a.ldy + n] = v;
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 3 forward fast path (conv_gemm_kt_kernel): K-contiguous LDS tiles.  Both operands are read from memory as float4 along K
+// (the activations are K-contiguous anyway; the kernel comes transposed, ConvArgs::wt [N][ktaps*Cin]) and go to LDS as ONE
+// 128-bit store per thread and operand row: tile [rows][16 k], the 16-byte chunk c (k = 4c .. 4c + 3) of row r at chunk slot
+// c ^ ((r >> 1) & 3), which makes both the stores and the reads conflict-free.  A lane reads its 8 k of a k-tile as two
+// 128-bit LDS loads: lane half lh holds k = 8 lh .. 8 lh + 7, MFMA step s multiplies the k pair (s, 8 + s) -- 8 LDS reads per
+// 32 MFMAs instead of 32, no transposing scalar stores.  (The summation order inside a k-tile differs from conv_gemm_kernel's:
+// results agree to fp32 rounding, not bit for bit.)
+// Tile shapes: NS sub-tiles of 32 rows per wave.  WN = 2: waves 2 x 2, tile 64 NS x 128 (NS = 1, 2: the 64- and 128-row tiles
+// of conv_gemm_fast_kernel).  WN = 4: the four waves side by side, each 32 NS rows x 32 columns -- NS = 5 gives a 160 x 128
+// tile, for output shapes whose 128-row tiling leaves a ragged last round on the 256 CUs (PostNetV2 at B = 64: 1600 tiles =
+// 6.25 per CU -> some CUs run 7; 160 rows: 1280 tiles = 5 per CU; launch_conv picks by that quotient).  Measured at that
+// shape: 1.30 -> 1.19 ms (layout) -> 1.06 ms (160-row tiles, three workgroups per CU) per layer.
+// ------------------------------------------------------------------------------------------------
+template <int NS, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WN == 4 ? 3 : 2, WN == 4 ? 3 : 4)))
+void conv_gemm_kt_kernel(ConvArgs a) {
+    static_assert(WN == 2 || WN == 4, "waves across the 128 columns");
+    constexpr int WM = 4 / WN;                       // waves down the rows
+    constexpr int NJ = 4 / WN;                       // 32-column sub-tiles per wave (WN = 2: 2, WN = 4: 1)
+    constexpr int BM = 32 * NS * WM;
+    constexpr int NP = (BM + 63) / 64;               // loader passes over the rows of the A tile
+    __shared__ __attribute__((aligned(16))) float As[2][BM][CG_BK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CG_BN][CG_BK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * CG_BN;
+    const int Ktot = a.ktaps * a.Cin;
+    const int nk = Ktot / CG_BK;
+    f32x16 acc[NS][NJ];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int kq = tid & 3, r0 = tid >> 2;           // loader: 16-byte chunk kq of tile rows r0, r0 + 64, ...
+    int tt[NP];
+    const float* xrow[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int m = m0 + r0 + p * 64;
+        tt[p] = (m < a.Mtot && r0 + p * 64 < BM) ? m % a.T : -(1 << 28);
+        xrow[p] = a.x + (size_t)min(m, a.Mtot - 1) * a.ldx + kq * 4;
+    }
+    const float* wrow[2];
+    bool w_ok[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int n = n0 + r0 + p * 64;
+        w_ok[p] = n < a.N;
+        wrow[p] = a.wt + (size_t)min(n, a.N - 1) * Ktot + kq * 4;
+    }
+    float4 ra[NP], rb[2];
+    int tap = 0, ci = 0;                             // k-tile kt covers channels [ci, ci + 16) of tap `tap`
+    auto load_tiles = [&](int kt) {
+        const int dt = tap - a.pad_l;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int ts = tt[p] + dt;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ts >= 0 && ts < a.T) v = *reinterpret_cast<const float4*>(xrow[p] + (long long)dt * a.ldx + ci);
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w_ok[p]) v = *reinterpret_cast<const float4*>(wrow[p] + kt * CG_BK);
+            rb[p] = v;
+        }
+        ci += CG_BK;
+        if (ci >= a.Cin) { ci = 0; ++tap; }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = r0 + p * 64;
+            if (BM % 64 == 0 || r < BM) *reinterpret_cast<float4*>(&As[buf][r][(kq ^ ((r >> 1) & 3)) * 4]) = ra[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = r0 + p * 64;
+            *reinterpret_cast<float4*>(&Bs[buf][r][(kq ^ ((r >> 1) & 3)) * 4]) = rb[p];
+        }
+    };
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        f32x4 av[NS][2], bv[NJ][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = wn * 32 * NJ + j * 32 + l31;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) bv[j][h] = *reinterpret_cast<const f32x4*>(&Bs[buf][r][((lh * 2 + h) ^ ((r >> 1) & 3)) * 4]);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int r = wm * 32 * NS + i * 32 + l31;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) av[i][h] = *reinterpret_cast<const f32x4*>(&As[buf][r][((lh * 2 + h) ^ ((r >> 1) & 3)) * 4]);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s >> 2][s & 3], bv[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * 32 * NJ + j * 32 + l31;
+        if (n >= a.N) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        const float sh = a.shift ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 * NS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.Mtot) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = tanhf(v);
+                if (a.res) v += a.res[(size_t)m * a.ldr + n];
+                a.y[(size_t)m * a.ldy + n] = v;
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

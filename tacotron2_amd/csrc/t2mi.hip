@@ -79,6 +79,8 @@ struct ConvLayer {
     float* scale = nullptr; // [cout] or null
     float* shift = nullptr; // [cout] or null
     int k = 0, cin = 0, cout = 0;
+    float* wt = nullptr;    // [cout][k*cin]: the same kernel transposed (conv_gemm_kt_kernel's operand) or null; whoever rewrites
+                            // w rewrites wt (conv_refresh_wt)
 };
 
 struct t2_model {
@@ -132,7 +134,8 @@ struct t2_model {
     long long n_persist = 0;            // persistent decodes launched (stat "persist_launches")
     int opt_enc_persist = 1;            // EncoderV2's BiLSTM as one persistent launch (persist.h encoder_kernel) at the paper-size class
     unsigned long long n_enc_persist = 0;
-    int opt_conv_mi = 0;                // 1: 64-row conv GEMM tiles always (measurement)
+    int opt_conv_mi = 0;                // measurement: 1 / 2 / 5 force 64- / 128- / 160-row conv GEMM tiles
+    int opt_conv_kt = 1;                // forward convolutions on conv_gemm_kt_kernel (K-contiguous LDS tiles, transposed kernel); 0: round 2's kernel
     int opt_bwd_persist = 1;            // training backward: the reverse-time recurrence as ONE persistent launch (persist_bwd.h)
     unsigned long long n_bwd_persist = 0;
     int opt_bwd_splitk = 1;             // training backward: K = 4H data-gradient GEMMs split in two halves over the grid (train_step.h)
@@ -340,6 +343,13 @@ static int make_conv(t2_model* m, ConvLayer* L, const std::string& prefix, int k
     T2_TRY(get_w(m, prefix + "/kernel", &w, {k, cin, cout}));
     L->k = k; L->cin = cin; L->cout = cout;
     T2_TRY(upload(m, &L->w, w->data));
+    if (cin % CG_BK == 0) {
+        const size_t K = (size_t)k * cin;
+        std::vector<float> t(K * cout);
+        for (size_t kk = 0; kk < K; ++kk)
+            for (int n = 0; n < cout; ++n) t[(size_t)n * K + kk] = w->data[kk * cout + n];
+        T2_TRY(upload(m, &L->wt, t));
+    }
     if (bn) {
         const HostWeight *g, *b, *mu, *var;
         const std::string p = prefix + "/batch_normalization/";
@@ -483,6 +493,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
     else if (!strcmp(name, "bwd_splitk")) m->opt_bwd_splitk = value;
     else if (!strcmp(name, "bwd_persist")) m->opt_bwd_persist = value;
     else if (!strcmp(name, "conv_mi")) m->opt_conv_mi = value;
+    else if (!strcmp(name, "conv_kt")) m->opt_conv_kt = value;
     else if (!strcmp(name, "enc_persist")) m->opt_enc_persist = value;
     else if (!strcmp(name, "time_lstm")) { m->opt_time_lstm = value; g_timer.used = 0; }
     else return fail(T2_EINVAL, "unknown option %s", name);
@@ -693,7 +704,22 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
     a.vec_a = (L.cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0);
     a.vec_b = (L.cout % 4 == 0) && (((uintptr_t)L.w) % 16 == 0);
     dim3 grid(ceil_div(L.cout, CG_BN), ceil_div(Mtot, CG_BM));
-    if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic) {
+    if (a.vec_a && L.wt != nullptr && L.cin % CG_BK == 0 && !m->opt_conv_generic && m->opt_conv_kt) {
+        // K-contiguous LDS tiles on the transposed kernel.  Tile height: 64 rows while 128-row tiles would leave fewer than ~3
+        // workgroups per CU; otherwise 128 or 160 rows, whichever leaves the fuller last round on the CUs
+        a.wt = L.wt;
+        const long long t128 = (long long)grid.x * grid.y, t160 = (long long)grid.x * ceil_div(Mtot, 160);
+        auto fill = [&](long long tiles) { const double q = (double)tiles / m->n_cu; return q / std::ceil(q); };
+        if (t128 < 3LL * m->n_cu || m->opt_conv_mi == 1) {
+            grid.y = ceil_div(Mtot, 64);
+            hipLaunchKernelGGL((conv_gemm_kt_kernel<1, 2>), grid, dim3(256), 0, m->ctx->stream, a);
+        } else if (m->opt_conv_mi != 2 && (m->opt_conv_mi == 5 || fill(t160) > fill(t128) + 0.02)) {
+            grid.y = ceil_div(Mtot, 160);
+            hipLaunchKernelGGL((conv_gemm_kt_kernel<5, 4>), grid, dim3(256), 0, m->ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL((conv_gemm_kt_kernel<2, 2>), grid, dim3(256), 0, m->ctx->stream, a);
+        }
+    } else if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic) {
         // fewer than ~3 workgroups of 128 rows per CU: 64-row tiles (twice the workgroups) keep more waves per SIMD
         if ((long long)grid.x * grid.y < 3LL * m->n_cu || m->opt_conv_mi == 1) {
             grid.y = ceil_div(Mtot, 64);

@@ -2204,6 +2204,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(float* __restrict__ dst,
     }
 }
 
+// the transposed copy of a convolution kernel (ConvLayer::wt, [cout][k*cin]) after w was rewritten on the device
+static void conv_refresh_wt(hipStream_t st, const ConvLayer& L) {
+    if (L.wt == nullptr) return;
+    const int K = L.k * L.cin;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(4096, ((long long)K * L.cout + 255) / 256))), dim3(256), 0, st,
+                       L.wt, K, L.w, L.cout, L.cout, K);
+}
+
 // inference batch norm folded to scale / shift (make_conv)
 __global__ __launch_bounds__(256) void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                                                       float* scale, float* shift, int C) {
@@ -2298,7 +2306,7 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
         const std::string pn = "encoder/conv1d_" + std::to_string(i);
         const float *g, *be, *mu, *var;
         T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
-        if (model_part) T2_TRY(copy(m->enc_convs[i].w, w, (size_t)d.enc_kernel * cin * E));
+        if (model_part) { T2_TRY(copy(m->enc_convs[i].w, w, (size_t)d.enc_kernel * cin * E)); conv_refresh_wt(st, m->enc_convs[i]); }
         if (trainer_part) hipLaunchKernelGGL(conv_flip_kernel, grid1((long long)d.enc_kernel * cin * E), dim3(256), 0, st, et->convT[i].w, w, d.enc_kernel, cin, E);
         T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/gamma", &g));
         T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/beta", &be));
@@ -2409,6 +2417,7 @@ static int load_params_impl(t2_trainer* tr, const float* flat, bool model_part, 
             ConvLayer& Lc = m->post_convs[i - 1];
             T2_TRY(flat_src(tr, flat, pn + "/kernel", &w));
             T2_TRY(copy(Lc.w, w, (size_t)d.postnet_kernel * cin * d.postnet_channels));
+            conv_refresh_wt(st, Lc);
             T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/gamma", &g));
             T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/beta", &be));
             T2_TRY(flat_src(tr, flat, pn + "/batch_normalization/moving_mean", &mu));

@@ -546,6 +546,7 @@ extern "C" int t2v1_postnet_trainer_export(t2v1_ptrainer* tr, const float* flat_
                     *mu = W(q + "/batch_normalization/moving_mean"), *va = W(q + "/batch_normalization/moving_variance");
         if (err != T2_OK) return err;
         HIP_TRY(hipMemcpyAsync(L.w, k, (size_t)L.k * L.cin * L.cout * 4, hipMemcpyDeviceToDevice, st));
+        conv_refresh_wt(st, L);
         hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(L.cout, 256)), dim3(256), 0, st, g, be, mu, va, m->base.d.bn_eps, L.scale, L.shift, L.cout);
         return T2_OK;
     };

@@ -115,7 +115,7 @@ def test_edge_single_position_and_limits(paper):
     mel_o, _, _ = O.decoder_v2(d.replace(min_iters=100), w, mem_o, memory_sequence_length=np.array([1]), max_iters=3)
     np.testing.assert_allclose(_np(mel), mel_o, atol=ATOL)
     with pytest.raises(T2Error) as ei:                                   # longer than the attention kernel's LDS plan
-        eng.decode_free(np.zeros((1, 700, d.enc_units), np.float32), np.array([700]), max_iters=2)
+        eng.decode_free(np.zeros((1, 7000, d.enc_units), np.float32), np.array([7000]), max_iters=2)    # ~6 400 since the chunked sweep
     assert ei.value.code == -1 and "too long" in ei.value.msg
     with pytest.raises(T2Error):                                         # length 0 is not a valid memory_sequence_length
         eng.decode_free(_np(mem), np.array([0]), max_iters=2)
