@@ -372,6 +372,21 @@ int t2v1_postnet_trainer_update_moving_stats(t2v1_ptrainer* tr, float* flat_para
  * buffer, on the device. */
 int t2v1_postnet_trainer_export(t2v1_ptrainer* tr, const float* flat_params);
 
+/* EncoderV1(is_training=True) with the embedding in front (tacotron_v1.py:18-49, modules.py:80-91, models.py:40-47): the encoder
+ * half of SingleSpeakerTacotronV1Model's training step (the V1 decoder has no backward pass: its TRAIN mode is not built).
+ * Same trainer type, flat-buffer convention, bind / update_moving_stats / export / destroy calls as the PostNet trainer above
+ * (variables: embedding, v1/encoder/...).  ids host int64 [B,T_in] (T2_ERANGE outside the table); lens host int64 [B] or NULL
+ * (models.py:46-47 passes none); PreNet dropout masks from the counter-based generator (seed); memory_out dev
+ * [B,T_in,cbhg_out_units].  _backward: dmemory dev = d loss / d memory -> gradients of every encoder variable and the table. */
+int t2v1_encoder_trainer_create(t2v1_model* m, int B, int T_in, t2v1_ptrainer** out);
+int t2v1_encoder_train_forward(t2v1_ptrainer* tr, const float* flat_params, const int64_t* ids, const int64_t* lens, float drop_rate,
+                               uint32_t seed, float* memory_out);
+int t2v1_encoder_train_forward_embedded(t2v1_ptrainer* tr, const float* flat_params, const float* emb, const int64_t* lens,
+                                        float drop_rate, uint32_t seed, float* memory_out);   /* EncoderV1.call on an embedded input */
+/* demb_out: dev [B,T_in,embedding_dim] or NULL, the gradient of the embedded input; the table's gradient is written after a
+ * forward from ids only */
+int t2v1_encoder_train_backward(t2v1_ptrainer* tr, const float* dmemory, float* flat_grads, float* demb_out);
+
 /* ---- spectrogram -> waveform ------------------------------------------------------------
  * Audio.inv_spectrogram_tf (util/audio.py:55-59): inv_amp_tf (:51-53: clip to [0,1], de-normalise with min_level_db,
  * + ref_level_db, dB -> amplitude), ** power, then _griffin_lim_tf (:66-82): y = inverse_stft(S); `iters` times

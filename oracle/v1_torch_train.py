@@ -72,25 +72,31 @@ def _relu(stats, z):
     return torch.relu(z) if shift == 0.0 else _ReluShift.apply(z, shift)
 
 
-def gru_seq(x, W, p, reverse):
-    """dynamic_rnn over tf.nn.rnn_cell.GRUCell, all T steps live (App. A2, A8)."""
+def gru_seq(x, W, p, reverse, lens=None):
+    """dynamic_rnn over tf.nn.rnn_cell.GRUCell (App. A2, A8).  lens: per-row lengths -- a row's steps past its length copy the
+    state through and emit zeros; the backward direction of bidirectional_dynamic_rnn walks a row from its last live position
+    (reverse_sequence with the lengths) and its outputs land at the positions they belong to."""
     B, T, _ = x.shape
     wg, bg, wc, bc = W[f"{p}/gates/kernel"], W[f"{p}/gates/bias"], W[f"{p}/candidate/kernel"], W[f"{p}/candidate/bias"]
     H = wc.shape[1]
+    lens_t = torch.full((B,), T, dtype=torch.long) if lens is None else torch.as_tensor(np.asarray(lens), dtype=torch.long)
+    rows = torch.arange(B)
     h = torch.zeros(B, H, dtype=DT)
-    out = [None] * T
-    order = range(T - 1, -1, -1) if reverse else range(T)
-    for t in order:
-        xt = x[:, t]
+    out = torch.zeros(B, T, H, dtype=DT)
+    for s in range(T):
+        live = s < lens_t                                                  # step s of every row
+        pos = (lens_t - 1 - s).clamp(min=0) if reverse else torch.full((B,), s, dtype=torch.long)
+        xt = x[rows, pos]
         g = torch.sigmoid(torch.cat([xt, h], -1) @ wg + bg)
         r, u = g[:, :H], g[:, H:]
         c = torch.tanh(torch.cat([xt, r * h], -1) @ wc + bc)
-        h = u * h + (1.0 - u) * c
-        out[t] = h
-    return torch.stack(out, dim=1)
+        hn = u * h + (1.0 - u) * c
+        h = torch.where(live[:, None], hn, h)
+        out = out.index_put((rows[live], pos[live]), hn[live])
+    return out
 
 
-def cbhg_train(W, p, x, max_filter_width, num_highway, eps, stats, use_moving=False):
+def cbhg_train(W, p, x, max_filter_width, num_highway, eps, stats, use_moving=False, lens=None):
     """CBHG.call (modules.py:205-229), is_training=True, input_lengths=None."""
     bank = torch.cat([conv1d_bn(x, W, f"{p}/conv1d_K{k}", torch.relu, eps, stats, use_moving) for k in range(1, max_filter_width + 1)], dim=-1)
     pooled = torch.cat([torch.maximum(bank[:, :-1], bank[:, 1:]), bank[:, -1:]], dim=1)        # MaxPooling1D(2, 1, SAME), App. A3
@@ -106,7 +112,7 @@ def cbhg_train(W, p, x, max_filter_width, num_highway, eps, stats, use_moving=Fa
         t = torch.sigmoid(hw @ W[f"{hp}/T/kernel"] + W[f"{hp}/T/bias"])
         hw = h * t + hw * (1.0 - t)
     rp = f"{p}/bidirectional_rnn"
-    return torch.cat([gru_seq(hw, W, f"{rp}/fw/gru_cell", False), gru_seq(hw, W, f"{rp}/bw/gru_cell", True)], dim=-1)
+    return torch.cat([gru_seq(hw, W, f"{rp}/fw/gru_cell", False, lens), gru_seq(hw, W, f"{rp}/bw/gru_cell", True, lens)], dim=-1)
 
 
 def postnet_train_forward_backward(d, w, mel, spec, spec_loss_mask, loss_count=None, use_moving=False, relu_shift=0.0):
@@ -130,3 +136,30 @@ def postnet_train_forward_backward(d, w, mel, spec, spec_loss_mask, loss_count=N
     stats.pop("relu_shift", None)
     return {"loss": float(loss.detach()), "spec": f32(out), "grads": grads, "bn_stats": {k: (f32(a), f32(b)) for k, (a, b) in stats.items()},
             "relu_margin": margin}
+
+
+def encoder_train_forward_backward(d, w, ids, lens, dmemory, drop_rate=0.5, seed=0, relu_shift=0.0):
+    """Embedding + EncoderV1(is_training=True) (models.py:40-47, tacotron_v1.py:18-49): two PreNets (Dense + relu + dropout,
+    modules.py:80-91; masks from the shared counter-based generator, stream 50 + layer, step 0, row = position in the batch) and
+    the CBHG with batch-statistics batch norm.  Scalar for the gradients: sum(memory * dmemory), i.e. dmemory is d loss / d memory.
+    Returns dict(memory, grads{name}, bn_stats)."""
+    from oracle import t2_oracle as O
+    names = [k for k in w if k == "embedding" or k.startswith("v1/encoder/")]
+    W = {k: _t(w[k]).clone().requires_grad_(not k.endswith(("moving_mean", "moving_variance"))) for k in names}
+    ids = np.asarray(ids)
+    B, T = ids.shape
+    x = W["embedding"][torch.as_tensor(ids.reshape(-1), dtype=torch.long)]
+    keep = 1.0 - drop_rate
+    for i in range(2):
+        q = f"v1/encoder/prenet_{i}/dense"
+        x = torch.relu(x @ W[q + "/kernel"] + W[q + "/bias"])
+        if drop_rate > 0:
+            u = O.rng_u01(seed, 50 + i, 0, B * T, x.shape[1])
+            x = x / keep * _t((u >= np.float32(drop_rate)).astype(np.float64))
+    stats = {"relu_shift": float(relu_shift)} if relu_shift else {}
+    y = cbhg_train(W, "v1/encoder/cbhg", x.reshape(B, T, -1), d.max_filter_width, d.num_highway, d.bn_eps, stats, False, lens)
+    (y * _t(dmemory)).sum().backward()
+    stats.pop("relu_margin", None); stats.pop("relu_shift", None)
+    f32 = lambda t: t.detach().numpy().astype(np.float32)
+    grads = {k: (f32(v.grad) if v.grad is not None else np.zeros(tuple(v.shape), np.float32)) for k, v in W.items()}
+    return {"memory": f32(y), "grads": grads, "bn_stats": {k: (f32(a), f32(b)) for k, (a, b) in stats.items()}}

@@ -81,6 +81,8 @@ struct ConvLayer {
     int k = 0, cin = 0, cout = 0;
     float* wt = nullptr;    // [cout][k*cin]: the same kernel transposed (conv_gemm_kt_kernel's operand) or null; whoever rewrites
                             // w rewrites wt (conv_refresh_wt)
+    int pad_l = -1;         // zero positions in front; -1: TF's SAME rule (k - 1) / 2.  The data gradient of an even-width SAME
+                            // convolution is the flipped kernel with k - 1 - (k - 1) / 2 in front
 };
 
 struct t2_model {
@@ -700,7 +702,7 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
                        int act, const float* res, int ldr) {
     ConvArgs a{};
     a.x = x; a.ldx = ldx; a.w = L.w; a.scale = L.scale; a.shift = L.shift; a.res = res; a.ldr = ldr; a.y = y; a.ldy = ldy;
-    a.Mtot = Mtot; a.T = T; a.Cin = L.cin; a.N = L.cout; a.ktaps = L.k; a.pad_l = (L.k - 1) / 2; a.act = act;
+    a.Mtot = Mtot; a.T = T; a.Cin = L.cin; a.N = L.cout; a.ktaps = L.k; a.pad_l = L.pad_l >= 0 ? L.pad_l : (L.k - 1) / 2; a.act = act;
     a.vec_a = (L.cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0);
     a.vec_b = (L.cout % 4 == 0) && (((uintptr_t)L.w) % 16 == 0);
     dim3 grid(ceil_div(L.cout, CG_BN), ceil_div(Mtot, CG_BM));

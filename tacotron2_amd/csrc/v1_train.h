@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256) void gru_prev_kernel(const float* __restrict__
 
 struct t2v1_ptrainer {
     t2v1_model* m = nullptr;
+    int which = 1;                       // 1: the PostNet (its CBHG, Dense(num_freq), L1 loss); 0: EncoderV1 (embedding, PreNets with dropout, its CBHG)
+    const CbhgW* c = nullptr;            // dimensions of that CBHG
+    std::string pfx;                     // its variable prefix
     int B = 0, T = 0;
     t2_trainer ws;                       // workspace carrier of the shared helpers (split-K partials, column sums, BN partial sums, offsets)
     char* slab = nullptr;
@@ -126,6 +129,13 @@ struct t2v1_ptrainer {
     float *wbank, *proj1T, *proj2T, *wlT, *wgxT[2], *wcxT[2], *whT[8], *wtT[8], *wadjT;
     // backward temporaries
     float *dout, *dzg[2], *dzc[2], *hprev, *rh, *da[2], *dzh, *dzt, *d80a, *d80b, *dp1a, *dp1b, *dkc_a, *dkc_b, *dwbank, *loss3;
+    // EncoderV1 only: token ids, embedded input, PreNet outputs (after relu and dropout), their gradients, transposed PreNet kernels,
+    // the flipped unified bank kernel and the gradient of the CBHG's input
+    int* ids = nullptr;
+    float *emb = nullptr, *pre[2] = {nullptr, nullptr}, *dpre[2] = {nullptr, nullptr}, *wpreT[2] = {nullptr, nullptr}, *wbankF = nullptr, *dx0 = nullptr;
+    float drop_rate = 0.f;
+    uint32_t seed = 0;
+    bool have_ids = false;               // the last forward looked the input up in the table (its gradient goes to the table)
 };
 
 static const float* pt_w(t2v1_ptrainer* tr, const std::string& name, int* err) {
@@ -147,19 +157,20 @@ extern "C" int t2v1_postnet_trainer_destroy(t2v1_ptrainer* tr) {
     return T2_OK;
 }
 
-extern "C" int t2v1_postnet_trainer_create(t2v1_model* m, int B, int T, t2v1_ptrainer** out) {
+static int cbhg_trainer_create(t2v1_model* m, int which, int B, int T, t2v1_ptrainer** out) {
     T2_TRY(v1_ready(m));
     if (!out) return fail(T2_EINVAL, "null argument");
     T2_TRY(check_batch(B, T));
-    const CbhgW& c = m->post_cbhg;
+    const CbhgW& c = which == 1 ? m->post_cbhg : m->enc_cbhg;
     const int nhw = (int)c.highway.size();
-    if (c.half != 128) return fail(T2_EINVAL, "the PostNet training step is built for post_net_cbhg_out_units = 256 (whole-sequence GRU kernels of 128 units)");
+    if (c.half != 128) return fail(T2_EINVAL, "the CBHG training step is built for cbhg_out_units = 256 (whole-sequence GRU kernels of 128 units)");
     if (c.K > T2V1_MAX_BANK || nhw > 8) return fail(T2_EINVAL, "at most %d bank kernels and 8 highway layers", T2V1_MAX_BANK);
     HIP_TRY(hipSetDevice(m->base.ctx->device));
     t2v1_ptrainer* tr = new t2v1_ptrainer();
-    tr->m = m; tr->B = B; tr->T = T;
+    tr->m = m; tr->B = B; tr->T = T; tr->which = which; tr->c = &c;
+    tr->pfx = which == 1 ? "v1/postnet/cbhg" : "v1/encoder/cbhg";
     tr->ws.m = &m->base;
-    const size_t M = (size_t)B * T, KC = (size_t)c.K * c.C, H = c.half, F = m->d.num_freq, cin = c.cin, P1 = c.P1, P2 = c.P2;
+    const size_t M = (size_t)B * T, KC = (size_t)c.K * c.C, H = c.half, F = which == 1 ? m->d.num_freq : 4, cin = c.cin, P1 = c.P1, P2 = c.P2;
     Carver cv;
     std::vector<std::pair<float**, size_t>> plan;
     auto want = [&](float** p, size_t floats) { plan.push_back({p, cv.take(floats * 4)}); };
@@ -183,16 +194,26 @@ extern "C" int t2v1_postnet_trainer_create(t2v1_model* m, int B, int T, t2v1_ptr
     want(&tr->hprev, M * H); want(&tr->rh, M * H); want(&tr->da[0], M * H); want(&tr->da[1], M * H); want(&tr->dzh, M * H); want(&tr->dzt, M * H);
     want(&tr->d80a, M * P2); want(&tr->d80b, M * P2); want(&tr->dp1a, M * P1); want(&tr->dp1b, M * P1); want(&tr->dkc_a, M * KC); want(&tr->dkc_b, M * KC);
     want(&tr->loss3, 8);
+    size_t o_ids = 0;
+    if (which == 0) {
+        const size_t E0 = m->d.embedding_dim, U0 = m->d.enc_prenet_units[0], U1 = m->d.enc_prenet_units[1];
+        want(&tr->emb, M * E0); want(&tr->pre[0], M * U0); want(&tr->pre[1], M * U1); want(&tr->dpre[0], M * std::max(U0, E0)); want(&tr->dpre[1], M * U1);
+        want(&tr->wpreT[0], E0 * U0); want(&tr->wpreT[1], U0 * U1); want(&tr->wbankF, (size_t)c.K * cin * KC); want(&tr->dx0, M * cin);
+        o_ids = cv.take(M * 4);
+    }
     const size_t o_lens = cv.take((size_t)B * 4);
     hipError_t e = hipMalloc((void**)&tr->slab, cv.off);
     if (e != hipSuccess) { delete tr; return fail(T2_ENOMEM, "hipMalloc(PostNet trainer, %zu bytes) failed: %s", cv.off, hipGetErrorString(e)); }
     for (auto& pr : plan) *pr.first = (float*)(tr->slab + pr.second);
     tr->lens = (int*)(tr->slab + o_lens);
+    if (which == 0) tr->ids = (int*)(tr->slab + o_ids);
     int rc = v1_lens_to_dev(m, nullptr, B, T, 0, tr->lens);
     if (rc != T2_OK) { t2v1_postnet_trainer_destroy(tr); return rc; }
     *out = tr;
     return T2_OK;
 }
+extern "C" int t2v1_postnet_trainer_create(t2v1_model* m, int B, int T, t2v1_ptrainer** out) { return cbhg_trainer_create(m, 1, B, T, out); }
+extern "C" int t2v1_encoder_trainer_create(t2v1_model* m, int B, int T, t2v1_ptrainer** out) { return cbhg_trainer_create(m, 0, B, T, out); }
 
 // where variable `name` lives in the flat parameter / gradient buffers (floats from the start)
 extern "C" int t2v1_postnet_trainer_bind(t2v1_ptrainer* tr, const char* name, int64_t offset) {
@@ -212,24 +233,19 @@ static int pt_bn_forward(t2v1_ptrainer* tr, const float* raw, int l, int C, cons
     return T2_OK;
 }
 
-// PostNet(is_training=True)(mel) (tacotron_v1.py:180-183).  mel dev [B][T][num_mels]; flat_params dev: the parameter buffer
-// (offsets bound with t2v1_postnet_trainer_bind); spec_out dev [B][T][num_freq].
-extern "C" int t2v1_postnet_train_forward(t2v1_ptrainer* tr, const float* flat_params, const float* mel, float* spec_out) {
-    if (!tr || !flat_params || !mel || !spec_out) return fail(T2_EINVAL, "null argument");
+// CBHG.call(is_training=True) (modules.py:205-229) on x dev [B][T][cin] with the lengths in tr->lens: leaves the output in
+// tr->out [B][T][2H] and the tape of the backward pass in the trainer
+static int cbhg_train_forward_impl(t2v1_ptrainer* tr, const float* x) {
     t2v1_model* m = tr->m;
     t2_model* b = &m->base;
-    HIP_TRY(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
-    const CbhgW& c = m->post_cbhg;
-    const int B = tr->B, T = tr->T, M = B * T, K = c.K, C = c.C, KC = K * C, H = c.half, F = m->d.num_freq, cin = c.cin, P1 = c.P1, P2 = c.P2;
+    const CbhgW& c = *tr->c;
+    const int B = tr->B, T = tr->T, M = B * T, K = c.K, C = c.C, KC = K * C, H = c.half, cin = c.cin, P1 = c.P1, P2 = c.P2;
     const int nhw = (int)c.highway.size();
-    tr->params = flat_params;
-    tr->have_forward = false;
-    tr->have_stats = false;
     int err = T2_OK;
-    const std::string p = "v1/postnet/cbhg";
+    const std::string p = tr->pfx;
     auto W = [&](const std::string& n) { return pt_w(tr, n, &err); };
-    HIP_TRY(hipMemcpyAsync(tr->x0, mel, (size_t)M * cin * 4, hipMemcpyDeviceToDevice, st));
+    if (x != tr->x0) HIP_TRY(hipMemcpyAsync(tr->x0, x, (size_t)M * cin * 4, hipMemcpyDeviceToDevice, st));
     // conv bank as one convolution of width K
     BankPtrs bk{}, bg{}, bb{};
     for (int k = 1; k <= K; ++k) {
@@ -294,8 +310,28 @@ extern "C" int t2v1_postnet_train_forward(t2v1_ptrainer* tr, const float* flat_p
     ga.lens = tr->lens; ga.out = tr->out; ga.B = B; ga.T = T;
     HIP_TRY(hipMemsetAsync(tr->out, 0, (size_t)M * 2 * H * 4, st));
     hipLaunchKernelGGL(gru_seq_kernel<128>, dim3(ceil_div(B, 16), 2), dim3(512), 0, st, ga);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+// PostNet(is_training=True)(mel) (tacotron_v1.py:180-183).  mel dev [B][T][num_mels]; flat_params dev: the parameter buffer
+// (offsets bound with t2v1_postnet_trainer_bind); spec_out dev [B][T][num_freq].
+extern "C" int t2v1_postnet_train_forward(t2v1_ptrainer* tr, const float* flat_params, const float* mel, float* spec_out) {
+    if (!tr || !flat_params || !mel || !spec_out) return fail(T2_EINVAL, "null argument");
+    if (tr->which != 1) return fail(T2_EINVAL, "not a PostNet trainer");
+    t2v1_model* m = tr->m;
+    t2_model* b = &m->base;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    const int M = tr->B * tr->T, H = tr->c->half, F = m->d.num_freq;
+    tr->params = flat_params;
+    tr->have_forward = false;
+    tr->have_stats = false;
+    int err = T2_OK;
+    auto W = [&](const std::string& n) { return pt_w(tr, n, &err); };
+    T2_TRY(cbhg_train_forward_impl(tr, mel));
     // Dense(num_freq) (tacotron_v1.py:176,182)
-    L = ConvLayer{}; L.w = const_cast<float*>(W("v1/postnet/linear/kernel")); L.shift = const_cast<float*>(W("v1/postnet/linear/bias")); L.k = 1; L.cin = 2 * H; L.cout = F;
+    ConvLayer L{}; L.w = const_cast<float*>(W("v1/postnet/linear/kernel")); L.shift = const_cast<float*>(W("v1/postnet/linear/bias")); L.k = 1; L.cin = 2 * H; L.cout = F;
     if (err != T2_OK) return err;
     T2_TRY(launch_conv(b, L, tr->out, 2 * H, tr->spec, F, M, M, 0, nullptr, 0));
     HIP_TRY(hipMemcpyAsync(spec_out, tr->spec, (size_t)M * F * 4, hipMemcpyDeviceToDevice, st));
@@ -342,19 +378,18 @@ static int pt_dgrad_dense(t2v1_ptrainer* tr, const float* x, int K, float* wT, i
 // Backward of t2v1_postnet_train_forward + the L1 loss of models.py:208-211.  spec_target dev [B][T][num_freq], mask dev [B][T]
 // (labels.spec_loss_mask), glob_count dev [1] or null (the non-zero weight count of a larger data-parallel batch).  Writes the
 // gradient of every trainable PostNet variable into flat_grads at the bound offsets and {sum, count, loss} into loss_out (dev [3]).
+static int cbhg_train_backward_impl(t2v1_ptrainer* tr, float* flat_grads, bool want_dx);
 extern "C" int t2v1_postnet_train_backward(t2v1_ptrainer* tr, const float* spec_target, const float* mask, const float* glob_count,
                                            float* flat_grads, float* loss_out) {
     if (!tr || !spec_target || !mask || !flat_grads || !loss_out) return fail(T2_EINVAL, "null argument");
+    if (tr->which != 1) return fail(T2_EINVAL, "not a PostNet trainer");
     if (!tr->have_forward) return fail(T2_ESTATE, "t2v1_postnet_train_forward has not run");
     t2v1_model* m = tr->m;
     t2_model* b = &m->base;
     HIP_TRY(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
-    const CbhgW& c = m->post_cbhg;
-    const int B = tr->B, T = tr->T, M = B * T, K = c.K, C = c.C, KC = K * C, H = c.half, F = m->d.num_freq, cin = c.cin, P1 = c.P1, P2 = c.P2;
-    const int nhw = (int)c.highway.size();
+    const int B = tr->B, T = tr->T, M = B * T, H = tr->c->half, F = m->d.num_freq;
     int err = T2_OK;
-    const std::string p = "v1/postnet/cbhg";
     auto W = [&](const std::string& n) { return pt_w(tr, n, &err); };
     auto G = [&](const std::string& n) -> float* {
         auto it = tr->ws.offsets.find(n);
@@ -376,6 +411,28 @@ extern "C" int t2v1_postnet_train_backward(t2v1_ptrainer* tr, const float* spec_
         T2_TRY(pt_transpose(tr, wl, tr->wlT, 2 * H, F));
         T2_TRY(pt_dgrad_dense(tr, dspec, F, tr->wlT, 2 * H, tr->dout, nullptr));
     }
+    T2_TRY(cbhg_train_backward_impl(tr, flat_grads, false));
+    tr->have_forward = false;                                  // the tape is consumed (d spec overwrote the forward output)
+    return T2_OK;
+}
+
+// Backward of cbhg_train_forward_impl from tr->dout (the gradient of the CBHG's output): every gradient of the CBHG's variables
+// into flat_grads; want_dx: the gradient of its input into tr->dx0 (residual branch + the bank's data gradient)
+static int cbhg_train_backward_impl(t2v1_ptrainer* tr, float* flat_grads, bool want_dx) {
+    t2v1_model* m = tr->m;
+    t2_model* b = &m->base;
+    hipStream_t st = b->ctx->stream;
+    const CbhgW& c = *tr->c;
+    const int B = tr->B, T = tr->T, M = B * T, K = c.K, C = c.C, KC = K * C, H = c.half, cin = c.cin, P1 = c.P1, P2 = c.P2;
+    const int nhw = (int)c.highway.size();
+    int err = T2_OK;
+    const std::string p = tr->pfx;
+    auto W = [&](const std::string& n) { return pt_w(tr, n, &err); };
+    auto G = [&](const std::string& n) -> float* {
+        auto it = tr->ws.offsets.find(n);
+        if (it == tr->ws.offsets.end()) { err = fail(T2_ESTATE, "no offset bound for '%s'", n.c_str()); return nullptr; }
+        return flat_grads + it->second;
+    };
     // BiGRU: reverse-time recurrences, then tape-wide weight gradients
     const char* dirs[2] = {"fw", "bw"};
     GruSeqBwdArgs ga{};
@@ -435,7 +492,7 @@ extern "C" int t2v1_postnet_train_backward(t2v1_ptrainer* tr, const float* spec_
         T2_TRY(pt_dgrad_dense(tr, tr->dzt, H, tr->wtT[i], H, dfree, other));
         dcur = dfree; dfree = other;
     }
-    // adjustment layer -> d (p2 + mel); the mel spectrogram is data, so the residual branch ends here
+    // adjustment layer -> d (p2 + x); the residual branch continues into d x at the end (want_dx)
     const float* d80 = nullptr;
     if (c.has_adj) {
         const float* wa = W(p + "/adjustment/kernel");
@@ -494,8 +551,15 @@ extern "C" int t2v1_postnet_train_backward(t2v1_ptrainer* tr, const float* spec_
         hipLaunchKernelGGL(bank_vec_scatter_kernel, dim3(ceil_div(KC, 256)), dim3(256), 0, st, tr->dgam[0], dg, K, C);
         hipLaunchKernelGGL(bank_vec_scatter_kernel, dim3(ceil_div(KC, 256)), dim3(256), 0, st, tr->dbet[0], db, K, C);
     }
+    if (want_dx) {
+        // d x = d (p2 + x) + the bank's data gradient: the convolution of d (bank output) with the flipped unified kernel; for an
+        // even width K the SAME padding is asymmetric (pad_l = (K - 1) / 2 in front), so the transposed convolution pads K - 1 - pad_l
+        hipLaunchKernelGGL(conv_flip_kernel, pt_grid((long long)K * cin * KC), dim3(256), 0, st, tr->wbankF, tr->wbank, K, cin, KC);
+        ConvLayer L{};
+        L.w = tr->wbankF; L.k = K; L.cin = KC; L.cout = cin; L.pad_l = K - 1 - (K - 1) / 2;
+        T2_TRY(launch_conv(b, L, tr->dkc_a, KC, tr->dx0, cin, M, T, 0, d80, P2));
+    }
     HIP_TRY(hipGetLastError());
-    tr->have_forward = false;                                  // the tape is consumed (d spec overwrote the forward output)
     return T2_OK;
 }
 
@@ -505,7 +569,7 @@ extern "C" int t2v1_postnet_trainer_update_moving_stats(t2v1_ptrainer* tr, float
     if (!tr || !flat_params) return fail(T2_EINVAL, "null argument");
     if (!tr->have_stats) return fail(T2_ESTATE, "t2v1_postnet_train_forward has not run");
     hipStream_t st = tr->m->base.ctx->stream;
-    const CbhgW& c = tr->m->post_cbhg;
+    const CbhgW& c = *tr->c;
     const int M = tr->B * tr->T;
     const float bessel = M > 1 ? (float)M / (float)(M - 1) : 1.0f;
     auto upd = [&](const std::string& q, const float* mean, const float* var, int C) -> int {
@@ -514,7 +578,7 @@ extern "C" int t2v1_postnet_trainer_update_moving_stats(t2v1_ptrainer* tr, float
         hipLaunchKernelGGL(bn_moving_update_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, flat_params + im->second, flat_params + iv->second, mean, var, momentum, bessel, C);
         return T2_OK;
     };
-    const std::string p = "v1/postnet/cbhg";
+    const std::string p = tr->pfx;
     for (int k = 1; k <= c.K; ++k) T2_TRY(upd(p + "/conv1d_K" + std::to_string(k), tr->mean[0] + (size_t)(k - 1) * c.C, tr->var[0] + (size_t)(k - 1) * c.C, c.C));
     T2_TRY(upd(p + "/proj1", tr->mean[1], tr->var[1], c.P1));
     T2_TRY(upd(p + "/proj2", tr->mean[2], tr->var[2], c.P2));
@@ -535,12 +599,12 @@ extern "C" int t2v1_postnet_trainer_export(t2v1_ptrainer* tr, const float* flat_
     t2v1_model* m = tr->m;
     HIP_TRY(hipSetDevice(m->base.ctx->device));
     hipStream_t st = m->base.ctx->stream;
-    CbhgW& c = m->post_cbhg;
+    CbhgW& c = tr->which == 1 ? m->post_cbhg : m->enc_cbhg;
     const int H = c.half;
     tr->params = flat_params;
     int err = T2_OK;
     auto W = [&](const std::string& n) { return pt_w(tr, n, &err); };
-    const std::string p = "v1/postnet/cbhg";
+    const std::string p = tr->pfx;
     auto conv = [&](ConvLayer& L, const std::string& q) -> int {
         const float *k = W(q + "/kernel"), *g = W(q + "/batch_normalization/gamma"), *be = W(q + "/batch_normalization/beta"),
                     *mu = W(q + "/batch_normalization/moving_mean"), *va = W(q + "/batch_normalization/moving_variance");
@@ -577,12 +641,163 @@ extern "C" int t2v1_postnet_trainer_export(t2v1_ptrainer* tr, const float* flat_
         cp2(bg, 2 * H, c.gru_x[dir].shift, 3 * H, 1, 2 * H); cp2(bc, H, c.gru_x[dir].shift + 2 * H, 3 * H, 1, H);
         cp2(wg + (size_t)H * 2 * H, 2 * H, c.gru_hg[dir], 2 * H, H, 2 * H); cp2(wc + (size_t)H * H, H, c.gru_hc[dir], H, H, H);
     }
-    {
+    if (tr->which == 1) {
         const float *k = W("v1/postnet/linear/kernel"), *bi = W("v1/postnet/linear/bias");
         if (err != T2_OK) return err;
         const int F = m->d.num_freq;
         cp2(k, F, m->post_linear.w, F, 2 * H, F); cp2(bi, F, m->post_linear.shift, F, 1, F);
+    } else {
+        const float* emb = W("embedding");
+        if (err != T2_OK) return err;
+        HIP_TRY(hipMemcpyAsync(m->embedding, emb, (size_t)m->d.num_symbols * m->d.embedding_dim * 4, hipMemcpyDeviceToDevice, st));
+        int in = m->d.embedding_dim;
+        for (int i = 0; i < 2; ++i) {
+            const std::string q = "v1/encoder/prenet_" + std::to_string(i) + "/dense";
+            const float *k = W(q + "/kernel"), *bi = W(q + "/bias");
+            if (err != T2_OK) return err;
+            const int u = m->d.enc_prenet_units[i];
+            cp2(k, u, m->enc_prenet[i].w, u, in, u); cp2(bi, u, m->enc_prenet[i].shift, u, 1, u);
+            in = u;
+        }
+    }
+    m->gru_packed_stale = true;           // the launch-per-step GRU operands (option gruseq = 0) still hold the old values
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
+// ==========================================================================================================================
+// EncoderV1(is_training=True) (tacotron_v1.py:18-49) with the embedding in front (models.py:40-47): Embedding -> two PreNets
+// (Dense + relu + dropout, modules.py:80-91; masks from the counter-based generator, streams T2_STREAM_V1_ENC_PRENET + i, step 0,
+// row = batch position, column = unit) -> CBHG with batch-statistics batch norm -- forward with a tape, and the backward pass
+// from the gradient of the encoder output down to the embedding table.  The V1 decoder has no backward pass yet, so this is
+// the encoder half of SingleSpeakerTacotronV1Model's training step.
+// ==========================================================================================================================
+#define T2_STREAM_V1_ENC_PRENET 50
+
+__global__ __launch_bounds__(256) void v1_dropout_kernel(float* __restrict__ x, float rate, uint32_t seed, int stream, long long M, int C) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M * C; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C;
+        x[i] = dropout_train(x[i], rate, t2_u01(seed, stream, 0, (uint32_t)m, (uint32_t)(i - m * C)));
+    }
+}
+// through the dropout and the relu of a PreNet: out is what the layer handed on (0 where either of them cut)
+__global__ __launch_bounds__(256) void v1_relu_dropout_bwd_kernel(const float* dy, const float* __restrict__ out, float inv_keep, float* dz, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dz[i] = out[i] != 0.f ? dy[i] * inv_keep : 0.f;
+}
+
+// ids host [B][T_in] (range-checked: T2_ERANGE), lens host [B] or null (the V1 model_fn passes none, models.py:46-47),
+// memory_out dev [B][T_in][cbhg_out_units]
+static int encoder_train_forward_impl(t2v1_ptrainer* tr, const float* flat_params, const int64_t* ids, const float* emb_in, const int64_t* lens,
+                                      float drop_rate, uint32_t seed, float* memory_out) {
+    if (!tr || !flat_params || (!ids && !emb_in) || !memory_out) return fail(T2_EINVAL, "null argument");
+    if (tr->which != 0) return fail(T2_EINVAL, "not an encoder trainer");
+    if (!(drop_rate >= 0.f && drop_rate < 1.f)) return fail(T2_EINVAL, "drop_rate %g outside [0, 1)", (double)drop_rate);
+    t2v1_model* m = tr->m;
+    t2_model* b = &m->base;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    const t2v1_dims& d = m->d;
+    const int B = tr->B, T = tr->T, M = B * T, H = tr->c->half;
+    tr->params = flat_params; tr->have_forward = false; tr->have_stats = false; tr->drop_rate = drop_rate; tr->seed = seed;
+    int err = T2_OK;
+    auto W = [&](const std::string& n) { return pt_w(tr, n, &err); };
+    tr->have_ids = ids != nullptr;
+    if (ids) {
+        std::vector<int> h_ids(M);
+        for (int i = 0; i < M; ++i) {
+            if (ids[i] < 0 || ids[i] >= d.num_symbols) return fail(T2_ERANGE, "embedding id %lld outside [0, %d) (modules.py:65-66)", (long long)ids[i], d.num_symbols);
+            h_ids[i] = (int)ids[i];
+        }
+        HIP_TRY(hipMemcpyAsync(tr->ids, h_ids.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));                    // h_ids is a local
+        const float* table = W("embedding");
+        if (err != T2_OK) return err;
+        hipLaunchKernelGGL(embedding_kernel, dim3(std::min(1024, ceil_div(M * d.embedding_dim, 256))), dim3(256), 0, st, tr->ids, table, tr->emb, M, d.embedding_dim);
+    } else {
+        HIP_TRY(hipMemcpyAsync(tr->emb, emb_in, (size_t)M * d.embedding_dim * 4, hipMemcpyDeviceToDevice, st));
+    }
+    T2_TRY(v1_lens_to_dev(m, lens, B, T, 0, tr->lens));
+    const float* cur = tr->emb;
+    int in = d.embedding_dim;
+    for (int i = 0; i < 2; ++i) {
+        const std::string q = "v1/encoder/prenet_" + std::to_string(i) + "/dense";
+        ConvLayer L{};
+        L.w = const_cast<float*>(W(q + "/kernel")); L.shift = const_cast<float*>(W(q + "/bias")); L.k = 1; L.cin = in; L.cout = d.enc_prenet_units[i];
+        if (err != T2_OK) return err;
+        T2_TRY(launch_conv(b, L, cur, in, tr->pre[i], L.cout, M, M, 1, nullptr, 0));
+        if (drop_rate > 0.f)
+            hipLaunchKernelGGL(v1_dropout_kernel, pt_grid((long long)M * L.cout), dim3(256), 0, st, tr->pre[i], drop_rate, seed, T2_STREAM_V1_ENC_PRENET + i, (long long)M, L.cout);
+        cur = tr->pre[i]; in = L.cout;
+    }
+    T2_TRY(cbhg_train_forward_impl(tr, tr->pre[1]));
+    HIP_TRY(hipMemcpyAsync(memory_out, tr->out, (size_t)M * 2 * H * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    tr->have_forward = true; tr->have_stats = true;
+    return T2_OK;
+}
+extern "C" int t2v1_encoder_train_forward(t2v1_ptrainer* tr, const float* flat_params, const int64_t* ids, const int64_t* lens, float drop_rate,
+                                          uint32_t seed, float* memory_out) {
+    if (!ids) return fail(T2_EINVAL, "ids is null");
+    return encoder_train_forward_impl(tr, flat_params, ids, nullptr, lens, drop_rate, seed, memory_out);
+}
+// EncoderV1.call(is_training=True) on an embedded input emb dev [B][T_in][embedding_dim] (the block on its own, tacotron_v1.py:46-49)
+extern "C" int t2v1_encoder_train_forward_embedded(t2v1_ptrainer* tr, const float* flat_params, const float* emb, const int64_t* lens, float drop_rate,
+                                                   uint32_t seed, float* memory_out) {
+    if (!emb) return fail(T2_EINVAL, "emb is null");
+    return encoder_train_forward_impl(tr, flat_params, nullptr, emb, lens, drop_rate, seed, memory_out);
+}
+
+// dmemory dev [B][T_in][cbhg_out_units]: the gradient of the loss w.r.t. the encoder output.  Writes the gradients of the CBHG,
+// the PreNets and (after a forward from ids) the embedding table into flat_grads at the bound offsets; demb_out (dev
+// [B][T_in][embedding_dim], may be null): the gradient of the embedded input.
+extern "C" int t2v1_encoder_train_backward(t2v1_ptrainer* tr, const float* dmemory, float* flat_grads, float* demb_out) {
+    if (!tr || !dmemory || !flat_grads) return fail(T2_EINVAL, "null argument");
+    if (tr->which != 0) return fail(T2_EINVAL, "not an encoder trainer");
+    if (!tr->have_forward) return fail(T2_ESTATE, "t2v1_encoder_train_forward has not run");
+    t2v1_model* m = tr->m;
+    t2_model* b = &m->base;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    const t2v1_dims& d = m->d;
+    const int M = tr->B * tr->T, H = tr->c->half;
+    HIP_TRY(hipMemcpyAsync(tr->dout, dmemory, (size_t)M * 2 * H * 4, hipMemcpyDeviceToDevice, st));
+    T2_TRY(cbhg_train_backward_impl(tr, flat_grads, true));
+    int err = T2_OK;
+    auto W = [&](const std::string& n) { return pt_w(tr, n, &err); };
+    auto G = [&](const std::string& n) -> float* {
+        auto it = tr->ws.offsets.find(n);
+        if (it == tr->ws.offsets.end()) { err = fail(T2_ESTATE, "no offset bound for '%s'", n.c_str()); return nullptr; }
+        return flat_grads + it->second;
+    };
+    const float inv_keep = 1.0f / (1.0f - tr->drop_rate);
+    const float* dy = tr->dx0;                                 // gradient of PreNet 1's output (= the CBHG's input)
+    for (int i = 1; i >= 0; --i) {
+        const std::string q = "v1/encoder/prenet_" + std::to_string(i) + "/dense";
+        const int u = d.enc_prenet_units[i], in = i == 0 ? d.embedding_dim : d.enc_prenet_units[0];
+        const float* x = i == 0 ? tr->emb : tr->pre[0];
+        const float* wk = W(q + "/kernel");
+        float *gk = G(q + "/kernel"), *gb = G(q + "/bias");
+        if (err != T2_OK) return err;
+        hipLaunchKernelGGL(v1_relu_dropout_bwd_kernel, pt_grid((long long)M * u), dim3(256), 0, st, dy, tr->pre[i], inv_keep, tr->dpre[i], (long long)M * u);
+        T2_TRY(bwd_wgrad(&tr->ws, x, in, in, tr->dpre[i], u, u, M, gk, u));
+        T2_TRY(col_sum(&tr->ws, tr->dpre[i], M, u, gb));
+        T2_TRY(pt_transpose(tr, wk, tr->wpreT[i], in, u));
+        if (i == 1) {
+            T2_TRY(pt_dgrad_dense(tr, tr->dpre[1], u, tr->wpreT[1], in, tr->dpre[0], nullptr));
+            dy = tr->dpre[0];                                  // masked in place by the next round
+        } else {
+            // d embedded rows -> the table: the rows of every symbol are added in row order (embedding_grad_kernel)
+            T2_TRY(pt_dgrad_dense(tr, tr->dpre[0], u, tr->wpreT[0], in, tr->emb, nullptr));      // the embedded input is consumed: its buffer takes d emb
+            if (demb_out) HIP_TRY(hipMemcpyAsync(demb_out, tr->emb, (size_t)M * in * 4, hipMemcpyDeviceToDevice, st));
+            if (tr->have_ids) {
+                float* ge = G("embedding");
+                if (err != T2_OK) return err;
+                hipLaunchKernelGGL(embedding_grad_kernel, dim3(d.num_symbols), dim3(256), 0, st, tr->ids, tr->emb, M, in, ge);
+            }
+        }
     }
     HIP_TRY(hipGetLastError());
+    tr->have_forward = false;
     return T2_OK;
 }

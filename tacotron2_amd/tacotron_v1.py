@@ -158,23 +158,37 @@ class CBHG:
 
 
 class EncoderV1:
-    """tacotron_v1.py:18-52."""
+    """tacotron_v1.py:18-52.  ``is_training=True`` with ``drop_rate > 0`` (PreNet dropout, batch-statistics batch norm in the
+    CBHG) runs ``EncoderV1Trainer`` and needs the flat parameter buffer it reads: ``flat_params`` / ``spec``
+    (``training.flatten_spec`` of the embedding + v1/encoder/ variables); ``seed`` advances per call."""
 
     def __init__(self, is_training, cbhg_out_units=256, conv_channels=128, max_filter_width=16, projection1_out_channels=128,
                  projection2_out_channels=128, num_highway=4, prenet_out_units=(256, 128), drop_rate=0.5,
-                 engine: EngineV1 = None, name=None, dtype=None):
-        if is_training and drop_rate > 0:
-            raise NotImplementedError("dropout sampling (training mode) is not built; use drop_rate=0 or is_training=False")
+                 engine: EngineV1 = None, name=None, dtype=None, flat_params: Optional[torch.Tensor] = None, spec=None, seed: int = 0):
         self.prenet_out_units = tuple(prenet_out_units)
         self.cbhg_out_units = cbhg_out_units
         self._engine = engine
+        self.is_training, self.drop_rate = bool(is_training), float(drop_rate)
+        self.flat_params, self.spec, self.seed, self.trainer = flat_params, spec, int(seed), None
+        if self.is_training and (flat_params is None or spec is None):
+            raise ValueError("EncoderV1(is_training=True) needs flat_params and spec (training.flatten_spec of the embedding and "
+                             "v1/encoder/ variables): batch-statistics batch norm and dropout run on the training step's buffer")
 
     def __call__(self, inputs, input_lengths=None, **kwargs):
         return self.call(inputs, input_lengths=input_lengths)
 
     def call(self, inputs, input_lengths=None, **kwargs):
         assert self.prenet_out_units[0] == inputs.shape[2]               # tacotron_v1.py:41-44
-        return self._engine.encode_embedded(inputs, input_lengths)
+        if not self.is_training:
+            return self._engine.encode_embedded(inputs, input_lengths)
+        B, T = int(inputs.shape[0]), int(inputs.shape[1])
+        if self.trainer is None or (self.trainer.B, self.trainer.T) != (B, T):
+            if self.trainer is not None:
+                self.trainer.close()
+            self.trainer = EncoderV1Trainer(self._engine, B, T, self.spec)
+        out = self.trainer.forward_embedded(self.flat_params, inputs, input_lengths, drop_rate=self.drop_rate, seed=self.seed)
+        self.seed += 1
+        return out
 
     def compute_output_shape(self, input_shape):
         return (input_shape[0], input_shape[1], self.cbhg_out_units)
@@ -298,6 +312,61 @@ class PostNetTrainer:
             self.close()
         except Exception:
             pass
+
+
+class EncoderV1Trainer(PostNetTrainer):
+    """The encoder half of SingleSpeakerTacotronV1Model's training step (models.py:40-47 with is_training=True): Embedding ->
+    PreNets with dropout -> CBHG with batch-statistics batch norm, forward with a tape and the backward pass from d loss /
+    d memory to the embedding table (include/t2mi.h, t2v1_encoder_train_*).  Same flat-buffer convention as ``PostNetTrainer``
+    over the ``embedding`` and ``v1/encoder/`` variables; ``update_moving_stats`` / ``export`` are inherited."""
+
+    def __init__(self, engine: EngineV1, B: int, T: int, spec):
+        self.engine, self.B, self.T, self.spec = engine, int(B), int(T), spec
+        self._spec = spec
+        self._h = C.c_void_p()
+        _lib.check(engine.lib.t2v1_encoder_trainer_create(engine._model, self.B, self.T, C.byref(self._h)))
+        for name, shape, off, size in spec:
+            _lib.check(engine.lib.t2v1_postnet_trainer_bind(self._h, name.encode(), int(off)))
+
+    @staticmethod
+    def encoder_weights(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+        return {k: v for k, v in weights.items() if k == "embedding" or k.startswith("v1/encoder/")}
+
+    def forward(self, flat_params: torch.Tensor, ids, lens=None, drop_rate: float = 0.5, seed: int = 0) -> torch.Tensor:
+        eng = self.engine
+        ids, lens = _i64(ids), _i64(lens)
+        if tuple(ids.shape) != (self.B, self.T):
+            raise ValueError("ids do not match the trainer's (B, T_in)")
+        self._params = self._flat(flat_params, "flat_params")
+        out = eng._out(self.B, self.T, eng.dims.cbhg_out_units)
+        with eng.context.ordered():
+            _lib.check(eng.lib.t2v1_encoder_train_forward(self._h, flat_params.data_ptr(), _hp(ids), _hp(lens), float(drop_rate),
+                                                          int(seed) & 0xFFFFFFFF, out.data_ptr()))
+        return out
+
+    def forward_embedded(self, flat_params: torch.Tensor, emb, lens=None, drop_rate: float = 0.5, seed: int = 0) -> torch.Tensor:
+        eng = self.engine
+        emb, lens = eng._f32(emb), _i64(lens)
+        if tuple(emb.shape) != (self.B, self.T, eng.dims.embedding_dim):
+            raise ValueError("input does not match the trainer's (B, T_in, embedding_dim)")
+        self._params = self._flat(flat_params, "flat_params")
+        out = eng._out(self.B, self.T, eng.dims.cbhg_out_units)
+        with eng.context.ordered():
+            _lib.check(eng.lib.t2v1_encoder_train_forward_embedded(self._h, flat_params.data_ptr(), emb.data_ptr(), _hp(lens), float(drop_rate),
+                                                                   int(seed) & 0xFFFFFFFF, out.data_ptr()))
+        return out
+
+    def backward(self, dmemory, flat_grads: torch.Tensor, want_input_grad: bool = False):
+        """Gradients of every encoder variable (and of the table after ``forward``) for d loss / d memory = ``dmemory``."""
+        eng = self.engine
+        dm = eng._f32(dmemory)
+        if tuple(dm.shape) != (self.B, self.T, eng.dims.cbhg_out_units):
+            raise ValueError("dmemory does not match the trainer's (B, T_in, cbhg_out_units)")
+        self._flat(flat_grads, "flat_grads")
+        demb = eng._out(self.B, self.T, eng.dims.embedding_dim) if want_input_grad else None
+        with eng.context.ordered():
+            _lib.check(eng.lib.t2v1_encoder_train_backward(self._h, dm.data_ptr(), flat_grads.data_ptr(), None if demb is None else demb.data_ptr()))
+        return demb
 
 
 class PostNet:

@@ -267,3 +267,115 @@ def test_postnet_training_step_two_ranks_share_the_loss_normalisation():
                 continue
             scale = float(np.abs(g_sum[off:off + size]).max())
             assert float(np.abs(r[2][off:off + size] - g_sum[off:off + size]).max()) <= 5e-3 * scale + 1e-9, name
+
+
+# ---- EncoderV1 training step (the encoder half of SingleSpeakerTacotronV1Model.model_fn(TRAIN), models.py:40-47) ----
+ENC = V1_PROFILE.replace(num_symbols=40)                                  # published encoder sizes: K = 16 bank, 128-unit GRUs, no adjustment layer
+ENC_NARROW = V1_PROFILE.replace(num_symbols=30, embedding_dim=32, encoder_prenet_out_units=(32, 48), conv_channels=16, max_filter_width=5,
+                                projection1_out_channels=24, projection2_out_channels=48, num_highway=2)     # adjustment layer 48 -> 128, odd bank
+
+
+def _enc_setup(d, seed=13):
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import EncoderV1Trainer, EngineV1
+    w = init_weights_v1(d, seed, perturb=True)
+    eng = EngineV1(d, w)
+    ew = EncoderV1Trainer.encoder_weights(w)
+    spec = TR.flatten_spec(ew)
+    flat = torch.tensor(TR.flatten(ew, spec), device="cuda")
+    return w, eng, ew, spec, flat
+
+
+@pytest.mark.parametrize("d,B,T,drop,with_lens", [(ENC_NARROW, 3, 11, 0.5, True), (ENC_NARROW, 18, 7, 0.0, False), (ENC, 4, 21, 0.5, True),
+                                                  (ENC, 33, 16, 0.5, False)])
+def test_encoder_v1_training_forward_and_every_gradient_against_autograd(d, B, T, drop, with_lens):
+    """Embedding -> PreNets (dropout masks from the shared counter-based generator) -> CBHG with batch statistics and sequence
+    lengths: the encoder output and the gradient of every encoder variable and of the embedding table for a random
+    d loss / d memory, against fp64 autograd; same kink-aware tolerance as the PostNet test above."""
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import EncoderV1Trainer
+    w, eng, ew, spec, flat = _enc_setup(d)
+    rng = np.random.default_rng(10 * B + T)
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    lens = None
+    if with_lens:
+        lens = rng.integers(max(1, T // 2), T + 1, size=B).astype(np.int64)
+        lens[0] = T
+    dmem = rng.standard_normal((B, T, d.cbhg_out_units)).astype(np.float32)
+    if lens is not None:
+        dmem *= (np.arange(T)[None, :] < lens[:, None])[:, :, None]      # nothing flows into positions past a row's length
+    seed = 77
+    ref = VT.encoder_train_forward_backward(d, w, ids, lens, dmem, drop, seed)
+    side = [VT.encoder_train_forward_backward(d, w, ids, lens, dmem, drop, seed, relu_shift=sh)["grads"] for sh in (KINK, -KINK)]
+    tr = EncoderV1Trainer(eng, B, T, spec)
+    mem = tr.forward(flat, ids, lens, drop_rate=drop, seed=seed)
+    np.testing.assert_allclose(_np(mem), ref["memory"], atol=ATOL)
+    grads = torch.full_like(flat, float("nan"))
+    demb = tr.backward(dmem, grads, want_input_grad=True)
+    assert tuple(demb.shape) == (B, T, d.embedding_dim) and np.isfinite(_np(demb)).all()
+    got = TR.unflatten(grads, spec)
+    checked = 0
+    for name, g_ref in ref["grads"].items():
+        if name.endswith(("moving_mean", "moving_variance")):
+            continue
+        scale = float(np.abs(g_ref).max())
+        assert scale >= 1e-7, (name, scale)
+        assert np.isfinite(got[name]).all(), name
+        spread = np.abs(side[0][name] - g_ref) + np.abs(side[1][name] - g_ref)
+        assert float(np.median(spread)) <= 5e-3 * scale and float(spread.max()) <= 0.1 * scale, (name, "kink spread too wide to test")
+        excess = np.abs(got[name] - g_ref) - (2e-3 * scale + 1e-9 + 1.5 * spread)
+        assert float(excess.max()) <= 0.0, (name, float(np.abs(got[name] - g_ref).max()), scale, float(spread.max()))
+        checked += 1
+    assert checked == sum(1 for n in ew if not n.endswith(("moving_mean", "moving_variance")))
+    # the table's gradient is the scatter-add of the input gradient
+    tab = np.zeros_like(w["embedding"])
+    np.add.at(tab, ids.reshape(-1), _np(demb).reshape(-1, d.embedding_dim))
+    np.testing.assert_allclose(got["embedding"], tab, atol=1e-5 * float(np.abs(tab).max()) + 1e-9)
+    tr.close()
+    eng.close()
+
+
+def test_encoder_v1_block_in_training_mode_and_export():
+    """EncoderV1(is_training=True).call on an embedded input (the block on its own, tacotron_v1.py:46-49): dropout seed advancing
+    per call, moving statistics updated from the batch statistics, and export: the engine's inference encoder then equals a
+    fresh engine built from the buffer's variables."""
+    import torch
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import EncoderV1, EngineV1
+    d, B, T = ENC_NARROW, 5, 9
+    w, eng, ew, spec, flat = _enc_setup(d)
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, d.num_symbols, (B, T))
+    emb = O.embedding_lookup(ids, w["embedding"])
+    with pytest.raises(ValueError):
+        EncoderV1(True, engine=eng, prenet_out_units=d.encoder_prenet_out_units)
+    enc = EncoderV1(True, d.cbhg_out_units, d.conv_channels, d.max_filter_width, d.projection1_out_channels, d.projection2_out_channels,
+                    d.num_highway, d.encoder_prenet_out_units, 0.5, engine=eng, flat_params=flat, spec=spec, seed=5)
+    y0, y1 = enc(emb), enc(emb)
+    assert float((y0 - y1).abs().max()) > 1e-3                               # another seed, other masks
+    dm = np.ones((B, T, d.cbhg_out_units), np.float32)
+    np.testing.assert_allclose(_np(y1), VT.encoder_train_forward_backward(d, w, ids, None, dm, 0.5, 6)["memory"], atol=ATOL)
+    before = TR.unflatten(flat, spec)
+    enc.trainer.update_moving_stats(flat)
+    ref = VT.encoder_train_forward_backward(d, w, ids, None, dm, 0.5, 6)
+    after = TR.unflatten(flat, spec)
+    n = B * T
+    for p_, (mu, var) in ref["bn_stats"].items():
+        q = p_ + "/batch_normalization"
+        np.testing.assert_allclose(after[q + "/moving_mean"], 0.99 * before[q + "/moving_mean"] + 0.01 * mu, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(after[q + "/moving_variance"], 0.99 * before[q + "/moving_variance"] + 0.01 * var * n / (n - 1), rtol=1e-4, atol=1e-6)
+    flat += 0.01 * torch.randn_like(flat)                                    # "trained" variables
+    flat.abs_()                                                              # keeps the moving variances positive
+    enc.trainer.export(flat)
+    full = dict(w)
+    full.update(TR.unflatten(flat, spec))
+    eng2 = EngineV1(d, full)
+    lens = np.array([9, 4, 6, 9, 2], np.int64)
+    np.testing.assert_allclose(_np(eng.encode(ids, lens)), _np(eng2.encode(ids, lens)), atol=2e-6, rtol=2e-6)
+    from tacotron2_amd._lib import T2Error
+    with pytest.raises(T2Error):
+        eng.set_option("gruseq", 0)                                          # the launch-per-step GRU operands were not rebuilt
+    eng2.close()
+    eng.close()
