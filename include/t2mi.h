@@ -387,6 +387,25 @@ int t2v1_encoder_train_forward_embedded(t2v1_ptrainer* tr, const float* flat_par
  * forward from ids only */
 int t2v1_encoder_train_backward(t2v1_ptrainer* tr, const float* dmemory, float* flat_grads, float* demb_out);
 
+/* DecoderV1.call(is_training=True) (tacotron_v1.py:94-153: PreNets with dropout, AttentionRNN(GRUCell, BahdanauAttention),
+ * OutputProjectionWrapper, two ResidualWrapper(GRUCell), mel / stop projections, under TrainingHelper helpers.py:141-184) with a
+ * tape, and the backward pass of loss = spec_loss(mel) + binary_loss(stop) (models.py:58-61): with the encoder trainer above,
+ * SingleSpeakerTacotronV1Model.model_fn(mode=TRAIN) (models.py:40-76).  One trainer per (B, T_in, S = T_out / r).  Flat-buffer
+ * convention as above over the v1/decoder/ and v1/attention/ variables.  memory dev [B,T_in,cbhg_out_units]; lens host [B] or
+ * NULL (memory_sequence_length); target dev [B,S*r,num_mels]; mel_out dev [B,S*r,num_mels], stop_out dev [B,S], align_out dev
+ * [S,B,T_in].  _backward: done / bin_mask dev [B,S], spec_mask dev [B,S*r] -> gradients into flat_grads, d loss / d memory into
+ * dmemory (dev [B,T_in,cbhg_out_units]), {mel_loss, done_loss, loss} into loss_out (dev [3]).  _set_loss_counts: dev [2], the
+ * non-zero loss-weight counts of a larger data-parallel batch (NULL: this batch's own). */
+typedef struct t2v1_dtrainer t2v1_dtrainer;
+int t2v1_decoder_trainer_create(t2v1_model* m, int B, int T_in, int S, t2v1_dtrainer** out);
+int t2v1_decoder_trainer_destroy(t2v1_dtrainer* tr);
+int t2v1_decoder_trainer_bind(t2v1_dtrainer* tr, const char* name, int64_t offset);
+int t2v1_decoder_trainer_set_loss_counts(t2v1_dtrainer* tr, const float* counts);
+int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_params, const float* memory, const int64_t* lens, const float* target,
+                               float drop_rate, uint32_t seed, float* mel_out, float* stop_out, float* align_out);
+int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done, const float* spec_mask, const float* bin_mask, float* flat_grads,
+                                float* dmemory, float* loss_out);
+
 /* ---- spectrogram -> waveform ------------------------------------------------------------
  * Audio.inv_spectrogram_tf (util/audio.py:55-59): inv_amp_tf (:51-53: clip to [0,1], de-normalise with min_level_db,
  * + ref_level_db, dB -> amplitude), ** power, then _griffin_lim_tf (:66-82): y = inverse_stft(S); `iters` times

@@ -163,3 +163,75 @@ def encoder_train_forward_backward(d, w, ids, lens, dmemory, drop_rate=0.5, seed
     f32 = lambda t: t.detach().numpy().astype(np.float32)
     grads = {k: (f32(v.grad) if v.grad is not None else np.zeros(tuple(v.shape), np.float32)) for k, v in W.items()}
     return {"memory": f32(y), "grads": grads, "bn_stats": {k: (f32(a), f32(b)) for k, (a, b) in stats.items()}}
+
+
+# ---- DecoderV1 training step (tacotron_v1.py:56-153 with is_training=True; losses of models.py:58-61) ----
+def _gru_cell(x, h, W, p):
+    wg, bg, wc, bc = W[f"{p}/gates/kernel"], W[f"{p}/gates/bias"], W[f"{p}/candidate/kernel"], W[f"{p}/candidate/bias"]
+    H = wc.shape[1]
+    g = torch.sigmoid(torch.cat([x, h], -1) @ wg + bg)
+    r, u = g[:, :H], g[:, H:]
+    c = torch.tanh(torch.cat([x, r * h], -1) @ wc + bc)
+    return u * h + (1.0 - u) * c
+
+
+def decoder_train_forward_backward(d, w, memory, lens, labels, drop_rate=0.5, seed=0, loss_counts=None):
+    """DecoderV1.call(is_training=True) (TrainingHelper: the last n_feed_frame target frames of the previous group are fed,
+    helpers.py:141-184) on OutputAndStopTokenWrapper(DecoderRNNV1(OutputProjectionWrapper(AttentionRNN(GRUCell, PreNets,
+    BahdanauAttention)), 2 x ResidualWrapper(GRUCell))), and loss = spec_loss(mel) + binary_loss(stop) (models.py:58-61).
+    PreNet dropout masks from the shared counter-based generator: stream 60 + layer, step t, row, unit.
+    labels: mel [B, S*r, M], done [B, S], spec_loss_mask [B, S*r], binary_loss_mask [B, S].
+    Returns dict(mel, stop, alignments [S, B, T], loss, mel_loss, done_loss, grads{name}, dmemory)."""
+    from oracle import t2_oracle as O
+    names = [k for k in w if k.startswith(("v1/decoder/", "v1/attention/"))]
+    W = {k: _t(w[k]).clone().requires_grad_(True) for k in names}
+    mem = _t(memory).clone().requires_grad_(True)
+    B, T, E = mem.shape
+    M, r, nf = d.num_mels, d.outputs_per_step, d.n_feed_frame
+    target = _t(labels["mel"])
+    S = target.shape[1] // r
+    grouped = target.reshape(B, S, M * r)
+    lens_t = torch.full((B,), T, dtype=torch.long) if lens is None else torch.as_tensor(np.asarray(lens), dtype=torch.long)
+    live = (torch.arange(T)[None, :] < lens_t[:, None])
+    values = mem * live[:, :, None].to(DT)
+    keys = values @ W["v1/attention/memory_layer/kernel"]
+    A, D = d.attention_out_units, d.decoder_out_units
+    ha, ctx, h1, h2 = torch.zeros(B, A, dtype=DT), torch.zeros(B, E, dtype=DT), torch.zeros(B, D, dtype=DT), torch.zeros(B, D, dtype=DT)
+    keep = 1.0 - drop_rate
+    mels, stops, aligns = [], [], []
+    for t in range(S):
+        x = torch.zeros(B, M * nf, dtype=DT) if t == 0 else grouped[:, t - 1, -M * nf:]
+        for i in range(2):
+            q = f"v1/decoder/prenet_{i}/dense"
+            x = torch.relu(x @ W[q + "/kernel"] + W[q + "/bias"])
+            if drop_rate > 0:
+                u = O.rng_u01(seed, 60 + i, t, B, x.shape[1])
+                x = x / keep * _t((u >= np.float32(drop_rate)).astype(np.float64))
+        ha = _gru_cell(torch.cat([x, ctx], -1), ha, W, "v1/decoder/attention_gru")
+        qv = ha @ W["v1/attention/query_layer/kernel"]
+        score = (W["v1/attention/attention_v"] * torch.tanh(keys + qv[:, None, :])).sum(-1)
+        score = torch.where(live, score, torch.full_like(score, -float("inf")))
+        a = torch.softmax(score, dim=-1)
+        ctx = (a[:, :, None] * values).sum(1)
+        y0 = torch.cat([ha, ctx], -1) @ W["v1/decoder/output_projection/kernel"] + W["v1/decoder/output_projection/bias"]
+        h1 = _gru_cell(y0, h1, W, "v1/decoder/gru_1")
+        y1 = y0 + h1
+        h2 = _gru_cell(y1, h2, W, "v1/decoder/gru_2")
+        y2 = y1 + h2
+        mels.append(y2 @ W["v1/decoder/out_projection/kernel"] + W["v1/decoder/out_projection/bias"])
+        stops.append(y2 @ W["v1/decoder/stop_token_projection/kernel"] + W["v1/decoder/stop_token_projection/bias"])
+        aligns.append(a)
+    mel = torch.stack(mels, 1).reshape(B, S * r, M)
+    stop = torch.stack(stops, 1)[:, :, 0]
+    m1, m2, done = _t(labels["spec_loss_mask"]), _t(labels["binary_loss_mask"]), _t(labels["done"])
+    n1 = float((m1 != 0).sum() * M) if loss_counts is None else loss_counts[0]
+    n2 = float((m2 != 0).sum()) if loss_counts is None else loss_counts[1]
+    mel_loss = ((mel - target).abs() * m1[:, :, None]).sum() / n1
+    ce = torch.clamp(stop, min=0) - stop * done + torch.log1p(torch.exp(-stop.abs()))
+    done_loss = (ce * m2).sum() / n2
+    loss = mel_loss + done_loss
+    loss.backward()
+    f32 = lambda t_: t_.detach().numpy().astype(np.float32)
+    return {"mel": f32(mel), "stop": f32(stop), "alignments": f32(torch.stack(aligns, 0)), "loss": float(loss.detach()),
+            "mel_loss": float(mel_loss.detach()), "done_loss": float(done_loss.detach()),
+            "grads": {k: f32(v.grad) for k, v in W.items()}, "dmemory": f32(mem.grad)}

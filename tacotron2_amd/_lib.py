@@ -91,6 +91,12 @@ _SIGS = {
     "t2v1_postnet_train_backward": (C.c_int, [_p, _p, _p, _p, _p, _p]),
     "t2v1_postnet_trainer_update_moving_stats": (C.c_int, [_p, _p, C.c_float]),
     "t2v1_postnet_trainer_export": (C.c_int, [_p, _p]),
+    "t2v1_decoder_trainer_create": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),
+    "t2v1_decoder_trainer_destroy": (C.c_int, [_p]),
+    "t2v1_decoder_trainer_bind": (C.c_int, [_p, C.c_char_p, C.c_int64]),
+    "t2v1_decoder_trainer_set_loss_counts": (C.c_int, [_p, _p]),
+    "t2v1_train_decoder_forward": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, C.c_uint32, _p, _p, _p]),
+    "t2v1_train_decoder_backward": (C.c_int, [_p, _p, _p, _p, _p, _p, _p]),
     "t2v1_encoder_trainer_create": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(_p)]),
     "t2v1_encoder_train_forward": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_uint32, _p]),
     "t2v1_encoder_train_forward_embedded": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_uint32, _p]),

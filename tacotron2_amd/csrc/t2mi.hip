@@ -2174,6 +2174,7 @@ extern "C" int t2_model_get_stat(t2_model* m, const char* name, double* out) {
 // training step of the Tacotron-1 PostNet model (BASELINE.json configs[4])
 // ------------------------------------------------------------------------------------------------
 #include "v1_train.h"
+#include "v1_dec_train.h"
 
 // ------------------------------------------------------------------------------------------------
 // spectrogram -> waveform (Griffin-Lim)

@@ -1,0 +1,574 @@
+// Training step of the Tacotron-1 decoder: DecoderV1.call(is_training=True) (tacotron/tacotron_v1.py:94-153) =
+// OutputAndStopTokenWrapper(DecoderRNNV1(OutputProjectionWrapper(AttentionRNN(GRUCell, PreNets with dropout, BahdanauAttention)),
+// 2 x ResidualWrapper(GRUCell))) (tacotron_v1.py:56-91, rnn_wrappers.py:81-186) under TrainingHelper (helpers.py:141-184), the
+// two losses of models.py:58-61, and the hand-written backward pass (BPTT) of all of it.  Included by t2mi.hip after v1_train.h.
+// With t2v1_encoder_train_* this is SingleSpeakerTacotronV1Model.model_fn(mode=TRAIN) (models.py:40-76).
+//
+// Design: correctness first -- plain row-major operands, one launch per phase (8 small GEMMs + 7 elementwise / attention
+// launches per decoder step forward, 8 + 9 backward), weights read in place from the caller's flat parameter buffer.  What keeps
+// the launch count down: (1) every operand a cell multiplies is kept CONCATENATED the way TF's kernels expect it ([ctx | h],
+// [ctx | r*h], [h_att | ctx], [y | h]), written in place by the kernels that produce the pieces, so a GRU cell is two GEMMs and
+// the per-step slices double as the tape of the weight-gradient GEMMs; (2) everything that does not feed the recurrence is
+// batched over all S*B rows: PreNets and their share of the attention GRU's pre-activations before the loop, the mel / stop
+// projections after it; in the backward pass the projection gradient before the loop, every weight gradient, the PreNets,
+// d values and the memory layer after it.
+#pragma once
+
+#define T2_STREAM_V1_DEC_PRENET 60
+
+struct V1Dst { float* p; int ld; };
+
+// x[m][:] of step t = m / B, row b = m % B: the last nf target frames of the previous group (TrainingHelper.next_inputs), zeros at t = 0
+__global__ __launch_bounds__(256) void v1d_feed_kernel(const float* __restrict__ target, float* __restrict__ xin, int B, int S, int r, int nf, int M) {
+    const long long n = (long long)S * B * nf * M;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (nf * M)), b = (int)((i / (nf * M)) % B), t = (int)(i / ((long long)nf * M * B));
+        xin[i] = t == 0 ? 0.f : target[((size_t)b * S * r + (size_t)t * r - nf) * M + c];
+    }
+}
+// PreNet dropout over the batched rows m = t * B + b: masks keyed on (seed, stream, step t, row b, unit)
+__global__ __launch_bounds__(256) void v1d_dropout_kernel(float* __restrict__ x, float rate, uint32_t seed, int stream, int B, long long rows, int C) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * C; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C;
+        x[i] = dropout_train(x[i], rate, t2_u01(seed, stream, (uint32_t)(m / B), (uint32_t)(m % B), (uint32_t)(i - m * C)));
+    }
+}
+// GRUCell gates: [r | u] = sigmoid(zg); the candidate's operand [x | r * h] from the gates' operand [x | h]
+__global__ __launch_bounds__(256) void v1d_gate_kernel(const float* __restrict__ zg, const float* __restrict__ cat, int X, int H, float* __restrict__ ru,
+                                                       float* __restrict__ catr, int B) {
+    const int W = X + H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * (W + H); i += gridDim.x * blockDim.x) {
+        const int b = i / (W + H), c = i - b * (W + H);
+        if (c < X) catr[(size_t)b * W + c] = cat[(size_t)b * W + c];
+        else if (c < W) {
+            const int u = c - X;
+            const float r = sigmoidf_(zg[(size_t)b * 2 * H + u]);
+            ru[(size_t)b * 2 * H + u] = r;
+            catr[(size_t)b * W + c] = r * cat[(size_t)b * W + c];
+        } else {
+            const int u = c - W;
+            ru[(size_t)b * 2 * H + H + u] = sigmoidf_(zg[(size_t)b * 2 * H + H + u]);
+        }
+    }
+}
+// c = tanh(zc); h' = u h + (1 - u) c -> up to two destinations; ResidualWrapper: y = x + h' -> up to two destinations (X == H)
+__global__ __launch_bounds__(256) void v1d_blend_kernel(const float* __restrict__ zc, const float* __restrict__ ru, const float* __restrict__ cat, int X, int H,
+                                                        float* __restrict__ cnd, V1Dst h0, V1Dst h1, V1Dst y0, V1Dst y1, int B) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * H; i += gridDim.x * blockDim.x) {
+        const int b = i / H, u = i - b * H;
+        const float c = tanhf(zc[i]), uu = ru[(size_t)b * 2 * H + H + u], h = cat[(size_t)b * (X + H) + X + u];
+        const float hn = uu * h + (1.0f - uu) * c;
+        cnd[i] = c;
+        if (h0.p) h0.p[(size_t)b * h0.ld + u] = hn;
+        if (h1.p) h1.p[(size_t)b * h1.ld + u] = hn;
+        if (y0.p || y1.p) {
+            const float y = cat[(size_t)b * (X + H) + u] + hn;
+            if (y0.p) y0.p[(size_t)b * y0.ld + u] = y;
+            if (y1.p) y1.p[(size_t)b * y1.ld + u] = y;
+        }
+    }
+}
+// BahdanauAttention.__call__ + AttentionWrapper._compute_attention (App. A5, A6) of one batch row per workgroup:
+// score_j = v . tanh(keys_j + q), softmax over the live positions (-inf mask), context = sum_j a_j values_j
+__global__ __launch_bounds__(256) void v1d_attn_fwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
+                                                           const float* __restrict__ v, const int* __restrict__ lens, int T, int A, int E,
+                                                           float* __restrict__ align, V1Dst c0, V1Dst c1) {
+    extern __shared__ float sm[];
+    float *s_q = sm, *s_v = sm + A, *s_e = sm + 2 * A;
+    __shared__ float s_red[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int len = lens[b];
+    for (int u = tid; u < A; u += 256) { s_q[u] = q[(size_t)b * A + u]; s_v[u] = v[u]; }
+    __syncthreads();
+    for (int j = wave; j < len; j += 4) {
+        const float* k = keys + ((size_t)b * T + j) * A;
+        float p = 0.f;
+        for (int u = lane; u < A; u += 64) p += s_v[u] * tanhf(k[u] + s_q[u]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+        if (lane == 0) s_e[j] = p;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < len; j += 256) mx = fmaxf(mx, s_e[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < T; j += 256) { const float e = j < len ? expf(s_e[j] - mx) : 0.f; s_e[j] = e; sum += e; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) s_red[4 + wave] = sum;
+    __syncthreads();
+    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    for (int j = tid; j < T; j += 256) { const float p = s_e[j] / sum; s_e[j] = p; align[(size_t)b * T + j] = p; }
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < len; ++j) acc = fmaf(s_e[j], values[((size_t)b * T + j) * E + e], acc);
+        if (c0.p) c0.p[(size_t)b * c0.ld + e] = acc;
+        if (c1.p) c1.p[(size_t)b * c1.ld + e] = acc;
+    }
+}
+// its backward for one row: d a_j = d ctx . values_j; softmax backward; d q = sum_j g_j, d keys_j += g_j, d v += sum_j d e_j tanh_j
+// with g_ju = d e_j v_u (1 - tanh_ju^2).  (d values is a tape-wide product afterwards; the Bahdanau state is not fed back.)
+__global__ __launch_bounds__(256) void v1d_attn_bwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
+                                                           const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align,
+                                                           const float* __restrict__ dctx, long long dctx_row_stride, int T, int A, int E,
+                                                           float* __restrict__ dq, float* __restrict__ dkeys, float* __restrict__ dvpart) {
+    extern __shared__ float sm[];
+    float *s_dc = sm, *s_de = sm + E;
+    __shared__ float s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int len = lens[b];
+    for (int e = tid; e < E; e += 256) s_dc[e] = dctx[(size_t)b * dctx_row_stride + e];
+    __syncthreads();
+    for (int j = wave; j < len; j += 4) {
+        const float* vj = values + ((size_t)b * T + j) * E;
+        float p = 0.f;
+        for (int e = lane; e < E; e += 64) p += s_dc[e] * vj[e];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+        if (lane == 0) s_de[j] = p;
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int j = tid; j < len; j += 256) s += align[(size_t)b * T + j] * s_de[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) s_red[wave] = s;
+    __syncthreads();
+    s = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    for (int j = tid; j < len; j += 256) s_de[j] = align[(size_t)b * T + j] * (s_de[j] - s);
+    __syncthreads();
+    for (int u = tid; u < A; u += 256) {
+        const float qu = q[(size_t)b * A + u], vu = v[u];
+        float aq = 0.f, av = 0.f;
+        for (int j = 0; j < len; ++j) {
+            const size_t ki = ((size_t)b * T + j) * A + u;
+            const float th = tanhf(keys[ki] + qu), de = s_de[j];
+            const float g = de * vu * (1.0f - th * th);
+            aq += g; av += de * th;
+            dkeys[ki] += g;
+        }
+        dq[(size_t)b * A + u] = aq;
+        dvpart[(size_t)b * A + u] += av;
+    }
+}
+// GRU cell backward, stage 1: d h' = d0 (+ d1) -> d zc, d zu, and the part of d h that does not pass a GEMM (d h' u)
+__global__ __launch_bounds__(256) void v1d_bwd1_kernel(const float* __restrict__ d0, int ld0, const float* __restrict__ d1, int ld1, const float* __restrict__ cat,
+                                                       const float* __restrict__ ru, const float* __restrict__ cnd, int X, int H, float* __restrict__ dzc,
+                                                       float* __restrict__ dzg, float* __restrict__ keep, int B) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * H; i += gridDim.x * blockDim.x) {
+        const int b = i / H, u = i - b * H;
+        float dh = d0[(size_t)b * ld0 + u];
+        if (d1) dh += d1[(size_t)b * ld1 + u];
+        const float uu = ru[(size_t)b * 2 * H + H + u], c = cnd[i], h = cat[(size_t)b * (X + H) + X + u];
+        dzc[i] = dh * (1.0f - uu) * (1.0f - c * c);
+        dzg[(size_t)b * 2 * H + H + u] = dh * (h - c) * uu * (1.0f - uu);
+        keep[i] = dh * uu;
+    }
+}
+// stage 2, after d [x | r h] = d zc . Wc^T: d r = d(r h) h -> d zr; keep += d(r h) r
+__global__ __launch_bounds__(256) void v1d_bwd2_kernel(const float* __restrict__ dcatr, const float* __restrict__ cat, const float* __restrict__ ru, int X, int H,
+                                                       float* __restrict__ dzg, float* __restrict__ keep, int B) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * H; i += gridDim.x * blockDim.x) {
+        const int b = i / H, u = i - b * H;
+        const float drh = dcatr[(size_t)b * (X + H) + X + u], r = ru[(size_t)b * 2 * H + u], h = cat[(size_t)b * (X + H) + X + u];
+        dzg[(size_t)b * 2 * H + u] = drh * h * r * (1.0f - r);
+        keep[i] += drh * r;
+    }
+}
+// stage 3, after d [x | h] = d zg . Wg^T: the state gradient handed to the step before, and d x (+ the residual's d y)
+__global__ __launch_bounds__(256) void v1d_bwd3_kernel(const float* __restrict__ dcatr, const float* __restrict__ dcat, const float* __restrict__ keep,
+                                                       const float* __restrict__ dres, int ldres, int X, int H, float* __restrict__ carry,
+                                                       float* __restrict__ dx, int lddx, int B) {
+    const int W = X + H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * W; i += gridDim.x * blockDim.x) {
+        const int b = i / W, c = i - b * W;
+        if (c < X) {
+            float g = dcatr[(size_t)b * W + c] + dcat[(size_t)b * W + c];
+            if (dres) g += dres[(size_t)b * ldres + c];
+            dx[(size_t)b * lddx + c] = g;
+        } else {
+            carry[(size_t)b * H + c - X] = keep[(size_t)b * H + c - X] + dcat[i];
+        }
+    }
+}
+// d ctx_t = (output projection's share) + (the share carried from step t + 1's attention GRU) -> the tape [B][S][E]
+__global__ __launch_bounds__(256) void v1d_dctx_kernel(const float* __restrict__ dcato, int A, int E, const float* __restrict__ carry, float* __restrict__ dctx_t,
+                                                       long long row_stride, int B) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * E; i += gridDim.x * blockDim.x) {
+        const int b = i / E, e = i - b * E;
+        dctx_t[(size_t)b * row_stride + e] = dcato[(size_t)b * (A + E) + A + e] + carry[i];
+    }
+}
+// mel [S][B][r*M] -> [B][S*r][M]
+__global__ __launch_bounds__(256) void v1d_sb_to_bt_kernel(const float* __restrict__ sb, float* __restrict__ bt, int B, int S, int rM) {
+    const long long n = (long long)S * B * rM;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % rM), b = (int)((i / rM) % B), t = (int)(i / ((long long)rM * B));
+        bt[((size_t)b * S + t) * rM + c] = sb[i];
+    }
+}
+// {mel_loss, done_loss, loss} from the two {sum, count, ratio} triples
+__global__ void v1d_loss_out_kernel(const float* __restrict__ l6, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = l6[2]; out[1] = l6[5]; out[2] = l6[2] + l6[5]; }
+}
+// d loss / d mel (masked L1, SUM_BY_NONZERO_WEIGHTS) in the [S][B][r*M] layout, and d loss / d stop logit (sigmoid cross entropy) [S][B]
+__global__ __launch_bounds__(256) void v1d_loss_grad_kernel(const float* __restrict__ mel_sb, const float* __restrict__ stop_sb, const float* __restrict__ target,
+                                                            const float* __restrict__ done, const float* __restrict__ m1, const float* __restrict__ m2,
+                                                            const float* __restrict__ n1, const float* __restrict__ n2, int B, int S, int r, int M,
+                                                            float* __restrict__ dmel_sb, float* __restrict__ dstop_sb) {
+    const int rM = r * M;
+    const float i1 = n1[0] > 0.f ? 1.0f / n1[0] : 0.f, i2 = n2[0] > 0.f ? 1.0f / n2[0] : 0.f;
+    const long long n = (long long)S * B * (rM + 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (rM + 1)), b = (int)((i / (rM + 1)) % B), t = (int)(i / ((long long)(rM + 1) * B));
+        if (c < rM) {
+            const int frame = t * r + c / M;
+            const float d = mel_sb[((size_t)t * B + b) * rM + c] - target[((size_t)b * S * r + frame) * M + c % M];
+            dmel_sb[((size_t)t * B + b) * rM + c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m1[(size_t)b * S * r + frame] * i1;
+        } else {
+            const float z = stop_sb[(size_t)t * B + b];
+            dstop_sb[(size_t)t * B + b] = (sigmoidf_(z) - done[(size_t)b * S + t]) * m2[(size_t)b * S + t] * i2;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void v1d_stop_to_bs_kernel(const float* __restrict__ stop_sb, float* __restrict__ stop_bs, int B, int S) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * S; i += gridDim.x * blockDim.x) {
+        const int t = i / B, b = i - t * B;
+        stop_bs[(size_t)b * S + t] = stop_sb[i];
+    }
+}
+
+struct t2v1_dtrainer {
+    t2v1_model* m = nullptr;
+    int B = 0, T = 0, S = 0;
+    t2_trainer ws;                       // workspace carrier of the shared helpers (split-K partials, column sums, offsets)
+    char* slab = nullptr;
+    bool have_forward = false;
+    const float* params = nullptr;
+    const float* glob_counts = nullptr;  // dev [2] or null
+    float drop_rate = 0.f;
+    int* lens = nullptr;
+    float *values, *keys, *target;
+    // tapes ([S] or [S + 1] slices of [B][.])
+    float *xin, *p0, *p1, *zgp, *zcp, *CATA, *CATAR, *RUa, *Ca, *Q, *ALIGN, *CATO, *CAT1, *CAT1R, *RU1, *C1, *CAT2, *CAT2R, *RU2, *C2, *Y2;
+    float *zg, *zc, *mel_sb, *stop_sb, *mel_bt, *stop_bs, *loss6;
+    // backward
+    float *dmel_sb, *dstop_sb, *DY2, *DZG2, *DZC2, *DZG1, *DZC1, *DY0, *DQ, *DZGa, *DZCa, *DCTX, *dkeys, *dvpart, *dvalues;
+    float *cHA, *cCTX, *cH1, *cH2, *keep, *dcatr, *dcat, *dy1, *dy0, *dcato, *dha, *dP1, *dP0;
+    float *WmT, *WsT, *Wg2T, *Wc2T, *Wg1T, *Wc1T, *WoT, *WqT, *WgaT, *WcaT, *WgpT, *WcpT, *Wp1T, *WmemT;
+};
+
+static const float* dt_w(t2v1_dtrainer* tr, const std::string& name, int* err) {
+    auto it = tr->ws.offsets.find(name);
+    if (it == tr->ws.offsets.end()) { *err = fail(T2_ESTATE, "no offset bound for '%s' (t2v1_decoder_trainer_bind)", name.c_str()); return nullptr; }
+    return tr->params + it->second;
+}
+static inline dim3 dt_grid(long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (n + 255) / 256))); }
+
+extern "C" int t2v1_decoder_trainer_destroy(t2v1_dtrainer* tr) {
+    if (!tr) return T2_OK;
+    (void)hipSetDevice(tr->m->base.ctx->device);
+    (void)hipStreamSynchronize(tr->m->base.ctx->stream);
+    if (tr->slab) (void)hipFree(tr->slab);
+    if (tr->ws.cs_part) (void)hipFree(tr->ws.cs_part);
+    if (tr->ws.wg_part) (void)hipFree(tr->ws.wg_part);
+    if (tr->ws.bn_part) (void)hipFree(tr->ws.bn_part);
+    delete tr;
+    return T2_OK;
+}
+
+extern "C" int t2v1_decoder_trainer_create(t2v1_model* m, int B, int T_in, int S, t2v1_dtrainer** out) {
+    T2_TRY(v1_ready(m));
+    if (!out || S < 1) return fail(T2_EINVAL, "bad argument");
+    T2_TRY(check_batch(B, T_in));
+    const t2v1_dims& d = m->d;
+    HIP_TRY(hipSetDevice(m->base.ctx->device));
+    t2v1_dtrainer* tr = new t2v1_dtrainer();
+    tr->m = m; tr->B = B; tr->T = T_in; tr->S = S;
+    tr->ws.m = &m->base;
+    const size_t P0 = d.dec_prenet_units[0], P1 = d.dec_prenet_units[1], A = d.attention_out_units, E = d.cbhg_out_units, D = d.decoder_out_units;
+    const size_t M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame, rM = r * M, SB = (size_t)S * B, BT = (size_t)B * T_in;
+    Carver cv;
+    std::vector<std::pair<float**, size_t>> plan;
+    auto want = [&](float** p, size_t floats) { plan.push_back({p, cv.take(floats * 4)}); };
+    want(&tr->values, BT * E); want(&tr->keys, BT * A); want(&tr->target, (size_t)B * S * rM);
+    want(&tr->xin, SB * nf * M); want(&tr->p0, SB * P0); want(&tr->p1, SB * P1); want(&tr->zgp, SB * 2 * A); want(&tr->zcp, SB * A);
+    want(&tr->CATA, (SB + B) * (E + A)); want(&tr->CATAR, SB * (E + A)); want(&tr->RUa, SB * 2 * A); want(&tr->Ca, SB * A); want(&tr->Q, SB * A);
+    want(&tr->ALIGN, SB * T_in); want(&tr->CATO, SB * (A + E));
+    want(&tr->CAT1, (SB + B) * 2 * D); want(&tr->CAT1R, SB * 2 * D); want(&tr->RU1, SB * 2 * D); want(&tr->C1, SB * D);
+    want(&tr->CAT2, (SB + B) * 2 * D); want(&tr->CAT2R, SB * 2 * D); want(&tr->RU2, SB * 2 * D); want(&tr->C2, SB * D); want(&tr->Y2, SB * D);
+    const size_t Hmax = std::max(A, D), Wmax = std::max(E + A, 2 * D);
+    want(&tr->zg, (size_t)B * 2 * Hmax); want(&tr->zc, (size_t)B * Hmax);
+    want(&tr->mel_sb, SB * rM); want(&tr->stop_sb, SB); want(&tr->mel_bt, SB * rM); want(&tr->stop_bs, SB); want(&tr->loss6, 8);
+    want(&tr->dmel_sb, SB * rM); want(&tr->dstop_sb, SB); want(&tr->DY2, SB * D); want(&tr->DZG2, SB * 2 * D); want(&tr->DZC2, SB * D);
+    want(&tr->DZG1, SB * 2 * D); want(&tr->DZC1, SB * D); want(&tr->DY0, SB * D); want(&tr->DQ, SB * A); want(&tr->DZGa, SB * 2 * A); want(&tr->DZCa, SB * A);
+    want(&tr->DCTX, SB * E); want(&tr->dkeys, BT * A); want(&tr->dvpart, (size_t)B * A); want(&tr->dvalues, BT * E);
+    want(&tr->cHA, (size_t)B * A); want(&tr->cCTX, (size_t)B * E); want(&tr->cH1, (size_t)B * D); want(&tr->cH2, (size_t)B * D);
+    want(&tr->keep, (size_t)B * Hmax); want(&tr->dcatr, (size_t)B * Wmax); want(&tr->dcat, (size_t)B * Wmax);
+    want(&tr->dy1, (size_t)B * D); want(&tr->dy0, (size_t)B * D); want(&tr->dcato, (size_t)B * (A + E)); want(&tr->dha, (size_t)B * A);
+    want(&tr->dP1, SB * P1); want(&tr->dP0, SB * P0);
+    want(&tr->WmT, rM * D); want(&tr->WsT, D); want(&tr->Wg2T, 2 * D * 2 * D); want(&tr->Wc2T, D * 2 * D); want(&tr->Wg1T, 2 * D * 2 * D); want(&tr->Wc1T, D * 2 * D);
+    want(&tr->WoT, D * (A + E)); want(&tr->WqT, A * A); want(&tr->WgaT, 2 * A * (E + A)); want(&tr->WcaT, A * (E + A)); want(&tr->WgpT, 2 * A * P1);
+    want(&tr->WcpT, A * P1); want(&tr->Wp1T, P1 * P0); want(&tr->WmemT, A * E);
+    const size_t o_lens = cv.take((size_t)B * 4);
+    hipError_t e = hipMalloc((void**)&tr->slab, cv.off);
+    if (e != hipSuccess) { delete tr; return fail(T2_ENOMEM, "hipMalloc(V1 decoder trainer, %zu bytes) failed: %s", cv.off, hipGetErrorString(e)); }
+    for (auto& pr : plan) *pr.first = (float*)(tr->slab + pr.second);
+    tr->lens = (int*)(tr->slab + o_lens);
+    *out = tr;
+    return T2_OK;
+}
+
+extern "C" int t2v1_decoder_trainer_bind(t2v1_dtrainer* tr, const char* name, int64_t offset) {
+    if (!tr || !name || offset < 0 || (offset & 3) != 0) return fail(T2_EINVAL, "bad argument (offsets are multiples of 4 floats)");
+    tr->ws.offsets[name] = offset;
+    return T2_OK;
+}
+// counts dev [2] = non-zero loss weights (spec x num_mels, stop) of a larger data-parallel batch, or null
+extern "C" int t2v1_decoder_trainer_set_loss_counts(t2v1_dtrainer* tr, const float* counts) {
+    if (!tr) return fail(T2_EINVAL, "null trainer");
+    tr->glob_counts = counts;
+    return T2_OK;
+}
+
+// y [B][N] (row stride ldy) = x [B][K] (row stride ldx) . w [K][N] (+ bias) (+ res): the small per-step products
+static int dt_gemm(t2v1_dtrainer* tr, const float* x, int ldx, int K, const float* w, int N, const float* bias, float* y, int ldy, const float* res, int ldr,
+                   int rows) {
+    ConvLayer L{};
+    L.w = const_cast<float*>(w); L.shift = const_cast<float*>(bias); L.k = 1; L.cin = K; L.cout = N;
+    return launch_conv(&tr->m->base, L, x, ldx, y, ldy, rows, rows, 0, res, ldr);
+}
+static void dt_transpose(t2v1_dtrainer* tr, const float* src, float* dst, int R, int C) {      // src [R][C] -> dst [C][R]
+    hipLaunchKernelGGL(transpose_kernel, dt_grid((long long)R * C), dim3(256), 0, tr->m->base.ctx->stream, dst, R, src, C, C, R);
+}
+
+// memory dev [B][T_in][E]; lens host [B] or null; target dev [B][S*r][M] (labels.mel); mel_out dev [B][S*r][M], stop_out dev [B][S],
+// align_out dev [S][B][T_in] (alignment_history.stack())
+extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_params, const float* memory, const int64_t* lens, const float* target,
+                                          float drop_rate, uint32_t seed, float* mel_out, float* stop_out, float* align_out) {
+    if (!tr || !flat_params || !memory || !target || !mel_out || !stop_out || !align_out) return fail(T2_EINVAL, "null argument");
+    if (!(drop_rate >= 0.f && drop_rate < 1.f)) return fail(T2_EINVAL, "drop_rate %g outside [0, 1)", (double)drop_rate);
+    t2v1_model* m = tr->m;
+    t2_model* b = &m->base;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    const t2v1_dims& d = m->d;
+    const int B = tr->B, T = tr->T, S = tr->S, P0 = d.dec_prenet_units[0], P1 = d.dec_prenet_units[1], A = d.attention_out_units, E = d.cbhg_out_units,
+              D = d.decoder_out_units, M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame, rM = r * M, SB = S * B;
+    tr->params = flat_params; tr->have_forward = false; tr->drop_rate = drop_rate;
+    T2_TRY(v1_lens_to_dev(m, lens, B, T, 1, tr->lens));
+    int err = T2_OK;
+    auto W = [&](const std::string& n) { return dt_w(tr, n, &err); };
+    const std::string pd = "v1/decoder/";
+    const float *Wp0 = W(pd + "prenet_0/dense/kernel"), *bp0 = W(pd + "prenet_0/dense/bias"), *Wp1 = W(pd + "prenet_1/dense/kernel"), *bp1 = W(pd + "prenet_1/dense/bias");
+    const float *Wga = W(pd + "attention_gru/gates/kernel"), *bga = W(pd + "attention_gru/gates/bias"), *Wca = W(pd + "attention_gru/candidate/kernel"),
+                *bca = W(pd + "attention_gru/candidate/bias");
+    const float *Wmem = W("v1/attention/memory_layer/kernel"), *Wq = W("v1/attention/query_layer/kernel"), *va = W("v1/attention/attention_v");
+    const float *Wo = W(pd + "output_projection/kernel"), *bo = W(pd + "output_projection/bias");
+    const float *Wg1 = W(pd + "gru_1/gates/kernel"), *bg1 = W(pd + "gru_1/gates/bias"), *Wc1 = W(pd + "gru_1/candidate/kernel"), *bc1 = W(pd + "gru_1/candidate/bias");
+    const float *Wg2 = W(pd + "gru_2/gates/kernel"), *bg2 = W(pd + "gru_2/gates/bias"), *Wc2 = W(pd + "gru_2/candidate/kernel"), *bc2 = W(pd + "gru_2/candidate/bias");
+    const float *Wm = W(pd + "out_projection/kernel"), *bm = W(pd + "out_projection/bias"), *Wst = W(pd + "stop_token_projection/kernel"),
+                *bst = W(pd + "stop_token_projection/bias");
+    if (err != T2_OK) return err;
+    // attention memory: values = memory * mask, keys = values . W_mem (BahdanauAttention constructor)
+    hipLaunchKernelGGL(mask_memory_kernel, dt_grid((long long)B * T * E), dim3(256), 0, st, memory, tr->lens, tr->values, B, T, E);
+    T2_TRY(dt_gemm(tr, tr->values, E, E, Wmem, A, nullptr, tr->keys, A, nullptr, 0, B * T));
+    HIP_TRY(hipMemcpyAsync(tr->target, target, (size_t)B * S * rM * 4, hipMemcpyDeviceToDevice, st));
+    // PreNets of all steps, and their share of the attention GRU's pre-activations
+    hipLaunchKernelGGL(v1d_feed_kernel, dt_grid((long long)SB * nf * M), dim3(256), 0, st, tr->target, tr->xin, B, S, r, nf, M);
+    {
+        ConvLayer L{};
+        L.w = const_cast<float*>(Wp0); L.shift = const_cast<float*>(bp0); L.k = 1; L.cin = nf * M; L.cout = P0;
+        T2_TRY(launch_conv(b, L, tr->xin, nf * M, tr->p0, P0, SB, SB, 1, nullptr, 0));
+        if (drop_rate > 0.f) hipLaunchKernelGGL(v1d_dropout_kernel, dt_grid((long long)SB * P0), dim3(256), 0, st, tr->p0, drop_rate, seed, T2_STREAM_V1_DEC_PRENET, B, (long long)SB, P0);
+        L.w = const_cast<float*>(Wp1); L.shift = const_cast<float*>(bp1); L.cin = P0; L.cout = P1;
+        T2_TRY(launch_conv(b, L, tr->p0, P0, tr->p1, P1, SB, SB, 1, nullptr, 0));
+        if (drop_rate > 0.f) hipLaunchKernelGGL(v1d_dropout_kernel, dt_grid((long long)SB * P1), dim3(256), 0, st, tr->p1, drop_rate, seed, T2_STREAM_V1_DEC_PRENET + 1, B, (long long)SB, P1);
+    }
+    T2_TRY(dt_gemm(tr, tr->p1, P1, P1, Wga, 2 * A, bga, tr->zgp, 2 * A, nullptr, 0, SB));
+    T2_TRY(dt_gemm(tr, tr->p1, P1, P1, Wca, A, bca, tr->zcp, A, nullptr, 0, SB));
+    // zero states: [ctx | h_att] of step 0, the h halves of [y | h] of step 0
+    HIP_TRY(hipMemsetAsync(tr->CATA, 0, (size_t)B * (E + A) * 4, st));
+    HIP_TRY(hipMemsetAsync(tr->CAT1, 0, (size_t)B * 2 * D * 4, st));
+    HIP_TRY(hipMemsetAsync(tr->CAT2, 0, (size_t)B * 2 * D * 4, st));
+    const int XA = E + A;
+    const size_t attn_lds = (size_t)(2 * A + T) * 4;
+    for (int t = 0; t < S; ++t) {
+        float *cata = tr->CATA + (size_t)t * B * XA, *cata_n = cata + (size_t)B * XA, *catar = tr->CATAR + (size_t)t * B * XA;
+        float *cato = tr->CATO + (size_t)t * B * (A + E);
+        float *cat1 = tr->CAT1 + (size_t)t * B * 2 * D, *cat1_n = cat1 + (size_t)B * 2 * D, *cat1r = tr->CAT1R + (size_t)t * B * 2 * D;
+        float *cat2 = tr->CAT2 + (size_t)t * B * 2 * D, *cat2_n = cat2 + (size_t)B * 2 * D, *cat2r = tr->CAT2R + (size_t)t * B * 2 * D;
+        // attention GRU on [p1_t | ctx_{t-1}] (AttentionWrapper, App. A6): the p1 rows of the kernels were applied above
+        T2_TRY(dt_gemm(tr, cata, XA, XA, Wga + (size_t)P1 * 2 * A, 2 * A, nullptr, tr->zg, 2 * A, tr->zgp + (size_t)t * B * 2 * A, 2 * A, B));
+        hipLaunchKernelGGL(v1d_gate_kernel, dt_grid((long long)B * (XA + A)), dim3(256), 0, st, tr->zg, cata, E, A, tr->RUa + (size_t)t * B * 2 * A, catar, B);
+        T2_TRY(dt_gemm(tr, catar, XA, XA, Wca + (size_t)P1 * A, A, nullptr, tr->zc, A, tr->zcp + (size_t)t * B * A, A, B));
+        hipLaunchKernelGGL(v1d_blend_kernel, dt_grid((long long)B * A), dim3(256), 0, st, tr->zc, tr->RUa + (size_t)t * B * 2 * A, cata, E, A, tr->Ca + (size_t)t * B * A,
+                           V1Dst{cato, A + E}, V1Dst{cata_n + E, XA}, V1Dst{nullptr, 0}, V1Dst{nullptr, 0}, B);
+        // Bahdanau attention
+        float* q = tr->Q + (size_t)t * B * A;
+        T2_TRY(dt_gemm(tr, cato, A + E, A, Wq, A, nullptr, q, A, nullptr, 0, B));
+        hipLaunchKernelGGL(v1d_attn_fwd_kernel, dim3(B), dim3(256), attn_lds, st, tr->keys, tr->values, q, va, tr->lens, T, A, E, tr->ALIGN + (size_t)t * B * T,
+                           V1Dst{cato + A, A + E}, V1Dst{cata_n, XA});
+        // OutputProjectionWrapper on [h_att | ctx] -> y0 = the x half of GRU 1's operand
+        T2_TRY(dt_gemm(tr, cato, A + E, A + E, Wo, D, bo, cat1, 2 * D, nullptr, 0, B));
+        // ResidualWrapper(GRUCell) x 2
+        T2_TRY(dt_gemm(tr, cat1, 2 * D, 2 * D, Wg1, 2 * D, bg1, tr->zg, 2 * D, nullptr, 0, B));
+        hipLaunchKernelGGL(v1d_gate_kernel, dt_grid((long long)B * 3 * D), dim3(256), 0, st, tr->zg, cat1, D, D, tr->RU1 + (size_t)t * B * 2 * D, cat1r, B);
+        T2_TRY(dt_gemm(tr, cat1r, 2 * D, 2 * D, Wc1, D, bc1, tr->zc, D, nullptr, 0, B));
+        hipLaunchKernelGGL(v1d_blend_kernel, dt_grid((long long)B * D), dim3(256), 0, st, tr->zc, tr->RU1 + (size_t)t * B * 2 * D, cat1, D, D, tr->C1 + (size_t)t * B * D,
+                           V1Dst{cat1_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{cat2, 2 * D}, V1Dst{nullptr, 0}, B);
+        T2_TRY(dt_gemm(tr, cat2, 2 * D, 2 * D, Wg2, 2 * D, bg2, tr->zg, 2 * D, nullptr, 0, B));
+        hipLaunchKernelGGL(v1d_gate_kernel, dt_grid((long long)B * 3 * D), dim3(256), 0, st, tr->zg, cat2, D, D, tr->RU2 + (size_t)t * B * 2 * D, cat2r, B);
+        T2_TRY(dt_gemm(tr, cat2r, 2 * D, 2 * D, Wc2, D, bc2, tr->zc, D, nullptr, 0, B));
+        hipLaunchKernelGGL(v1d_blend_kernel, dt_grid((long long)B * D), dim3(256), 0, st, tr->zc, tr->RU2 + (size_t)t * B * 2 * D, cat2, D, D, tr->C2 + (size_t)t * B * D,
+                           V1Dst{cat2_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{tr->Y2 + (size_t)t * B * D, D}, V1Dst{nullptr, 0}, B);
+    }
+    // mel / stop projections of all steps (OutputAndStopTokenWrapper, rnn_wrappers.py:105-109)
+    T2_TRY(dt_gemm(tr, tr->Y2, D, D, Wm, rM, bm, tr->mel_sb, rM, nullptr, 0, SB));
+    T2_TRY(dt_gemm(tr, tr->Y2, D, D, Wst, 1, bst, tr->stop_sb, 1, nullptr, 0, SB));
+    hipLaunchKernelGGL(v1d_sb_to_bt_kernel, dt_grid((long long)SB * rM), dim3(256), 0, st, tr->mel_sb, tr->mel_bt, B, S, rM);
+    hipLaunchKernelGGL(v1d_stop_to_bs_kernel, dt_grid((long long)SB), dim3(256), 0, st, tr->stop_sb, tr->stop_bs, B, S);
+    HIP_TRY(hipMemcpyAsync(mel_out, tr->mel_bt, (size_t)SB * rM * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(stop_out, tr->stop_bs, (size_t)SB * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(align_out, tr->ALIGN, (size_t)SB * T * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    tr->have_forward = true;
+    return T2_OK;
+}
+
+// one GRU cell backward (three elementwise stages around two GEMMs); dz tapes written for the weight gradients
+static int dt_gru_bwd(t2v1_dtrainer* tr, const float* d0, int ld0, const float* d1, int ld1, const float* cat, const float* ru, const float* cnd, int X, int H,
+                      const float* WcT, const float* WgT, float* dzc, float* dzg, const float* dres, int ldres, float* carry, float* dx, int lddx) {
+    hipStream_t st = tr->m->base.ctx->stream;
+    const int B = tr->B, Wd = X + H;
+    hipLaunchKernelGGL(v1d_bwd1_kernel, dt_grid((long long)B * H), dim3(256), 0, st, d0, ld0, d1, ld1, cat, ru, cnd, X, H, dzc, dzg, tr->keep, B);
+    T2_TRY(dt_gemm(tr, dzc, H, H, WcT, Wd, nullptr, tr->dcatr, Wd, nullptr, 0, B));
+    hipLaunchKernelGGL(v1d_bwd2_kernel, dt_grid((long long)B * H), dim3(256), 0, st, tr->dcatr, cat, ru, X, H, dzg, tr->keep, B);
+    T2_TRY(dt_gemm(tr, dzg, 2 * H, 2 * H, WgT, Wd, nullptr, tr->dcat, Wd, nullptr, 0, B));
+    hipLaunchKernelGGL(v1d_bwd3_kernel, dt_grid((long long)B * Wd), dim3(256), 0, st, tr->dcatr, tr->dcat, tr->keep, dres, ldres, X, H, carry, dx, lddx, B);
+    return T2_OK;
+}
+
+// done dev [B][S], spec_mask dev [B][S*r], bin_mask dev [B][S].  Writes every v1/decoder/ and v1/attention/ gradient into flat_grads,
+// d loss / d memory into dmemory (dev [B][T_in][E]) and {mel_loss, done_loss, loss} into loss_out (dev [3]).
+extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done, const float* spec_mask, const float* bin_mask, float* flat_grads,
+                                           float* dmemory, float* loss_out) {
+    if (!tr || !done || !spec_mask || !bin_mask || !flat_grads || !dmemory || !loss_out) return fail(T2_EINVAL, "null argument");
+    if (!tr->have_forward) return fail(T2_ESTATE, "t2v1_train_decoder_forward has not run");
+    t2v1_model* m = tr->m;
+    t2_model* b = &m->base;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    const t2v1_dims& d = m->d;
+    const int B = tr->B, T = tr->T, S = tr->S, P0 = d.dec_prenet_units[0], P1 = d.dec_prenet_units[1], A = d.attention_out_units, E = d.cbhg_out_units,
+              D = d.decoder_out_units, M = d.num_mels, r = d.outputs_per_step, nf = d.n_feed_frame, rM = r * M, SB = S * B, XA = E + A;
+    int err = T2_OK;
+    auto W = [&](const std::string& n) { return dt_w(tr, n, &err); };
+    auto G = [&](const std::string& n) -> float* {
+        auto it = tr->ws.offsets.find(n);
+        if (it == tr->ws.offsets.end()) { err = fail(T2_ESTATE, "no offset bound for '%s'", n.c_str()); return nullptr; }
+        return flat_grads + it->second;
+    };
+    const std::string pd = "v1/decoder/";
+    const float *Wp1 = W(pd + "prenet_1/dense/kernel");
+    const float *Wga = W(pd + "attention_gru/gates/kernel"), *Wca = W(pd + "attention_gru/candidate/kernel");
+    const float *Wmem = W("v1/attention/memory_layer/kernel"), *Wq = W("v1/attention/query_layer/kernel"), *va = W("v1/attention/attention_v");
+    const float *Wo = W(pd + "output_projection/kernel"), *Wg1 = W(pd + "gru_1/gates/kernel"), *Wc1 = W(pd + "gru_1/candidate/kernel");
+    const float *Wg2 = W(pd + "gru_2/gates/kernel"), *Wc2 = W(pd + "gru_2/candidate/kernel");
+    const float *Wm = W(pd + "out_projection/kernel"), *Wst = W(pd + "stop_token_projection/kernel");
+    if (err != T2_OK) return err;
+    // losses (models.py:58-61) and their gradients
+    T2_TRY(t2_spec_loss(b->ctx, tr->mel_bt, tr->target, spec_mask, B, S * r, M, tr->loss6));
+    T2_TRY(t2_binary_loss(b->ctx, tr->stop_bs, done, bin_mask, B, S, tr->loss6 + 3));
+    const float *n1 = tr->glob_counts ? tr->glob_counts : tr->loss6 + 1, *n2 = tr->glob_counts ? tr->glob_counts + 1 : tr->loss6 + 4;
+    hipLaunchKernelGGL(v1d_loss_grad_kernel, dt_grid((long long)SB * (rM + 1)), dim3(256), 0, st, tr->mel_sb, tr->stop_sb, tr->target, done, spec_mask, bin_mask, n1, n2,
+                       B, S, r, M, tr->dmel_sb, tr->dstop_sb);
+    hipLaunchKernelGGL(v1d_loss_out_kernel, dim3(1), dim3(64), 0, st, tr->loss6, loss_out);
+    // transposed operands of the data-gradient products
+    dt_transpose(tr, Wm, tr->WmT, D, rM); dt_transpose(tr, Wst, tr->WsT, D, 1);
+    dt_transpose(tr, Wg2, tr->Wg2T, 2 * D, 2 * D); dt_transpose(tr, Wc2, tr->Wc2T, 2 * D, D);
+    dt_transpose(tr, Wg1, tr->Wg1T, 2 * D, 2 * D); dt_transpose(tr, Wc1, tr->Wc1T, 2 * D, D);
+    dt_transpose(tr, Wo, tr->WoT, A + E, D); dt_transpose(tr, Wq, tr->WqT, A, A);
+    dt_transpose(tr, Wga + (size_t)P1 * 2 * A, tr->WgaT, XA, 2 * A); dt_transpose(tr, Wca + (size_t)P1 * A, tr->WcaT, XA, A);
+    dt_transpose(tr, Wga, tr->WgpT, P1, 2 * A); dt_transpose(tr, Wca, tr->WcpT, P1, A);
+    dt_transpose(tr, Wp1, tr->Wp1T, P0, P1); dt_transpose(tr, Wmem, tr->WmemT, E, A);
+    // d y2 of all steps: the projections do not depend on the recurrence
+    T2_TRY(dt_gemm(tr, tr->dmel_sb, rM, rM, tr->WmT, D, nullptr, tr->DY2, D, nullptr, 0, SB));
+    T2_TRY(dt_gemm(tr, tr->dstop_sb, 1, 1, tr->WsT, D, nullptr, tr->DY2, D, tr->DY2, D, SB));
+    HIP_TRY(hipMemsetAsync(tr->cHA, 0, (size_t)B * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->cCTX, 0, (size_t)B * E * 4, st));
+    HIP_TRY(hipMemsetAsync(tr->cH1, 0, (size_t)B * D * 4, st)); HIP_TRY(hipMemsetAsync(tr->cH2, 0, (size_t)B * D * 4, st));
+    HIP_TRY(hipMemsetAsync(tr->dkeys, 0, (size_t)B * T * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->dvpart, 0, (size_t)B * A * 4, st));
+    const size_t attn_lds = (size_t)(E + T) * 4;
+    for (int t = S - 1; t >= 0; --t) {
+        const float *cata = tr->CATA + (size_t)t * B * XA, *cato = tr->CATO + (size_t)t * B * (A + E);
+        const float *cat1 = tr->CAT1 + (size_t)t * B * 2 * D, *cat2 = tr->CAT2 + (size_t)t * B * 2 * D;
+        const float* dy2 = tr->DY2 + (size_t)t * B * D;
+        // y2 = y1 + h2': d h2' = d y2 + carry; d y1 = d y2 + d x
+        T2_TRY(dt_gru_bwd(tr, dy2, D, tr->cH2, D, cat2, tr->RU2 + (size_t)t * B * 2 * D, tr->C2 + (size_t)t * B * D, D, D, tr->Wc2T, tr->Wg2T,
+                          tr->DZC2 + (size_t)t * B * D, tr->DZG2 + (size_t)t * B * 2 * D, dy2, D, tr->cH2, tr->dy1, D));
+        float* dy0 = tr->DY0 + (size_t)t * B * D;
+        T2_TRY(dt_gru_bwd(tr, tr->dy1, D, tr->cH1, D, cat1, tr->RU1 + (size_t)t * B * 2 * D, tr->C1 + (size_t)t * B * D, D, D, tr->Wc1T, tr->Wg1T,
+                          tr->DZC1 + (size_t)t * B * D, tr->DZG1 + (size_t)t * B * 2 * D, tr->dy1, D, tr->cH1, dy0, D));
+        // output projection: d [h_att | ctx]
+        T2_TRY(dt_gemm(tr, dy0, D, D, tr->WoT, A + E, nullptr, tr->dcato, A + E, nullptr, 0, B));
+        float* dctx_t = tr->DCTX + (size_t)t * E;                       // tape [B][S][E]
+        hipLaunchKernelGGL(v1d_dctx_kernel, dt_grid((long long)B * E), dim3(256), 0, st, tr->dcato, A, E, tr->cCTX, dctx_t, (long long)S * E, B);
+        float* dq = tr->DQ + (size_t)t * B * A;
+        hipLaunchKernelGGL(v1d_attn_bwd_kernel, dim3(B), dim3(256), attn_lds, st, tr->keys, tr->values, tr->Q + (size_t)t * B * A, va, tr->lens,
+                           tr->ALIGN + (size_t)t * B * T, dctx_t, (long long)S * E, T, A, E, dq, tr->dkeys, tr->dvpart);
+        // d h_att = output projection's share + d q . Wq^T (+ the carry, added in stage 1)
+        T2_TRY(dt_gemm(tr, dq, A, A, tr->WqT, A, nullptr, tr->dha, A, tr->dcato, A + E, B));
+        // attention GRU on [p1 | ctx_{t-1}]: d ctx_{t-1} -> carry; the p1 share is batched after the loop
+        T2_TRY(dt_gru_bwd(tr, tr->dha, A, tr->cHA, A, cata, tr->RUa + (size_t)t * B * 2 * A, tr->Ca + (size_t)t * B * A, E, A, tr->WcaT, tr->WgaT,
+                          tr->DZCa + (size_t)t * B * A, tr->DZGa + (size_t)t * B * 2 * A, nullptr, 0, tr->cHA, tr->cCTX, E));
+    }
+    HIP_TRY(hipGetLastError());
+    // ---- weight gradients: tape-wide GEMMs ----
+    float *gWm = G(pd + "out_projection/kernel"), *gbm = G(pd + "out_projection/bias"), *gWs = G(pd + "stop_token_projection/kernel"), *gbs = G(pd + "stop_token_projection/bias");
+    float *gWg2 = G(pd + "gru_2/gates/kernel"), *gbg2 = G(pd + "gru_2/gates/bias"), *gWc2 = G(pd + "gru_2/candidate/kernel"), *gbc2 = G(pd + "gru_2/candidate/bias");
+    float *gWg1 = G(pd + "gru_1/gates/kernel"), *gbg1 = G(pd + "gru_1/gates/bias"), *gWc1 = G(pd + "gru_1/candidate/kernel"), *gbc1 = G(pd + "gru_1/candidate/bias");
+    float *gWo = G(pd + "output_projection/kernel"), *gbo = G(pd + "output_projection/bias");
+    float *gWq = G("v1/attention/query_layer/kernel"), *gva = G("v1/attention/attention_v"), *gWmem = G("v1/attention/memory_layer/kernel");
+    float *gWga = G(pd + "attention_gru/gates/kernel"), *gbga = G(pd + "attention_gru/gates/bias"), *gWca = G(pd + "attention_gru/candidate/kernel"),
+          *gbca = G(pd + "attention_gru/candidate/bias");
+    float *gWp1 = G(pd + "prenet_1/dense/kernel"), *gbp1 = G(pd + "prenet_1/dense/bias"), *gWp0 = G(pd + "prenet_0/dense/kernel"), *gbp0 = G(pd + "prenet_0/dense/bias");
+    if (err != T2_OK) return err;
+    t2_trainer* ws = &tr->ws;
+    T2_TRY(bwd_wgrad(ws, tr->Y2, D, D, tr->dmel_sb, rM, rM, SB, gWm, rM)); T2_TRY(col_sum(ws, tr->dmel_sb, SB, rM, gbm));
+    T2_TRY(bwd_wgrad(ws, tr->Y2, D, D, tr->dstop_sb, 1, 1, SB, gWs, 1)); T2_TRY(col_sum(ws, tr->dstop_sb, SB, 1, gbs));
+    T2_TRY(bwd_wgrad(ws, tr->CAT2, 2 * D, 2 * D, tr->DZG2, 2 * D, 2 * D, SB, gWg2, 2 * D)); T2_TRY(col_sum(ws, tr->DZG2, SB, 2 * D, gbg2));
+    T2_TRY(bwd_wgrad(ws, tr->CAT2R, 2 * D, 2 * D, tr->DZC2, D, D, SB, gWc2, D)); T2_TRY(col_sum(ws, tr->DZC2, SB, D, gbc2));
+    T2_TRY(bwd_wgrad(ws, tr->CAT1, 2 * D, 2 * D, tr->DZG1, 2 * D, 2 * D, SB, gWg1, 2 * D)); T2_TRY(col_sum(ws, tr->DZG1, SB, 2 * D, gbg1));
+    T2_TRY(bwd_wgrad(ws, tr->CAT1R, 2 * D, 2 * D, tr->DZC1, D, D, SB, gWc1, D)); T2_TRY(col_sum(ws, tr->DZC1, SB, D, gbc1));
+    T2_TRY(bwd_wgrad(ws, tr->CATO, A + E, A + E, tr->DY0, D, D, SB, gWo, D)); T2_TRY(col_sum(ws, tr->DY0, SB, D, gbo));
+    T2_TRY(bwd_wgrad(ws, tr->CATO, A + E, A, tr->DQ, A, A, SB, gWq, A));
+    T2_TRY(col_sum(ws, tr->dvpart, B, A, gva));
+    T2_TRY(bwd_wgrad(ws, tr->p1, P1, P1, tr->DZGa, 2 * A, 2 * A, SB, gWga, 2 * A));
+    T2_TRY(bwd_wgrad(ws, tr->CATA, XA, XA, tr->DZGa, 2 * A, 2 * A, SB, gWga + (size_t)P1 * 2 * A, 2 * A)); T2_TRY(col_sum(ws, tr->DZGa, SB, 2 * A, gbga));
+    T2_TRY(bwd_wgrad(ws, tr->p1, P1, P1, tr->DZCa, A, A, SB, gWca, A));
+    T2_TRY(bwd_wgrad(ws, tr->CATAR, XA, XA, tr->DZCa, A, A, SB, gWca + (size_t)P1 * A, A)); T2_TRY(col_sum(ws, tr->DZCa, SB, A, gbca));
+    // PreNets, all steps at once (dropout and relu masks from the taped outputs)
+    const float inv_keep = 1.0f / (1.0f - tr->drop_rate);
+    T2_TRY(dt_gemm(tr, tr->DZGa, 2 * A, 2 * A, tr->WgpT, P1, nullptr, tr->dP1, P1, nullptr, 0, SB));
+    T2_TRY(dt_gemm(tr, tr->DZCa, A, A, tr->WcpT, P1, nullptr, tr->dP1, P1, tr->dP1, P1, SB));
+    hipLaunchKernelGGL(v1_relu_dropout_bwd_kernel, dt_grid((long long)SB * P1), dim3(256), 0, st, tr->dP1, tr->p1, inv_keep, tr->dP1, (long long)SB * P1);
+    T2_TRY(bwd_wgrad(ws, tr->p0, P0, P0, tr->dP1, P1, P1, SB, gWp1, P1)); T2_TRY(col_sum(ws, tr->dP1, SB, P1, gbp1));
+    T2_TRY(dt_gemm(tr, tr->dP1, P1, P1, tr->Wp1T, P0, nullptr, tr->dP0, P0, nullptr, 0, SB));
+    hipLaunchKernelGGL(v1_relu_dropout_bwd_kernel, dt_grid((long long)SB * P0), dim3(256), 0, st, tr->dP0, tr->p0, inv_keep, tr->dP0, (long long)SB * P0);
+    T2_TRY(bwd_wgrad(ws, tr->xin, nf * M, nf * M, tr->dP0, P0, P0, SB, gWp0, P0)); T2_TRY(col_sum(ws, tr->dP0, SB, P0, gbp0));
+    // attention memory: d values = sum_t a_t (x) d ctx_t + d keys . W_mem^T; d W_mem = values^T . d keys; d memory = d values * mask
+    hipLaunchKernelGGL(dvalues_kernel, dim3(ceil_div(T, 16), B, ceil_div(E, 512)), dim3(512), 0, st, tr->ALIGN, tr->DCTX, B, T, S, E, tr->dvalues);
+    T2_TRY(bwd_wgrad(ws, tr->values, E, E, tr->dkeys, A, A, (long long)B * T, gWmem, A));
+    T2_TRY(dt_gemm(tr, tr->dkeys, A, A, tr->WmemT, E, nullptr, dmemory, E, tr->dvalues, E, B * T));
+    hipLaunchKernelGGL(mask_rows_kernel, dt_grid((long long)B * T * E), dim3(256), 0, st, dmemory, tr->lens, B, T, E);
+    HIP_TRY(hipGetLastError());
+    tr->have_forward = false;
+    return T2_OK;
+}

@@ -369,6 +369,70 @@ class EncoderV1Trainer(PostNetTrainer):
         return demb
 
 
+class DecoderV1Trainer:
+    """DecoderV1.call(is_training=True) with a tape and its backward pass (include/t2mi.h, t2v1_train_decoder_*): the decoder
+    half of SingleSpeakerTacotronV1Model's training step, over the ``v1/decoder/`` and ``v1/attention/`` variables of one flat
+    fp32 device buffer.  One trainer per (B, T_in, S)."""
+
+    def __init__(self, engine: EngineV1, B: int, T_in: int, S: int, spec):
+        self.engine, self.B, self.T_in, self.S, self.spec = engine, int(B), int(T_in), int(S), spec
+        self._h = C.c_void_p()
+        _lib.check(engine.lib.t2v1_decoder_trainer_create(engine._model, self.B, self.T_in, self.S, C.byref(self._h)))
+        for name, shape, off, size in spec:
+            _lib.check(engine.lib.t2v1_decoder_trainer_bind(self._h, name.encode(), int(off)))
+
+    @staticmethod
+    def decoder_weights(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+        return {k: v for k, v in weights.items() if k.startswith(("v1/decoder/", "v1/attention/"))}
+
+    def _flat(self, t, what):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                and t.numel() == training.flat_size(self.spec)):
+            raise ValueError(f"{what} must be a contiguous fp32 device tensor of {training.flat_size(self.spec)} elements")
+        return t
+
+    def forward(self, flat_params, memory, lens, target, drop_rate: float = 0.5, seed: int = 0):
+        """-> (mel [B, S*r, M], stop [B, S, 1], alignments [S, B, T_in])."""
+        eng, d = self.engine, self.engine.dims
+        memory, target, lens = eng._f32(memory), eng._f32(target), _i64(lens)
+        if tuple(memory.shape) != (self.B, self.T_in, d.cbhg_out_units) or tuple(target.shape) != (self.B, self.S * d.outputs_per_step, d.num_mels):
+            raise ValueError("memory / target do not match the trainer's (B, T_in, S)")
+        self._params = self._flat(flat_params, "flat_params")
+        mel, stop, align = torch.empty_like(target), eng._out(self.B, self.S), eng._out(self.S, self.B, self.T_in)
+        with eng.context.ordered():
+            _lib.check(eng.lib.t2v1_train_decoder_forward(self._h, flat_params.data_ptr(), memory.data_ptr(), _hp(lens), target.data_ptr(), float(drop_rate),
+                                                          int(seed) & 0xFFFFFFFF, mel.data_ptr(), stop.data_ptr(), align.data_ptr()))
+        return mel, stop.unsqueeze(-1), align
+
+    def set_loss_counts(self, counts: Optional[torch.Tensor]):
+        self._counts = None if counts is None else self.engine._f32(counts)
+        _lib.check(self.engine.lib.t2v1_decoder_trainer_set_loss_counts(self._h, None if self._counts is None else self._counts.data_ptr()))
+
+    def backward(self, done, spec_loss_mask, binary_loss_mask, flat_grads):
+        """-> (dmemory [B, T_in, E], losses dev [3] = mel, done, total)."""
+        eng, d = self.engine, self.engine.dims
+        done, m1, m2 = eng._f32(done), eng._f32(spec_loss_mask), eng._f32(binary_loss_mask)
+        if tuple(done.shape) != (self.B, self.S) or tuple(m2.shape) != (self.B, self.S) or tuple(m1.shape) != (self.B, self.S * d.outputs_per_step):
+            raise ValueError("label shapes do not match the trainer's (B, S)")
+        self._flat(flat_grads, "flat_grads")
+        dmem, losses = eng._out(self.B, self.T_in, d.cbhg_out_units), eng._out(3)
+        with eng.context.ordered():
+            _lib.check(eng.lib.t2v1_train_decoder_backward(self._h, done.data_ptr(), m1.data_ptr(), m2.data_ptr(), flat_grads.data_ptr(),
+                                                           dmem.data_ptr(), losses.data_ptr()))
+        return dmem, losses
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.engine, "_model", None):
+            self.engine.lib.t2v1_decoder_trainer_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PostNet:
     """tacotron_v1.py:156-186: CBHG on the mel spectrogram, then Dense(num_freq).  ``is_training=True`` (batch-statistics batch
     norm, modules.py:149-157) needs the flat parameter buffer the training step owns: ``flat_params`` / ``spec`` (see

@@ -379,3 +379,65 @@ def test_encoder_v1_block_in_training_mode_and_export():
         eng.set_option("gruseq", 0)                                          # the launch-per-step GRU operands were not rebuilt
     eng2.close()
     eng.close()
+
+
+# ---- DecoderV1 training step ----
+def _dec_case(d, B, T, S, seed):
+    rng = np.random.default_rng(seed)
+    r = d.outputs_per_step
+    mem = (rng.standard_normal((B, T, d.cbhg_out_units)) * 0.5).astype(np.float32)
+    lens = rng.integers(max(1, T // 2), T + 1, size=B).astype(np.int64)
+    lens[0] = T
+    tl = rng.integers(max(1, S * r // 2), S * r + 1, size=B)
+    tl[0] = S * r
+    sl = (tl + r - 1) // r
+    labels = {"mel": rng.uniform(0, 1, (B, S * r, d.num_mels)).astype(np.float32),
+              "done": (np.arange(S)[None, :] >= (sl[:, None] - 1)).astype(np.float32),
+              "spec_loss_mask": (np.arange(S * r)[None, :] < tl[:, None]).astype(np.float32),
+              "binary_loss_mask": (np.arange(S)[None, :] < sl[:, None]).astype(np.float32)}
+    return mem, lens, labels
+
+
+@pytest.mark.parametrize("name,B,T,S,drop", [("tiny", 3, 7, 5, 0.5), ("mid", 5, 19, 6, 0.5), ("ref", 4, 23, 5, 0.5), ("ref", 33, 12, 4, 0.0)])
+def test_decoder_v1_training_forward_and_every_gradient_against_autograd(name, B, T, S, drop):
+    """Teacher-forced training forward of DecoderV1 (PreNet dropout from the shared counter-based generator) and the BPTT of
+    spec_loss + binary_loss: mel, stop, alignments, losses, every v1/decoder/ and v1/attention/ gradient and d loss / d memory
+    against fp64 autograd (no kinks apart from the PreNets' relu, whose inputs are targets through one or two layers)."""
+    import torch
+    from tests.test_gpu_v1 import DIMS
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import DecoderV1Trainer, EngineV1
+    d = DIMS[name]
+    w = init_weights_v1(d, 9, perturb=True)
+    eng = EngineV1(d, w)
+    dw = DecoderV1Trainer.decoder_weights(w)
+    spec = TR.flatten_spec(dw)
+    flat = torch.tensor(TR.flatten(dw, spec), device="cuda")
+    mem, lens, labels = _dec_case(d, B, T, S, 1000 * B + T)
+    ref = VT.decoder_train_forward_backward(d, w, mem, lens, labels, drop, 31)
+    tr = DecoderV1Trainer(eng, B, T, S, spec)
+    mel, stop, align = tr.forward(flat, mem, lens, labels["mel"], drop_rate=drop, seed=31)
+    np.testing.assert_allclose(_np(mel), ref["mel"], atol=ATOL)
+    np.testing.assert_allclose(_np(stop)[..., 0], ref["stop"], atol=ATOL)
+    np.testing.assert_allclose(_np(align), ref["alignments"], atol=ATOL)
+    grads = torch.full_like(flat, float("nan"))
+    dmem, losses = tr.backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], grads)
+    ls = _np(losses)
+    assert abs(ls[0] - ref["mel_loss"]) <= 2e-4 * max(1.0, ref["mel_loss"]) and abs(ls[1] - ref["done_loss"]) <= 2e-4 * max(1.0, ref["done_loss"])
+    assert abs(ls[2] - ref["loss"]) <= 2e-4 * max(1.0, ref["loss"])
+    got = TR.unflatten(grads, spec)
+    assert set(got) == set(ref["grads"])
+    for k, g_ref in ref["grads"].items():
+        scale = float(np.abs(g_ref).max())
+        assert scale >= 1e-7, (k, scale)
+        assert np.isfinite(got[k]).all(), k
+        err = float(np.abs(got[k] - g_ref).max())
+        assert err <= 2e-3 * scale + 1e-9, (k, err, scale)
+    scale = float(np.abs(ref["dmemory"]).max())
+    assert float(np.abs(_np(dmem) - ref["dmemory"]).max()) <= 2e-3 * scale + 1e-9
+    for b_ in range(B):
+        assert not _np(dmem)[b_, lens[b_]:].any()                            # values = memory * mask
+    with pytest.raises(Exception):
+        tr.backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], grads)
+    tr.close()
+    eng.close()
