@@ -468,21 +468,131 @@ class ModeKeys:
 
 
 class SingleSpeakerTacotronV1Model:
-    """models.py:15-133.  PREDICT returns the reference's prediction dict (:122-129); EVAL the losses of the
-    free-feeding and the teacher-forced pass (:94-107); TRAIN is not built (no backward pass yet)."""
+    """models.py:15-133.  PREDICT returns the reference's prediction dict (:122-129); EVAL the losses of the free-feeding and
+    the teacher-forced pass (:94-107); TRAIN (:57-76) runs one whole training step on the model's flat parameter buffer
+    (``self.flat_params``: embedding, v1/encoder/, v1/attention/, v1/decoder/; created from ``weights`` at the first TRAIN call):
+    EncoderV1 / DecoderV1 in training mode (PreNet dropout, batch-statistics batch norm; the encoder without lengths, :47),
+    spec_loss + binary_loss, backward through decoder and encoder, clip_by_global_norm(1.0) + Adam at the (decayed) rate, the
+    batch norms' UPDATE_OPS.  The next EVAL / PREDICT call rebuilds the engine from the trained variables."""
 
     def __init__(self, params: V1Dims, weights: Optional[Dict[str, np.ndarray]] = None, device: int = 0, seed: int = 1234,
                  engine: EngineV1 = None):
         self.params = params
-        self.engine = engine if engine is not None else EngineV1(params, weights if weights is not None else init_weights_v1(params, seed), device)
-        p = params
+        self._weights = weights if weights is not None else (None if engine is not None else init_weights_v1(params, seed))
+        self._device, self.seed = device, seed
+        self._own_engine = engine is None
+        self.engine = engine if engine is not None else EngineV1(params, self._weights, device)
+        self._make_decoder()
+        self.flat_params = self.flat_grads = self.optimizer = None
+        self._enc_tr = self._dec_tr = None
+        self.global_step, self._stale = 0, False
+
+    def _make_decoder(self):
+        p = self.params
         self.decoder = DecoderV1(prenet_out_units=p.decoder_prenet_out_units, drop_rate=0.0, attention_out_units=p.attention_out_units,
                                  decoder_out_units=p.decoder_out_units, num_mels=p.num_mels, outputs_per_step=p.outputs_per_step,
                                  max_iters=p.max_iters, n_feed_frame=p.n_feed_frame, min_iters=p.min_iters, engine=self.engine)
 
+    @staticmethod
+    def _hp(params, name, default):
+        if params is None:
+            return default
+        return params.get(name, default) if isinstance(params, dict) else getattr(params, name, default)
+
+    def _setup_training(self, params):
+        if self._weights is None:
+            raise ValueError("SingleSpeakerTacotronV1Model(weights=...) is needed for mode TRAIN (the initial values of the variables)")
+        tw = {k: v for k, v in self._weights.items() if not k.startswith("v1/postnet/")}
+        self.spec = training.flatten_spec(tw)
+        self.flat_params = torch.from_numpy(training.flatten(tw, self.spec)).to(self.engine.device)
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        init = self._hp(params, "initial_learning_rate", 0.002)
+        lr = (lambda step: training.learning_rate_decay(init, step)) if self._hp(params, "decay_learning_rate", True) else init
+        self._adam = (lr, self._hp(params, "adam_beta1", 0.9), self._hp(params, "adam_beta2", 0.999), self._hp(params, "adam_eps", 1e-8))
+        self.optimizer = training.AdamOptimizer(self.engine, self.flat_params.numel(), *self._adam)
+
+    def _trainers(self, B, T_in, S):
+        if self._enc_tr is None or (self._enc_tr.B, self._enc_tr.T) != (B, T_in):
+            if self._enc_tr is not None:
+                self._enc_tr.close()
+            self._enc_tr = EncoderV1Trainer(self.engine, B, T_in, self.spec)
+        if self._dec_tr is None or (self._dec_tr.B, self._dec_tr.T_in, self._dec_tr.S) != (B, T_in, S):
+            if self._dec_tr is not None:
+                self._dec_tr.close()
+            self._dec_tr = DecoderV1Trainer(self.engine, B, T_in, S, self.spec)
+        return self._enc_tr, self._dec_tr
+
+    def train_step(self, features, labels, params=None, group=None):
+        """One TRAIN step (models.py:40-76).  Data parallel over ``group``: as ``training.Trainer.train_step`` (global non-zero
+        loss-weight counts first, summed gradients, rank-folded mask seed, moving statistics averaged)."""
+        if self.flat_params is None:
+            self._setup_training(params)
+        f = features if isinstance(features, dict) else features.__dict__
+        lab = labels if isinstance(labels, dict) else labels.__dict__
+        eng, d = self.engine, self.params
+        ids = _i64(f["source"])
+        B, T_in = ids.shape
+        S = int(np.shape(lab["mel"])[1]) // d.outputs_per_step
+        enc_tr, dec_tr = self._trainers(B, T_in, S)
+        world = training._world(group)
+        seed = training.rank_seed(self.seed + self.global_step, training._rank(group), world)
+        self.flat_grads.zero_()
+        counts = None
+        if world > 1:
+            counts = training.global_loss_counts(eng._f32(lab["spec_loss_mask"]), eng._f32(lab["binary_loss_mask"]), d.num_mels, group)
+        dec_tr.set_loss_counts(counts)
+        memory = enc_tr.forward(self.flat_params, ids, None, drop_rate=self._hp(params, "encoder_prenet_drop_rate", 0.5), seed=seed)
+        mel, stop, align = dec_tr.forward(self.flat_params, memory, f["source_length"], lab["mel"],
+                                          drop_rate=self._hp(params, "decoder_prenet_drop_rate", 0.5), seed=seed)
+        dmem, losses = dec_tr.backward(lab["done"], lab["spec_loss_mask"], lab["binary_loss_mask"], self.flat_grads)
+        enc_tr.backward(dmem, self.flat_grads)
+        if world > 1:
+            training.allreduce_sum(self.flat_grads, group)
+            m1, m2 = eng._f32(lab["spec_loss_mask"]), eng._f32(lab["binary_loss_mask"])
+            own = torch.stack([(m1 != 0).sum().to(torch.float32) * float(d.num_mels), (m2 != 0).sum().to(torch.float32)])
+            num = training.allreduce_sum(losses[:2] * own, group)
+            ml, dl = num[0] / counts[0].clamp(min=1), num[1] / counts[1].clamp(min=1)
+            losses = torch.stack([ml, dl, ml + dl])
+        lr = self.optimizer.learning_rate(self.global_step) if callable(self.optimizer.learning_rate) else self.optimizer.learning_rate
+        self.global_step = self.optimizer.apply_gradients(self.flat_grads, self.flat_params, global_step=self.global_step, clip_norm=1.0)
+        enc_tr.update_moving_stats(self.flat_params)
+        if world > 1:
+            training.Trainer._average_moving_stats(enc_tr, self.flat_params, group, world)
+        self._stale = True
+        return {"loss": losses[2], "mel_loss": losses[0], "done_loss": losses[1], "global_step": self.global_step, "learning_rate": lr,
+                "mel": mel, "alignment": align.permute(1, 2, 0)}
+
+    def trained_weights(self) -> Dict[str, np.ndarray]:
+        out = dict(self._weights)
+        out.update(training.unflatten(self.flat_params, self.spec))
+        return out
+
+    def _refresh_engine(self):
+        """EVAL / PREDICT after TRAIN: the inference decoder's packed operands have no device-side refresh, so the engine is
+        rebuilt from the trained variables (a host round trip, once per switch from training to inference)."""
+        if not self._own_engine:
+            raise RuntimeError("the engine was passed in: build a new EngineV1 from model.trained_weights()")
+        self._weights = self.trained_weights()
+        for t in (self._enc_tr, self._dec_tr):
+            if t is not None:
+                t.close()
+        self._enc_tr = self._dec_tr = None
+        if self.optimizer is not None:
+            state = self.optimizer.state()
+            self.optimizer.close()
+        self.engine.close()
+        self.engine = EngineV1(self.params, self._weights, self._device)
+        if self.optimizer is not None:
+            self.optimizer = training.AdamOptimizer(self.engine, self.flat_params.numel(), *self._adam)
+            self.optimizer.load_state(*state)
+        self._make_decoder()
+        self._stale = False
+
     def model_fn(self, features, labels=None, mode=ModeKeys.PREDICT, params=None):
         if mode == ModeKeys.TRAIN:
-            raise NotImplementedError("the training step (gradients) is not built yet")
+            return self.train_step(features, labels, params)
+        if self._stale:
+            self._refresh_engine()
         is_validation = mode == ModeKeys.EVAL
         f = features if isinstance(features, dict) else features.__dict__
         lab = None if labels is None else (labels if isinstance(labels, dict) else labels.__dict__)
@@ -510,6 +620,11 @@ class SingleSpeakerTacotronV1Model:
         return self.model_fn(features, None, ModeKeys.PREDICT)["predictions"]
 
     def close(self):
+        for t in (self._enc_tr, self._dec_tr):
+            if t is not None:
+                t.close()
+        if self.optimizer is not None:
+            self.optimizer.close()
         self.engine.close()
 
 

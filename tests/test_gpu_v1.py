@@ -214,7 +214,7 @@ def test_v1_model_fn_predict_and_eval():
     post = TacotronV1PostNetModel(d, eng)
     spec = post.model_fn({"mel": ref["mel"]}, None, ModeKeys.PREDICT)["predictions"]["spec"]
     np.testing.assert_allclose(_np(spec), V.postnet_v1(d, w, ref["mel"]), atol=ATOL)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):        # TRAIN needs the variables' initial values (weights=...); the step itself: tests/test_gpu_v1_train.py
         model.model_fn({"source": ids, "source_length": lens}, labels, ModeKeys.TRAIN)
 
 

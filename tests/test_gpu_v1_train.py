@@ -441,3 +441,69 @@ def test_decoder_v1_training_forward_and_every_gradient_against_autograd(name, B
         tr.backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], grads)
     tr.close()
     eng.close()
+
+
+def test_single_speaker_v1_model_fn_train_loop_against_oracle():
+    """SingleSpeakerTacotronV1Model.model_fn(TRAIN) (models.py:40-76) twice against the oracle loop (encoder oracle o decoder
+    oracle through d memory, clip_by_global_norm(1.0), TF-form Adam at the Noam rate, UPDATE_OPS), then PREDICT with the trained
+    variables = a fresh model built from them."""
+    from tests.test_gpu_v1 import DIMS
+    from tacotron2_amd.tacotron_v1 import ModeKeys, SingleSpeakerTacotronV1Model
+    d = DIMS["ref"].replace(num_symbols=40, max_iters=6, min_iters=2)
+    w = init_weights_v1(d, 19, perturb=True)
+    model = SingleSpeakerTacotronV1Model(d, weights=w, seed=100)
+    hp = {"initial_learning_rate": 0.002, "decay_learning_rate": True, "encoder_prenet_drop_rate": 0.5, "decoder_prenet_drop_rate": 0.5}
+    B, T, S = 5, 11, 4
+    names = sorted(k for k in w if not k.startswith("v1/postnet/"))
+    trainable = [k for k in names if not k.endswith(("moving_mean", "moving_variance"))]
+    w_ref = {k: w[k].copy() for k in w}
+    m_ref = {k: np.zeros_like(w[k]) for k in trainable}
+    v_ref = {k: np.zeros_like(w[k]) for k in trainable}
+    lrs = []
+    for it in range(2):
+        rng = np.random.default_rng(40 + it)
+        ids = rng.integers(0, d.num_symbols, (B, T))
+        _, lens, labels = _dec_case(d, B, T, S, 70 + it)
+        seed = 100 + it                                                      # model seed + global_step
+        enc = VT.encoder_train_forward_backward(d, w_ref, ids, None, np.zeros((B, T, d.cbhg_out_units), np.float32), 0.5, seed)
+        dec = VT.decoder_train_forward_backward(d, w_ref, enc["memory"], lens, labels, 0.5, seed)
+        enc = VT.encoder_train_forward_backward(d, w_ref, ids, None, dec["dmemory"], 0.5, seed)
+        res = model.model_fn({"source": ids, "source_length": lens}, labels, ModeKeys.TRAIN, hp)
+        assert res["global_step"] == it + 1
+        assert abs(float(res["loss"]) - dec["loss"]) <= 5e-4 * max(1.0, dec["loss"]), (it, float(res["loss"]), dec["loss"])
+        np.testing.assert_allclose(_np(res["mel"]), dec["mel"], atol=2e-3)
+        grads = dict(dec["grads"])
+        grads.update(enc["grads"])
+        lr = O.learning_rate_decay(0.002, it)
+        lrs.append(lr)
+        assert abs(res["learning_rate"] - lr) < 1e-12
+        clipped, _ = O.clip_by_global_norm([grads[k] for k in trainable], 1.0)
+        for k, g in zip(trainable, clipped):
+            w_ref[k], m_ref[k], v_ref[k] = O.adam_apply(w_ref[k], g, m_ref[k], v_ref[k], it + 1, lr)
+        n = B * T
+        for p_, (mu, var) in enc["bn_stats"].items():
+            q = p_ + "/batch_normalization"
+            w_ref[q + "/moving_mean"] = (0.99 * w_ref[q + "/moving_mean"] + 0.01 * mu).astype(np.float32)
+            w_ref[q + "/moving_variance"] = (0.99 * w_ref[q + "/moving_variance"] + 0.01 * var * n / (n - 1)).astype(np.float32)
+    got = model.trained_weights()
+    tot = sum(lrs)
+    for k in ("v1/encoder/cbhg/proj1/batch_normalization/moving_mean", "v1/encoder/cbhg/conv1d_K3/batch_normalization/moving_variance"):
+        np.testing.assert_allclose(got[k], w_ref[k], rtol=1e-3, atol=1e-5)
+    for k in ("embedding", "v1/encoder/cbhg/proj1/kernel", "v1/decoder/attention_gru/gates/kernel", "v1/attention/query_layer/kernel",
+              "v1/decoder/gru_2/candidate/kernel", "v1/decoder/out_projection/kernel"):
+        assert float(np.abs(got[k] - w[k]).max()) <= 1.05 * tot
+        assert float(np.abs(got[k] - w[k]).max()) >= 0.5 * lrs[0]
+        np.testing.assert_allclose(got[k], w_ref[k], atol=0.3 * tot)
+    np.testing.assert_array_equal(got["v1/postnet/linear/kernel"], w["v1/postnet/linear/kernel"])      # not a variable of this model
+    # PREDICT after TRAIN uses the trained variables
+    ids = np.random.default_rng(5).integers(0, d.num_symbols, (2, 9))
+    feats = {"source": ids, "source_length": np.array([9, 6])}
+    pred = model.predict(feats)
+    fresh = SingleSpeakerTacotronV1Model(d, weights=got)
+    ref = fresh.predict(feats)
+    np.testing.assert_allclose(_np(pred["mel"]), _np(ref["mel"]), atol=1e-6)
+    # and training goes on afterwards (optimizer state carried over the engine rebuild)
+    res = model.model_fn({"source": ids, "source_length": np.array([9, 6])}, _dec_case(d, 2, 9, 3, 3)[2], ModeKeys.TRAIN, hp)
+    assert res["global_step"] == 3 and np.isfinite(float(res["loss"]))
+    fresh.close()
+    model.close()
