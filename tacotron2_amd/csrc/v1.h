@@ -35,6 +35,7 @@ struct t2v1_model {
     ConvLayer dec_prenet_plain[2], proj_plain;   // teacher-forced decodes: PreNets and projections of all steps as batched GEMMs
     int opt_tfbatch = 1;
     int opt_gruseq = 1;                   // CBHG BiGRU of 128 units per direction as one persistent launch (gru_seq_kernel)
+    int opt_skinny = 1;                   // training recurrence: per-step products on v1d_skinny_gemm_kernel (0: conv_gemm tiles)
     bool gru_packed_stale = false;        // a trainer exported new variables: only the whole-sequence GRU operands were rebuilt
     GruPacked att_gru, gru1, gru2;
     float* v_a = nullptr;
@@ -191,6 +192,7 @@ extern "C" int t2v1_model_set_option(t2v1_model* m, const char* name, int value)
     if (!m || !name) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "graph")) m->opt_graph = value;
     else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
+    else if (!strcmp(name, "skinny")) m->opt_skinny = value;
     else if (!strcmp(name, "gruseq")) {
         if (!value && m->gru_packed_stale) return fail(T2_ESTATE, "gruseq = 0 after a trainer export: the launch-per-step GRU operands hold the variables of before the training");
         m->opt_gruseq = value;

@@ -68,64 +68,77 @@ __global__ __launch_bounds__(256) void v1d_blend_kernel(const float* __restrict_
         }
     }
 }
-// BahdanauAttention.__call__ + AttentionWrapper._compute_attention (App. A5, A6) of one batch row per workgroup:
-// score_j = v . tanh(keys_j + q), softmax over the live positions (-inf mask), context = sum_j a_j values_j
-__global__ __launch_bounds__(256) void v1d_attn_fwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
-                                                           const float* __restrict__ v, const int* __restrict__ lens, int T, int A, int E,
-                                                           float* __restrict__ align, V1Dst c0, V1Dst c1) {
+// BahdanauAttention.__call__ + AttentionWrapper._compute_attention (App. A5, A6) of one batch row per workgroup of 16 waves:
+// score_j = v . tanh(keys_j + q) (a wave per position), softmax over the live positions (-inf mask), context = sum_j a_j values_j
+// (four position groups per context column, added in group order).  tanh on the hardware exp / rcp (fast_tanhf, ~1e-6); the
+// backward kernel uses the same function.
+#define V1D_ATT_THREADS 1024
+__global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_fwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
+                                                                       const float* __restrict__ v, const int* __restrict__ lens, int T, int A, int E,
+                                                                       float* __restrict__ align, V1Dst c0, V1Dst c1) {
     extern __shared__ float sm[];
-    float *s_q = sm, *s_v = sm + A, *s_e = sm + 2 * A;
-    __shared__ float s_red[8];
+    float *s_q = sm, *s_v = sm + A, *s_e = sm + 2 * A, *s_part = sm + 2 * A + T;        // s_part [4][E]
+    __shared__ float s_red[32];
+    constexpr int NW = V1D_ATT_THREADS / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = lens[b];
-    for (int u = tid; u < A; u += 256) { s_q[u] = q[(size_t)b * A + u]; s_v[u] = v[u]; }
+    for (int u = tid; u < A; u += V1D_ATT_THREADS) { s_q[u] = q[(size_t)b * A + u]; s_v[u] = v[u]; }
     __syncthreads();
-    for (int j = wave; j < len; j += 4) {
+    for (int j = wave; j < len; j += NW) {
         const float* k = keys + ((size_t)b * T + j) * A;
         float p = 0.f;
-        for (int u = lane; u < A; u += 64) p += s_v[u] * tanhf(k[u] + s_q[u]);
+        for (int u = lane; u < A; u += 64) p += s_v[u] * fast_tanhf(k[u] + s_q[u]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
         if (lane == 0) s_e[j] = p;
     }
     __syncthreads();
     float mx = -INFINITY;
-    for (int j = tid; j < len; j += 256) mx = fmaxf(mx, s_e[j]);
+    for (int j = tid; j < len; j += V1D_ATT_THREADS) mx = fmaxf(mx, s_e[j]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    mx = s_red[0];
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, s_red[w]);
     float sum = 0.f;
-    for (int j = tid; j < T; j += 256) { const float e = j < len ? expf(s_e[j] - mx) : 0.f; s_e[j] = e; sum += e; }
+    for (int j = tid; j < T; j += V1D_ATT_THREADS) { const float e = j < len ? expf(s_e[j] - mx) : 0.f; s_e[j] = e; sum += e; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    if (lane == 0) s_red[4 + wave] = sum;
+    if (lane == 0) s_red[NW + wave] = sum;
     __syncthreads();
-    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-    for (int j = tid; j < T; j += 256) { const float p = s_e[j] / sum; s_e[j] = p; align[(size_t)b * T + j] = p; }
+    sum = 0.f;
+    for (int w = 0; w < NW; ++w) sum += s_red[NW + w];
+    for (int j = tid; j < T; j += V1D_ATT_THREADS) { const float p = s_e[j] / sum; s_e[j] = p; align[(size_t)b * T + j] = p; }
     __syncthreads();
-    for (int e = tid; e < E; e += 256) {
+    const int g = tid >> 8;
+    for (int e = tid & 255; e < E; e += 256) {
         float acc = 0.f;
-        for (int j = 0; j < len; ++j) acc = fmaf(s_e[j], values[((size_t)b * T + j) * E + e], acc);
+        for (int j = g; j < len; j += 4) acc = fmaf(s_e[j], values[((size_t)b * T + j) * E + e], acc);
+        s_part[g * E + e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += V1D_ATT_THREADS) {
+        const float acc = (s_part[e] + s_part[E + e]) + (s_part[2 * E + e] + s_part[3 * E + e]);
         if (c0.p) c0.p[(size_t)b * c0.ld + e] = acc;
         if (c1.p) c1.p[(size_t)b * c1.ld + e] = acc;
     }
 }
 // its backward for one row: d a_j = d ctx . values_j; softmax backward; d q = sum_j g_j, d keys_j += g_j, d v += sum_j d e_j tanh_j
 // with g_ju = d e_j v_u (1 - tanh_ju^2).  (d values is a tape-wide product afterwards; the Bahdanau state is not fed back.)
-__global__ __launch_bounds__(256) void v1d_attn_bwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
-                                                           const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align,
-                                                           const float* __restrict__ dctx, long long dctx_row_stride, int T, int A, int E,
-                                                           float* __restrict__ dq, float* __restrict__ dkeys, float* __restrict__ dvpart) {
+__global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_bwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
+                                                                       const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align,
+                                                                       const float* __restrict__ dctx, long long dctx_row_stride, int T, int A, int E,
+                                                                       float* __restrict__ dq, float* __restrict__ dkeys, float* __restrict__ dvpart) {
     extern __shared__ float sm[];
-    float *s_dc = sm, *s_de = sm + E;
-    __shared__ float s_red[4];
+    float *s_dc = sm, *s_de = sm + E, *s_pq = sm + E + T, *s_pv = s_pq + 4 * A;          // partial d q / d v [4][A]
+    __shared__ float s_red[16];
+    constexpr int NW = V1D_ATT_THREADS / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = lens[b];
-    for (int e = tid; e < E; e += 256) s_dc[e] = dctx[(size_t)b * dctx_row_stride + e];
+    for (int e = tid; e < E; e += V1D_ATT_THREADS) s_dc[e] = dctx[(size_t)b * dctx_row_stride + e];
     __syncthreads();
-    for (int j = wave; j < len; j += 4) {
+    for (int j = wave; j < len; j += NW) {
         const float* vj = values + ((size_t)b * T + j) * E;
         float p = 0.f;
         for (int e = lane; e < E; e += 64) p += s_dc[e] * vj[e];
@@ -135,27 +148,33 @@ __global__ __launch_bounds__(256) void v1d_attn_bwd_kernel(const float* __restri
     }
     __syncthreads();
     float s = 0.f;
-    for (int j = tid; j < len; j += 256) s += align[(size_t)b * T + j] * s_de[j];
+    for (int j = tid; j < len; j += V1D_ATT_THREADS) s += align[(size_t)b * T + j] * s_de[j];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) s_red[wave] = s;
     __syncthreads();
-    s = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    s = 0.f;
+    for (int w = 0; w < NW; ++w) s += s_red[w];
     __syncthreads();
-    for (int j = tid; j < len; j += 256) s_de[j] = align[(size_t)b * T + j] * (s_de[j] - s);
+    for (int j = tid; j < len; j += V1D_ATT_THREADS) s_de[j] = align[(size_t)b * T + j] * (s_de[j] - s);
     __syncthreads();
-    for (int u = tid; u < A; u += 256) {
+    const int g = tid >> 8;
+    for (int u = tid & 255; u < A; u += 256) {
         const float qu = q[(size_t)b * A + u], vu = v[u];
         float aq = 0.f, av = 0.f;
-        for (int j = 0; j < len; ++j) {
+        for (int j = g; j < len; j += 4) {
             const size_t ki = ((size_t)b * T + j) * A + u;
-            const float th = tanhf(keys[ki] + qu), de = s_de[j];
-            const float g = de * vu * (1.0f - th * th);
-            aq += g; av += de * th;
-            dkeys[ki] += g;
+            const float th = fast_tanhf(keys[ki] + qu), de = s_de[j];
+            const float gg = de * vu * (1.0f - th * th);
+            aq += gg; av += de * th;
+            dkeys[ki] += gg;
         }
-        dq[(size_t)b * A + u] = aq;
-        dvpart[(size_t)b * A + u] += av;
+        s_pq[g * A + u] = aq; s_pv[g * A + u] = av;
+    }
+    __syncthreads();
+    for (int u = tid; u < A; u += V1D_ATT_THREADS) {
+        dq[(size_t)b * A + u] = (s_pq[u] + s_pq[A + u]) + (s_pq[2 * A + u] + s_pq[3 * A + u]);
+        dvpart[(size_t)b * A + u] += (s_pv[u] + s_pv[A + u]) + (s_pv[2 * A + u] + s_pv[3 * A + u]);
     }
 }
 // GRU cell backward, stage 1: d h' = d0 (+ d1) -> d zc, d zu, and the part of d h that does not pass a GEMM (d h' u)
@@ -245,6 +264,54 @@ __global__ __launch_bounds__(256) void v1d_stop_to_bs_kernel(const float* __rest
     }
 }
 
+// y [rows][N] = x [rows][K] . w [K][N] (+ bias) (+ res) for rows <= 64 (the per-step products of the recurrence: 32 batch rows against
+// 256..640 x 256..512 kernels in TF layout).  conv_gemm_*'s 64 x 128 tiles leave 2-4 workgroups with a serial K loop for such a
+// product (31 us each, measured); here a workgroup owns 16 output columns and all rows, its four waves split K (k-blocks of 16
+// round robin) on v_mfma_f32_16x16x4_f32 and add their partial tiles through LDS: N / 16 workgroups, ~3 us.
+// MFMA step j of a k-block takes k = 4 kg + j from lane group kg (A: one float4 of x per lane and row block; B: W[k][n0 + c16]).
+template <int MB>
+__global__ __launch_bounds__(256) void v1d_skinny_gemm_kernel(const float* __restrict__ x, int ldx, int K, const float* __restrict__ w, int N,
+                                                              const float* __restrict__ bias, float* y, int ldy, const float* res, int ldr, int rows) {
+    __shared__ f32x4 red[4][MB][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, c16 = lane & 15;
+    const int n0 = blockIdx.x * 16, n = n0 + c16;
+    const bool n_ok = n < N;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = K >> 4;
+    for (int kb = wave; kb < nkb; kb += 4) {
+        const int k0 = kb * 16 + 4 * kg;
+        f32x4 a[MB];
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) {
+            const int row = rb * 16 + c16;
+            a[rb] = row < rows ? *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float bw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bw[j] = n_ok ? w[(size_t)(k0 + j) * N + n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][j], bw[j], acc[rb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) red[wave][rb][lane] = acc[rb];
+    __syncthreads();
+    // D layout: reg r of lane (kg, c16) = row 4 kg + r, column c16; thread -> (row block, lane, reg)
+    for (int i = tid; i < MB * 64 * 4; i += 256) {
+        const int r = i & 3, l = (i >> 2) & 63, rb = i >> 8;
+        const int row = rb * 16 + 4 * (l >> 4) + r, col = n0 + (l & 15);
+        if (row < rows && col < N) {
+            float v = red[0][rb][l][r] + red[1][rb][l][r] + red[2][rb][l][r] + red[3][rb][l][r];
+            if (bias) v += bias[col];
+            if (res) v += res[(size_t)row * ldr + col];
+            y[(size_t)row * ldy + col] = v;
+        }
+    }
+}
+
 struct t2v1_dtrainer {
     t2v1_model* m = nullptr;
     int B = 0, T = 0, S = 0;
@@ -263,7 +330,32 @@ struct t2v1_dtrainer {
     float *dmel_sb, *dstop_sb, *DY2, *DZG2, *DZC2, *DZG1, *DZC1, *DY0, *DQ, *DZGa, *DZCa, *DCTX, *dkeys, *dvpart, *dvalues;
     float *cHA, *cCTX, *cH1, *cH2, *keep, *dcatr, *dcat, *dy1, *dy0, *dcato, *dha, *dP1, *dP0;
     float *WmT, *WsT, *Wg2T, *Wc2T, *Wg1T, *Wc1T, *WoT, *WqT, *WgaT, *WcaT, *WgpT, *WcpT, *Wp1T, *WmemT;
+    // the two recurrence loops as hipGraphs (S x 15 / S x 17 launches each): every pointer in them is the trainer's own or lies in
+    // the flat parameter buffer, so a graph stays valid as long as that buffer's address does
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    const float* gparams[2] = {nullptr, nullptr};
 };
+
+template <typename F>
+static int dt_run_loop(t2v1_dtrainer* tr, int which, F&& body) {
+    hipStream_t st = tr->m->base.ctx->stream;
+    if (!tr->m->opt_graph) return body();
+    if (tr->gexec[which] == nullptr || tr->gparams[which] != tr->params) {
+        if (tr->gexec[which]) { (void)hipGraphExecDestroy(tr->gexec[which]); tr->gexec[which] = nullptr; }
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int r = body();
+        const hipError_t e = hipStreamEndCapture(st, &g);
+        if (r != T2_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+        if (e != hipSuccess) return fail(T2_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        const hipError_t e2 = hipGraphInstantiate(&tr->gexec[which], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e2 != hipSuccess) { tr->gexec[which] = nullptr; return fail(T2_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e2)); }
+        tr->gparams[which] = tr->params;
+    }
+    HIP_TRY(hipGraphLaunch(tr->gexec[which], st));
+    return T2_OK;
+}
 
 static const float* dt_w(t2v1_dtrainer* tr, const std::string& name, int* err) {
     auto it = tr->ws.offsets.find(name);
@@ -276,6 +368,7 @@ extern "C" int t2v1_decoder_trainer_destroy(t2v1_dtrainer* tr) {
     if (!tr) return T2_OK;
     (void)hipSetDevice(tr->m->base.ctx->device);
     (void)hipStreamSynchronize(tr->m->base.ctx->stream);
+    for (int i = 0; i < 2; ++i) if (tr->gexec[i]) (void)hipGraphExecDestroy(tr->gexec[i]);
     if (tr->slab) (void)hipFree(tr->slab);
     if (tr->ws.cs_part) (void)hipFree(tr->ws.cs_part);
     if (tr->ws.wg_part) (void)hipFree(tr->ws.wg_part);
@@ -341,6 +434,17 @@ extern "C" int t2v1_decoder_trainer_set_loss_counts(t2v1_dtrainer* tr, const flo
 // y [B][N] (row stride ldy) = x [B][K] (row stride ldx) . w [K][N] (+ bias) (+ res): the small per-step products
 static int dt_gemm(t2v1_dtrainer* tr, const float* x, int ldx, int K, const float* w, int N, const float* bias, float* y, int ldy, const float* res, int ldr,
                    int rows) {
+    if (rows <= 64 && K % 16 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && tr->m->opt_skinny) {
+        hipStream_t st = tr->m->base.ctx->stream;
+        const dim3 grid(ceil_div(N, 16));
+        switch (ceil_div(rows, 16)) {
+            case 1: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<1>, grid, dim3(256), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
+            case 2: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<2>, grid, dim3(256), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
+            case 3: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<3>, grid, dim3(256), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
+            default: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<4>, grid, dim3(256), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
+        }
+        return T2_OK;
+    }
     ConvLayer L{};
     L.w = const_cast<float*>(w); L.shift = const_cast<float*>(bias); L.k = 1; L.cin = K; L.cout = N;
     return launch_conv(&tr->m->base, L, x, ldx, y, ldy, rows, rows, 0, res, ldr);
@@ -399,7 +503,8 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
     HIP_TRY(hipMemsetAsync(tr->CAT1, 0, (size_t)B * 2 * D * 4, st));
     HIP_TRY(hipMemsetAsync(tr->CAT2, 0, (size_t)B * 2 * D * 4, st));
     const int XA = E + A;
-    const size_t attn_lds = (size_t)(2 * A + T) * 4;
+    const size_t attn_lds = (size_t)(2 * A + T + 4 * E) * 4;
+    T2_TRY(dt_run_loop(tr, 0, [&]() -> int {
     for (int t = 0; t < S; ++t) {
         float *cata = tr->CATA + (size_t)t * B * XA, *cata_n = cata + (size_t)B * XA, *catar = tr->CATAR + (size_t)t * B * XA;
         float *cato = tr->CATO + (size_t)t * B * (A + E);
@@ -414,7 +519,7 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
         // Bahdanau attention
         float* q = tr->Q + (size_t)t * B * A;
         T2_TRY(dt_gemm(tr, cato, A + E, A, Wq, A, nullptr, q, A, nullptr, 0, B));
-        hipLaunchKernelGGL(v1d_attn_fwd_kernel, dim3(B), dim3(256), attn_lds, st, tr->keys, tr->values, q, va, tr->lens, T, A, E, tr->ALIGN + (size_t)t * B * T,
+        hipLaunchKernelGGL(v1d_attn_fwd_kernel, dim3(B), dim3(V1D_ATT_THREADS), attn_lds, st, tr->keys, tr->values, q, va, tr->lens, T, A, E, tr->ALIGN + (size_t)t * B * T,
                            V1Dst{cato + A, A + E}, V1Dst{cata_n, XA});
         // OutputProjectionWrapper on [h_att | ctx] -> y0 = the x half of GRU 1's operand
         T2_TRY(dt_gemm(tr, cato, A + E, A + E, Wo, D, bo, cat1, 2 * D, nullptr, 0, B));
@@ -430,6 +535,8 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
         hipLaunchKernelGGL(v1d_blend_kernel, dt_grid((long long)B * D), dim3(256), 0, st, tr->zc, tr->RU2 + (size_t)t * B * 2 * D, cat2, D, D, tr->C2 + (size_t)t * B * D,
                            V1Dst{cat2_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{tr->Y2 + (size_t)t * B * D, D}, V1Dst{nullptr, 0}, B);
     }
+    return T2_OK;
+    }));
     // mel / stop projections of all steps (OutputAndStopTokenWrapper, rnn_wrappers.py:105-109)
     T2_TRY(dt_gemm(tr, tr->Y2, D, D, Wm, rM, bm, tr->mel_sb, rM, nullptr, 0, SB));
     T2_TRY(dt_gemm(tr, tr->Y2, D, D, Wst, 1, bst, tr->stop_sb, 1, nullptr, 0, SB));
@@ -505,7 +612,8 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
     HIP_TRY(hipMemsetAsync(tr->cHA, 0, (size_t)B * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->cCTX, 0, (size_t)B * E * 4, st));
     HIP_TRY(hipMemsetAsync(tr->cH1, 0, (size_t)B * D * 4, st)); HIP_TRY(hipMemsetAsync(tr->cH2, 0, (size_t)B * D * 4, st));
     HIP_TRY(hipMemsetAsync(tr->dkeys, 0, (size_t)B * T * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->dvpart, 0, (size_t)B * A * 4, st));
-    const size_t attn_lds = (size_t)(E + T) * 4;
+    const size_t attn_lds = (size_t)(E + T + 8 * A) * 4;
+    T2_TRY(dt_run_loop(tr, 1, [&]() -> int {
     for (int t = S - 1; t >= 0; --t) {
         const float *cata = tr->CATA + (size_t)t * B * XA, *cato = tr->CATO + (size_t)t * B * (A + E);
         const float *cat1 = tr->CAT1 + (size_t)t * B * 2 * D, *cat2 = tr->CAT2 + (size_t)t * B * 2 * D;
@@ -521,7 +629,7 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
         float* dctx_t = tr->DCTX + (size_t)t * E;                       // tape [B][S][E]
         hipLaunchKernelGGL(v1d_dctx_kernel, dt_grid((long long)B * E), dim3(256), 0, st, tr->dcato, A, E, tr->cCTX, dctx_t, (long long)S * E, B);
         float* dq = tr->DQ + (size_t)t * B * A;
-        hipLaunchKernelGGL(v1d_attn_bwd_kernel, dim3(B), dim3(256), attn_lds, st, tr->keys, tr->values, tr->Q + (size_t)t * B * A, va, tr->lens,
+        hipLaunchKernelGGL(v1d_attn_bwd_kernel, dim3(B), dim3(V1D_ATT_THREADS), attn_lds, st, tr->keys, tr->values, tr->Q + (size_t)t * B * A, va, tr->lens,
                            tr->ALIGN + (size_t)t * B * T, dctx_t, (long long)S * E, T, A, E, dq, tr->dkeys, tr->dvpart);
         // d h_att = output projection's share + d q . Wq^T (+ the carry, added in stage 1)
         T2_TRY(dt_gemm(tr, dq, A, A, tr->WqT, A, nullptr, tr->dha, A, tr->dcato, A + E, B));
@@ -529,6 +637,8 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
         T2_TRY(dt_gru_bwd(tr, tr->dha, A, tr->cHA, A, cata, tr->RUa + (size_t)t * B * 2 * A, tr->Ca + (size_t)t * B * A, E, A, tr->WcaT, tr->WgaT,
                           tr->DZCa + (size_t)t * B * A, tr->DZGa + (size_t)t * B * 2 * A, nullptr, 0, tr->cHA, tr->cCTX, E));
     }
+    return T2_OK;
+    }));
     HIP_TRY(hipGetLastError());
     // ---- weight gradients: tape-wide GEMMs ----
     float *gWm = G(pd + "out_projection/kernel"), *gbm = G(pd + "out_projection/bias"), *gWs = G(pd + "stop_token_projection/kernel"), *gbs = G(pd + "stop_token_projection/bias");
