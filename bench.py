@@ -379,13 +379,27 @@ def main():
             lens_o = rng1.integers(To1 // 2, To1 + 1, B1); lens_o[0] = To1
             msk1v = torch.tensor((np.arange(To1)[None, :] < lens_o[:, None]).astype(np.float32), device="cuda")
             dt_pt, res_pt = timed(lambda: pmodel.model_fn({"mel": mel1v}, {"spec": spec1v, "spec_loss_mask": msk1v}, ModeKeys.TRAIN))
+            # SingleSpeakerTacotronV1Model.model_fn(TRAIN) (models.py:40-76): the whole step, batch_size 32 (hparams.py:63)
+            from tacotron2_amd.tacotron_v1 import SingleSpeakerTacotronV1Model
+            S1 = To1 // d1.outputs_per_step
+            tl1 = rng1.integers(To1 // 2, To1 + 1, B1); tl1[0] = To1
+            sl1 = (tl1 + d1.outputs_per_step - 1) // d1.outputs_per_step
+            lab1 = {"mel": tgt1v, "done": (np.arange(S1)[None, :] >= (sl1[:, None] - 1)).astype(np.float32),
+                    "spec_loss_mask": (np.arange(To1)[None, :] < tl1[:, None]).astype(np.float32),
+                    "binary_loss_mask": (np.arange(S1)[None, :] < sl1[:, None]).astype(np.float32)}
+            tmodel = SingleSpeakerTacotronV1Model(d1, weights=w1, seed=3)
+            dt_tr1, res_tr1 = timed(lambda: tmodel.model_fn({"source": ids1v, "source_length": lens1v}, lab1, ModeKeys.TRAIN))
+            v1_train_loss = float(res_tr1["loss"])
+            tmodel.close()
             out["v1"] = {"workload": "BASELINE.json configs[4]: Tacotron v1 (tacotron_v1.py), reference hparams sizes, B=32, T_in<=140, "
                                      "800 frames: EncoderV1 (CBHG) + teacher-forced DecoderV1 forward; mel -> linear CBHG PostNet forward; "
-                                     "PostNet training step (forward, L1 loss, backward, clip + Adam, moving statistics)",
+                                     "PostNet training step (forward, L1 loss, backward, clip + Adam, moving statistics); "
+                                     "SingleSpeakerTacotronV1Model training step (encoder + decoder forward and backward, clip + Adam)",
                          "teacher_forced_ms": dt_f * 1e3, "teacher_forced_mel_frames_per_s": B1 * To1 / dt_f,
                          "postnet_ms": dt_p * 1e3, "postnet_spectrogram_frames_per_s": B1 * To1 / dt_p,
                          "postnet_train_step_ms": dt_pt * 1e3, "postnet_train_spectrogram_frames_per_s": B1 * To1 / dt_pt,
-                         "postnet_train_loss": float(res_pt["loss"])}
+                         "postnet_train_loss": float(res_pt["loss"]),
+                         "train_step_ms": dt_tr1 * 1e3, "train_mel_frames_per_s": B1 * To1 / dt_tr1, "train_loss": v1_train_loss}
             eng1.close()
         except Exception as ex:
             out["v1"] = {"error": repr(ex)}

@@ -266,13 +266,14 @@ __global__ __launch_bounds__(256) void v1d_stop_to_bs_kernel(const float* __rest
 
 // y [rows][N] = x [rows][K] . w [K][N] (+ bias) (+ res) for rows <= 64 (the per-step products of the recurrence: 32 batch rows against
 // 256..640 x 256..512 kernels in TF layout).  conv_gemm_*'s 64 x 128 tiles leave 2-4 workgroups with a serial K loop for such a
-// product (31 us each, measured); here a workgroup owns 16 output columns and all rows, its four waves split K (k-blocks of 16
+// product (31 us each, measured); here a workgroup owns 16 output columns and all rows, its eight waves split K (k-blocks of 16
 // round robin) on v_mfma_f32_16x16x4_f32 and add their partial tiles through LDS: N / 16 workgroups, ~3 us.
 // MFMA step j of a k-block takes k = 4 kg + j from lane group kg (A: one float4 of x per lane and row block; B: W[k][n0 + c16]).
+#define V1D_SK_WAVES 8
 template <int MB>
-__global__ __launch_bounds__(256) void v1d_skinny_gemm_kernel(const float* __restrict__ x, int ldx, int K, const float* __restrict__ w, int N,
+__global__ __launch_bounds__(64 * V1D_SK_WAVES) void v1d_skinny_gemm_kernel(const float* __restrict__ x, int ldx, int K, const float* __restrict__ w, int N,
                                                               const float* __restrict__ bias, float* y, int ldy, const float* res, int ldr, int rows) {
-    __shared__ f32x4 red[4][MB][64];
+    __shared__ f32x4 red[V1D_SK_WAVES][MB][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, c16 = lane & 15;
     const int n0 = blockIdx.x * 16, n = n0 + c16;
     const bool n_ok = n < N;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void v1d_skinny_gemm_kernel(const float* __res
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nkb = K >> 4;
-    for (int kb = wave; kb < nkb; kb += 4) {
+    for (int kb = wave; kb < nkb; kb += V1D_SK_WAVES) {
         const int k0 = kb * 16 + 4 * kg;
         f32x4 a[MB];
 #pragma unroll
@@ -300,11 +301,13 @@ __global__ __launch_bounds__(256) void v1d_skinny_gemm_kernel(const float* __res
     for (int rb = 0; rb < MB; ++rb) red[wave][rb][lane] = acc[rb];
     __syncthreads();
     // D layout: reg r of lane (kg, c16) = row 4 kg + r, column c16; thread -> (row block, lane, reg)
-    for (int i = tid; i < MB * 64 * 4; i += 256) {
+    for (int i = tid; i < MB * 64 * 4; i += 64 * V1D_SK_WAVES) {
         const int r = i & 3, l = (i >> 2) & 63, rb = i >> 8;
         const int row = rb * 16 + 4 * (l >> 4) + r, col = n0 + (l & 15);
         if (row < rows && col < N) {
-            float v = red[0][rb][l][r] + red[1][rb][l][r] + red[2][rb][l][r] + red[3][rb][l][r];
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < V1D_SK_WAVES; ++wv) v += red[wv][rb][l][r];
             if (bias) v += bias[col];
             if (res) v += res[(size_t)row * ldr + col];
             y[(size_t)row * ldy + col] = v;
@@ -438,10 +441,10 @@ static int dt_gemm(t2v1_dtrainer* tr, const float* x, int ldx, int K, const floa
         hipStream_t st = tr->m->base.ctx->stream;
         const dim3 grid(ceil_div(N, 16));
         switch (ceil_div(rows, 16)) {
-            case 1: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<1>, grid, dim3(256), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
-            case 2: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<2>, grid, dim3(256), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
-            case 3: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<3>, grid, dim3(256), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
-            default: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<4>, grid, dim3(256), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
+            case 1: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<1>, grid, dim3(64 * V1D_SK_WAVES), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
+            case 2: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<2>, grid, dim3(64 * V1D_SK_WAVES), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
+            case 3: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<3>, grid, dim3(64 * V1D_SK_WAVES), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
+            default: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<4>, grid, dim3(64 * V1D_SK_WAVES), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
         }
         return T2_OK;
     }
