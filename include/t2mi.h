@@ -373,7 +373,7 @@ int t2v1_postnet_trainer_update_moving_stats(t2v1_ptrainer* tr, float* flat_para
 int t2v1_postnet_trainer_export(t2v1_ptrainer* tr, const float* flat_params);
 
 /* EncoderV1(is_training=True) with the embedding in front (tacotron_v1.py:18-49, modules.py:80-91, models.py:40-47): the encoder
- * half of SingleSpeakerTacotronV1Model's training step (the V1 decoder has no backward pass: its TRAIN mode is not built).
+ * half of SingleSpeakerTacotronV1Model's training step (the decoder half: t2v1_train_decoder_* below).
  * Same trainer type, flat-buffer convention, bind / update_moving_stats / export / destroy calls as the PostNet trainer above
  * (variables: embedding, v1/encoder/...).  ids host int64 [B,T_in] (T2_ERANGE outside the table); lens host int64 [B] or NULL
  * (models.py:46-47 passes none); PreNet dropout masks from the counter-based generator (seed); memory_out dev

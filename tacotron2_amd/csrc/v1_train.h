@@ -669,8 +669,8 @@ extern "C" int t2v1_postnet_trainer_export(t2v1_ptrainer* tr, const float* flat_
 // EncoderV1(is_training=True) (tacotron_v1.py:18-49) with the embedding in front (models.py:40-47): Embedding -> two PreNets
 // (Dense + relu + dropout, modules.py:80-91; masks from the counter-based generator, streams T2_STREAM_V1_ENC_PRENET + i, step 0,
 // row = batch position, column = unit) -> CBHG with batch-statistics batch norm -- forward with a tape, and the backward pass
-// from the gradient of the encoder output down to the embedding table.  The V1 decoder has no backward pass yet, so this is
-// the encoder half of SingleSpeakerTacotronV1Model's training step.
+// from the gradient of the encoder output down to the embedding table: the encoder half of SingleSpeakerTacotronV1Model's
+// training step (the decoder half: v1_dec_train.h).
 // ==========================================================================================================================
 #define T2_STREAM_V1_ENC_PRENET 50
 

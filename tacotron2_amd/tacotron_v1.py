@@ -2,9 +2,13 @@
 DecoderV1 :94, PostNet :156), of CBHG (tacotron/modules.py:163-232) and of the two V1 model_fns
 (tacotron/models.py:15-133, :185-263) on the HIP library.  No arithmetic lives here: ``EngineV1`` binds
 the ``t2v1_*`` entry points of include/t2mi.h; the classes keep the reference's constructor arguments,
-call signatures, return values and error behaviour.  Inference arithmetic only (dropout off, batch norm
-with moving statistics): ``is_training=True`` selects the TrainingHelper exactly as the reference does
-and requires ``drop_rate == 0`` -- the reference's own test (tests/decoder_test.py:47) runs that way."""
+call signatures, return values and error behaviour.  The block classes run the inference arithmetic
+(dropout off, batch norm with moving statistics; ``DecoderV1(is_training=True)`` selects the TrainingHelper
+exactly as the reference does and requires ``drop_rate == 0`` -- the reference's own test,
+tests/decoder_test.py:47, runs that way); the training arithmetic (dropout, batch statistics, tapes, the
+hand-written backward passes) lives behind ``PostNetTrainer``, ``EncoderV1Trainer`` and ``DecoderV1Trainer``
+(``t2v1_*_train_*``), which ``PostNet(is_training=True)``, ``EncoderV1(is_training=True)`` and the TRAIN mode
+of both model_fns use."""
 from __future__ import annotations
 
 import ctypes as C
