@@ -269,10 +269,37 @@ __global__ __launch_bounds__(256) void v1d_stop_to_bs_kernel(const float* __rest
 // product (31 us each, measured); here a workgroup owns 16 output columns and all rows, its eight waves split K (k-blocks of 16
 // round robin) on v_mfma_f32_16x16x4_f32 and add their partial tiles through LDS: N / 16 workgroups, ~3 us.
 // MFMA step j of a k-block takes k = 4 kg + j from lane group kg (A: one float4 of x per lane and row block; B: W[k][n0 + c16]).
+// The elementwise stage that consumes a product rides in its epilogue (EPI): a launch of a few microseconds each, six per step
+// forward and seven backward.
+enum { SK_PLAIN = 0, SK_GATE = 1, SK_BLEND = 2, SK_BWD2 = 3, SK_BWD3 = 4, SK_DCTX = 5, SK_BWD1 = 6 };
+// stage 1 of a GRU cell's backward (v1d_bwd1_kernel) on a value the epilogue has just produced: d h' = value + add
+struct SkBwd1 {
+    const float* add = nullptr; int ldadd = 0; const float* cat = nullptr; const float* ru = nullptr; const float* cnd = nullptr; int X = 0, H = 0;
+    float* dzc = nullptr; float* dzg = nullptr; float* keep = nullptr;
+};
+__device__ __forceinline__ void sk_bwd1(const SkBwd1& q, int row, int u, float dh) {
+    if (q.add) dh += q.add[(size_t)row * q.ldadd + u];
+    const float uu = q.ru[(size_t)row * 2 * q.H + q.H + u], c = q.cnd[(size_t)row * q.H + u], h = q.cat[(size_t)row * (q.X + q.H) + q.X + u];
+    q.dzc[(size_t)row * q.H + u] = dh * (1.0f - uu) * (1.0f - c * c);
+    q.dzg[(size_t)row * 2 * q.H + q.H + u] = dh * (h - c) * uu * (1.0f - uu);
+    q.keep[(size_t)row * q.H + u] = dh * uu;
+}
+struct SkEpi {
+    const float* bias = nullptr; const float* res = nullptr; int ldr = 0;    // v = product + bias[col] + res[row][col]
+    float* y = nullptr; int ldy = 0;                                          // v itself (null: not stored)
+    const float* cat = nullptr; int X = 0, H = 0;                             // the cell's operand [x | h], row stride X + H
+    float* ru = nullptr;                                                      // [r | u], row stride 2H (written by GATE, read by the others)
+    float* catr = nullptr;                                                    // GATE: the candidate's operand [x | r h]
+    float* cnd = nullptr; V1Dst h0{nullptr, 0}, h1{nullptr, 0}, y0{nullptr, 0}, y1{nullptr, 0};   // BLEND (as v1d_blend_kernel)
+    float* dzg = nullptr; float* keep = nullptr;                              // BWD2 (as v1d_bwd2_kernel)
+    const float* dcatr = nullptr; const float* dres = nullptr; int ldres = 0; float* carry = nullptr; float* dx = nullptr; int lddx = 0;   // BWD3
+    const float* cin = nullptr; float* dctx = nullptr; long long row_stride = 0; int A = 0;      // DCTX (as v1d_dctx_kernel)
+    SkBwd1 b1x, b1c;   // BWD3: stage 1 of the cell fed by d x (same step) / of this cell one step earlier (fed by the carry); BWD1: b1x on v
+};
 #define V1D_SK_WAVES 8
-template <int MB>
+template <int MB, int EPI>
 __global__ __launch_bounds__(64 * V1D_SK_WAVES) void v1d_skinny_gemm_kernel(const float* __restrict__ x, int ldx, int K, const float* __restrict__ w, int N,
-                                                              const float* __restrict__ bias, float* y, int ldy, const float* res, int ldr, int rows) {
+                                                                            SkEpi e, int rows) {
     __shared__ f32x4 red[V1D_SK_WAVES][MB][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, c16 = lane & 15;
     const int n0 = blockIdx.x * 16, n = n0 + c16;
@@ -299,18 +326,64 @@ __global__ __launch_bounds__(64 * V1D_SK_WAVES) void v1d_skinny_gemm_kernel(cons
     }
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[wave][rb][lane] = acc[rb];
+    if constexpr (EPI == SK_GATE) {
+        // the x half of the candidate's operand is a copy: every workgroup moves its share of the rows * X words
+        const int total = rows * e.X, per = (total + (int)gridDim.x - 1) / (int)gridDim.x, Wd = e.X + e.H;
+        for (int i = blockIdx.x * per + tid; i < min(total, (int)(blockIdx.x + 1) * per); i += 64 * V1D_SK_WAVES) {
+            const int b = i / e.X, c = i - b * e.X;
+            e.catr[(size_t)b * Wd + c] = e.cat[(size_t)b * Wd + c];
+        }
+    }
     __syncthreads();
-    // D layout: reg r of lane (kg, c16) = row 4 kg + r, column c16; thread -> (row block, lane, reg)
-    for (int i = tid; i < MB * 64 * 4; i += 64 * V1D_SK_WAVES) {
-        const int r = i & 3, l = (i >> 2) & 63, rb = i >> 8;
-        const int row = rb * 16 + 4 * (l >> 4) + r, col = n0 + (l & 15);
-        if (row < rows && col < N) {
-            float v = 0.f;
+    // D layout: reg r of lane (kg, c16) = row 4 kg + r, column c16; thread -> (row, column) with the column fastest
+    for (int i = tid; i < MB * 256; i += 64 * V1D_SK_WAVES) {
+        const int c = i & 15, rr = i >> 4, rb = rr >> 4, l = ((rr >> 2) & 3) * 16 + c, r = rr & 3;
+        const int row = rr, col = n0 + c;
+        if (row >= rows || col >= N) continue;
+        float v = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < V1D_SK_WAVES; ++wv) v += red[wv][rb][l][r];
-            if (bias) v += bias[col];
-            if (res) v += res[(size_t)row * ldr + col];
-            y[(size_t)row * ldy + col] = v;
+        for (int wv = 0; wv < V1D_SK_WAVES; ++wv) v += red[wv][rb][l][r];
+        if (e.bias) v += e.bias[col];
+        if (e.res) v += e.res[(size_t)row * e.ldr + col];
+        if (e.y) e.y[(size_t)row * e.ldy + col] = v;
+        const int X = e.X, H = e.H, Wd = X + H;
+        if constexpr (EPI == SK_GATE) {                   // N = 2H: [r | u] = sigmoid(v); [x | r h]
+            const float sg = sigmoidf_(v);
+            e.ru[(size_t)row * 2 * H + col] = sg;
+            if (col < H) e.catr[(size_t)row * Wd + X + col] = sg * e.cat[(size_t)row * Wd + X + col];
+        } else if constexpr (EPI == SK_BLEND) {           // N = H: c = tanh(v); h' = u h + (1 - u) c; residual y = x + h'
+            const float cc = tanhf(v), uu = e.ru[(size_t)row * 2 * H + H + col], h = e.cat[(size_t)row * Wd + X + col];
+            const float hn = uu * h + (1.0f - uu) * cc;
+            e.cnd[(size_t)row * H + col] = cc;
+            if (e.h0.p) e.h0.p[(size_t)row * e.h0.ld + col] = hn;
+            if (e.h1.p) e.h1.p[(size_t)row * e.h1.ld + col] = hn;
+            if (e.y0.p || e.y1.p) {
+                const float yy = e.cat[(size_t)row * Wd + col] + hn;
+                if (e.y0.p) e.y0.p[(size_t)row * e.y0.ld + col] = yy;
+                if (e.y1.p) e.y1.p[(size_t)row * e.y1.ld + col] = yy;
+            }
+        } else if constexpr (EPI == SK_BWD2) {            // N = X + H: v = d [x | r h]; d zr, keep += d(r h) r
+            if (col >= X) {
+                const int u = col - X;
+                const float rg = e.ru[(size_t)row * 2 * H + u], h = e.cat[(size_t)row * Wd + col];
+                e.dzg[(size_t)row * 2 * H + u] = v * h * rg * (1.0f - rg);
+                e.keep[(size_t)row * H + u] += v * rg;
+            }
+        } else if constexpr (EPI == SK_BWD3) {            // N = X + H: v = d [x | h] of the gates' product
+            if (col < X) {
+                float g = e.dcatr[(size_t)row * Wd + col] + v;
+                if (e.dres) g += e.dres[(size_t)row * e.ldres + col];
+                e.dx[(size_t)row * e.lddx + col] = g;
+                if (e.b1x.dzc) sk_bwd1(e.b1x, row, col, g);
+            } else {
+                const float cr = e.keep[(size_t)row * H + col - X] + v;
+                e.carry[(size_t)row * H + col - X] = cr;
+                if (e.b1c.dzc) sk_bwd1(e.b1c, row, col - X, cr);
+            }
+        } else if constexpr (EPI == SK_DCTX) {            // N = A + E: v = d [h_att | ctx] of the output projection
+            if (col >= e.A) e.dctx[(size_t)row * e.row_stride + col - e.A] = v + e.cin[(size_t)row * (N - e.A) + col - e.A];
+        } else if constexpr (EPI == SK_BWD1) {
+            sk_bwd1(e.b1x, row, col, v);
         }
     }
 }
@@ -331,7 +404,7 @@ struct t2v1_dtrainer {
     float *zg, *zc, *mel_sb, *stop_sb, *mel_bt, *stop_bs, *loss6;
     // backward
     float *dmel_sb, *dstop_sb, *DY2, *DZG2, *DZC2, *DZG1, *DZC1, *DY0, *DQ, *DZGa, *DZCa, *DCTX, *dkeys, *dvpart, *dvalues;
-    float *cHA, *cCTX, *cH1, *cH2, *keep, *dcatr, *dcat, *dy1, *dy0, *dcato, *dha, *dP1, *dP0;
+    float *cHA, *cCTX, *cH1, *cH2, *keep, *keep1, *keepA, *dcatr, *dcat, *dy1, *dy0, *dcato, *dha, *dP1, *dP0;
     float *WmT, *WsT, *Wg2T, *Wc2T, *Wg1T, *Wc1T, *WoT, *WqT, *WgaT, *WcaT, *WgpT, *WcpT, *Wp1T, *WmemT;
     // the two recurrence loops as hipGraphs (S x 15 / S x 17 launches each): every pointer in them is the trainer's own or lies in
     // the flat parameter buffer, so a graph stays valid as long as that buffer's address does
@@ -407,7 +480,7 @@ extern "C" int t2v1_decoder_trainer_create(t2v1_model* m, int B, int T_in, int S
     want(&tr->DZG1, SB * 2 * D); want(&tr->DZC1, SB * D); want(&tr->DY0, SB * D); want(&tr->DQ, SB * A); want(&tr->DZGa, SB * 2 * A); want(&tr->DZCa, SB * A);
     want(&tr->DCTX, SB * E); want(&tr->dkeys, BT * A); want(&tr->dvpart, (size_t)B * A); want(&tr->dvalues, BT * E);
     want(&tr->cHA, (size_t)B * A); want(&tr->cCTX, (size_t)B * E); want(&tr->cH1, (size_t)B * D); want(&tr->cH2, (size_t)B * D);
-    want(&tr->keep, (size_t)B * Hmax); want(&tr->dcatr, (size_t)B * Wmax); want(&tr->dcat, (size_t)B * Wmax);
+    want(&tr->keep, (size_t)B * Hmax); want(&tr->keep1, (size_t)B * Hmax); want(&tr->keepA, (size_t)B * Hmax); want(&tr->dcatr, (size_t)B * Wmax); want(&tr->dcat, (size_t)B * Wmax);
     want(&tr->dy1, (size_t)B * D); want(&tr->dy0, (size_t)B * D); want(&tr->dcato, (size_t)B * (A + E)); want(&tr->dha, (size_t)B * A);
     want(&tr->dP1, SB * P1); want(&tr->dP0, SB * P0);
     want(&tr->WmT, rM * D); want(&tr->WsT, D); want(&tr->Wg2T, 2 * D * 2 * D); want(&tr->Wc2T, D * 2 * D); want(&tr->Wg1T, 2 * D * 2 * D); want(&tr->Wc1T, D * 2 * D);
@@ -434,23 +507,51 @@ extern "C" int t2v1_decoder_trainer_set_loss_counts(t2v1_dtrainer* tr, const flo
     return T2_OK;
 }
 
+static inline bool dt_skinny_ok(t2v1_dtrainer* tr, const float* x, int ldx, int K, int rows) {
+    return rows <= 64 && K % 16 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && tr->m->opt_skinny;
+}
+template <int EPI>
+static void dt_skinny(t2v1_dtrainer* tr, const float* x, int ldx, int K, const float* w, int N, const SkEpi& e, int rows) {
+    hipStream_t st = tr->m->base.ctx->stream;
+    const dim3 grid(ceil_div(N, 16)), blk(64 * V1D_SK_WAVES);
+    switch (ceil_div(rows, 16)) {
+        case 1: hipLaunchKernelGGL((v1d_skinny_gemm_kernel<1, EPI>), grid, blk, 0, st, x, ldx, K, w, N, e, rows); break;
+        case 2: hipLaunchKernelGGL((v1d_skinny_gemm_kernel<2, EPI>), grid, blk, 0, st, x, ldx, K, w, N, e, rows); break;
+        case 3: hipLaunchKernelGGL((v1d_skinny_gemm_kernel<3, EPI>), grid, blk, 0, st, x, ldx, K, w, N, e, rows); break;
+        default: hipLaunchKernelGGL((v1d_skinny_gemm_kernel<4, EPI>), grid, blk, 0, st, x, ldx, K, w, N, e, rows); break;
+    }
+}
 // y [B][N] (row stride ldy) = x [B][K] (row stride ldx) . w [K][N] (+ bias) (+ res): the small per-step products
 static int dt_gemm(t2v1_dtrainer* tr, const float* x, int ldx, int K, const float* w, int N, const float* bias, float* y, int ldy, const float* res, int ldr,
                    int rows) {
-    if (rows <= 64 && K % 16 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && tr->m->opt_skinny) {
-        hipStream_t st = tr->m->base.ctx->stream;
-        const dim3 grid(ceil_div(N, 16));
-        switch (ceil_div(rows, 16)) {
-            case 1: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<1>, grid, dim3(64 * V1D_SK_WAVES), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
-            case 2: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<2>, grid, dim3(64 * V1D_SK_WAVES), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
-            case 3: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<3>, grid, dim3(64 * V1D_SK_WAVES), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
-            default: hipLaunchKernelGGL(v1d_skinny_gemm_kernel<4>, grid, dim3(64 * V1D_SK_WAVES), 0, st, x, ldx, K, w, N, bias, y, ldy, res, ldr, rows); break;
-        }
+    if (dt_skinny_ok(tr, x, ldx, K, rows)) {
+        SkEpi e; e.bias = bias; e.res = res; e.ldr = ldr; e.y = y; e.ldy = ldy;
+        dt_skinny<SK_PLAIN>(tr, x, ldx, K, w, N, e, rows);
         return T2_OK;
     }
     ConvLayer L{};
     L.w = const_cast<float*>(w); L.shift = const_cast<float*>(bias); L.k = 1; L.cin = K; L.cout = N;
     return launch_conv(&tr->m->base, L, x, ldx, y, ldy, rows, rows, 0, res, ldr);
+}
+// GRUCell forward of one step on the operand cat = [x | h]: gates product (+ bias, + the batched share zgp) ->
+// [r | u] tape, catr = [x | r h]; candidate product -> c tape, h' (and the residual y = x + h') to their destinations.  Two launches
+// on the skinny path, four otherwise.
+static int dt_gru_fwd(t2v1_dtrainer* tr, const float* cat, float* catr, int X, int H, const float* Wg, const float* bg, const float* zgp, const float* Wc,
+                      const float* bc, const float* zcp, float* ru, float* cnd, V1Dst h0, V1Dst h1, V1Dst y0, V1Dst y1) {
+    hipStream_t st = tr->m->base.ctx->stream;
+    const int B = tr->B, Wd = X + H;
+    if (dt_skinny_ok(tr, cat, Wd, Wd, B) && dt_skinny_ok(tr, catr, Wd, Wd, B)) {
+        SkEpi g; g.bias = bg; g.res = zgp; g.ldr = 2 * H; g.cat = cat; g.X = X; g.H = H; g.ru = ru; g.catr = catr;
+        dt_skinny<SK_GATE>(tr, cat, Wd, Wd, Wg, 2 * H, g, B);
+        SkEpi c; c.bias = bc; c.res = zcp; c.ldr = H; c.cat = cat; c.X = X; c.H = H; c.ru = ru; c.cnd = cnd; c.h0 = h0; c.h1 = h1; c.y0 = y0; c.y1 = y1;
+        dt_skinny<SK_BLEND>(tr, catr, Wd, Wd, Wc, H, c, B);
+        return T2_OK;
+    }
+    T2_TRY(dt_gemm(tr, cat, Wd, Wd, Wg, 2 * H, bg, tr->zg, 2 * H, zgp, 2 * H, B));
+    hipLaunchKernelGGL(v1d_gate_kernel, dt_grid((long long)B * (Wd + H)), dim3(256), 0, st, tr->zg, cat, X, H, ru, catr, B);
+    T2_TRY(dt_gemm(tr, catr, Wd, Wd, Wc, H, bc, tr->zc, H, zcp, H, B));
+    hipLaunchKernelGGL(v1d_blend_kernel, dt_grid((long long)B * H), dim3(256), 0, st, tr->zc, ru, cat, X, H, cnd, h0, h1, y0, y1, B);
+    return T2_OK;
 }
 static void dt_transpose(t2v1_dtrainer* tr, const float* src, float* dst, int R, int C) {      // src [R][C] -> dst [C][R]
     hipLaunchKernelGGL(transpose_kernel, dt_grid((long long)R * C), dim3(256), 0, tr->m->base.ctx->stream, dst, R, src, C, C, R);
@@ -514,11 +615,9 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
         float *cat1 = tr->CAT1 + (size_t)t * B * 2 * D, *cat1_n = cat1 + (size_t)B * 2 * D, *cat1r = tr->CAT1R + (size_t)t * B * 2 * D;
         float *cat2 = tr->CAT2 + (size_t)t * B * 2 * D, *cat2_n = cat2 + (size_t)B * 2 * D, *cat2r = tr->CAT2R + (size_t)t * B * 2 * D;
         // attention GRU on [p1_t | ctx_{t-1}] (AttentionWrapper, App. A6): the p1 rows of the kernels were applied above
-        T2_TRY(dt_gemm(tr, cata, XA, XA, Wga + (size_t)P1 * 2 * A, 2 * A, nullptr, tr->zg, 2 * A, tr->zgp + (size_t)t * B * 2 * A, 2 * A, B));
-        hipLaunchKernelGGL(v1d_gate_kernel, dt_grid((long long)B * (XA + A)), dim3(256), 0, st, tr->zg, cata, E, A, tr->RUa + (size_t)t * B * 2 * A, catar, B);
-        T2_TRY(dt_gemm(tr, catar, XA, XA, Wca + (size_t)P1 * A, A, nullptr, tr->zc, A, tr->zcp + (size_t)t * B * A, A, B));
-        hipLaunchKernelGGL(v1d_blend_kernel, dt_grid((long long)B * A), dim3(256), 0, st, tr->zc, tr->RUa + (size_t)t * B * 2 * A, cata, E, A, tr->Ca + (size_t)t * B * A,
-                           V1Dst{cato, A + E}, V1Dst{cata_n + E, XA}, V1Dst{nullptr, 0}, V1Dst{nullptr, 0}, B);
+        T2_TRY(dt_gru_fwd(tr, cata, catar, E, A, Wga + (size_t)P1 * 2 * A, nullptr, tr->zgp + (size_t)t * B * 2 * A, Wca + (size_t)P1 * A, nullptr,
+                          tr->zcp + (size_t)t * B * A, tr->RUa + (size_t)t * B * 2 * A, tr->Ca + (size_t)t * B * A, V1Dst{cato, A + E}, V1Dst{cata_n + E, XA},
+                          V1Dst{nullptr, 0}, V1Dst{nullptr, 0}));
         // Bahdanau attention
         float* q = tr->Q + (size_t)t * B * A;
         T2_TRY(dt_gemm(tr, cato, A + E, A, Wq, A, nullptr, q, A, nullptr, 0, B));
@@ -527,16 +626,10 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
         // OutputProjectionWrapper on [h_att | ctx] -> y0 = the x half of GRU 1's operand
         T2_TRY(dt_gemm(tr, cato, A + E, A + E, Wo, D, bo, cat1, 2 * D, nullptr, 0, B));
         // ResidualWrapper(GRUCell) x 2
-        T2_TRY(dt_gemm(tr, cat1, 2 * D, 2 * D, Wg1, 2 * D, bg1, tr->zg, 2 * D, nullptr, 0, B));
-        hipLaunchKernelGGL(v1d_gate_kernel, dt_grid((long long)B * 3 * D), dim3(256), 0, st, tr->zg, cat1, D, D, tr->RU1 + (size_t)t * B * 2 * D, cat1r, B);
-        T2_TRY(dt_gemm(tr, cat1r, 2 * D, 2 * D, Wc1, D, bc1, tr->zc, D, nullptr, 0, B));
-        hipLaunchKernelGGL(v1d_blend_kernel, dt_grid((long long)B * D), dim3(256), 0, st, tr->zc, tr->RU1 + (size_t)t * B * 2 * D, cat1, D, D, tr->C1 + (size_t)t * B * D,
-                           V1Dst{cat1_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{cat2, 2 * D}, V1Dst{nullptr, 0}, B);
-        T2_TRY(dt_gemm(tr, cat2, 2 * D, 2 * D, Wg2, 2 * D, bg2, tr->zg, 2 * D, nullptr, 0, B));
-        hipLaunchKernelGGL(v1d_gate_kernel, dt_grid((long long)B * 3 * D), dim3(256), 0, st, tr->zg, cat2, D, D, tr->RU2 + (size_t)t * B * 2 * D, cat2r, B);
-        T2_TRY(dt_gemm(tr, cat2r, 2 * D, 2 * D, Wc2, D, bc2, tr->zc, D, nullptr, 0, B));
-        hipLaunchKernelGGL(v1d_blend_kernel, dt_grid((long long)B * D), dim3(256), 0, st, tr->zc, tr->RU2 + (size_t)t * B * 2 * D, cat2, D, D, tr->C2 + (size_t)t * B * D,
-                           V1Dst{cat2_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{tr->Y2 + (size_t)t * B * D, D}, V1Dst{nullptr, 0}, B);
+        T2_TRY(dt_gru_fwd(tr, cat1, cat1r, D, D, Wg1, bg1, nullptr, Wc1, bc1, nullptr, tr->RU1 + (size_t)t * B * 2 * D, tr->C1 + (size_t)t * B * D,
+                          V1Dst{cat1_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{cat2, 2 * D}, V1Dst{nullptr, 0}));
+        T2_TRY(dt_gru_fwd(tr, cat2, cat2r, D, D, Wg2, bg2, nullptr, Wc2, bc2, nullptr, tr->RU2 + (size_t)t * B * 2 * D, tr->C2 + (size_t)t * B * D,
+                          V1Dst{cat2_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{tr->Y2 + (size_t)t * B * D, D}, V1Dst{nullptr, 0}));
     }
     return T2_OK;
     }));
@@ -555,14 +648,26 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
 
 // one GRU cell backward (three elementwise stages around two GEMMs); dz tapes written for the weight gradients
 static int dt_gru_bwd(t2v1_dtrainer* tr, const float* d0, int ld0, const float* d1, int ld1, const float* cat, const float* ru, const float* cnd, int X, int H,
-                      const float* WcT, const float* WgT, float* dzc, float* dzg, const float* dres, int ldres, float* carry, float* dx, int lddx) {
+                      const float* WcT, const float* WgT, float* dzc, float* dzg, const float* dres, int ldres, float* carry, float* dx, int lddx,
+                      float* keep = nullptr, bool stage1_done = false, const SkBwd1* b1x = nullptr, const SkBwd1* b1c = nullptr) {
     hipStream_t st = tr->m->base.ctx->stream;
     const int B = tr->B, Wd = X + H;
-    hipLaunchKernelGGL(v1d_bwd1_kernel, dt_grid((long long)B * H), dim3(256), 0, st, d0, ld0, d1, ld1, cat, ru, cnd, X, H, dzc, dzg, tr->keep, B);
+    if (!keep) keep = tr->keep;
+    if (!stage1_done) hipLaunchKernelGGL(v1d_bwd1_kernel, dt_grid((long long)B * H), dim3(256), 0, st, d0, ld0, d1, ld1, cat, ru, cnd, X, H, dzc, dzg, keep, B);
+    if (dt_skinny_ok(tr, dzc, H, H, B) && dt_skinny_ok(tr, dzg, 2 * H, 2 * H, B)) {          // stages 2 and 3 in the products' epilogues
+        SkEpi e2; e2.y = tr->dcatr; e2.ldy = Wd; e2.cat = cat; e2.X = X; e2.H = H; e2.ru = const_cast<float*>(ru); e2.dzg = dzg; e2.keep = keep;
+        dt_skinny<SK_BWD2>(tr, dzc, H, H, WcT, Wd, e2, B);
+        SkEpi e3; e3.X = X; e3.H = H; e3.dcatr = tr->dcatr; e3.dres = dres; e3.ldres = ldres; e3.keep = keep; e3.carry = carry; e3.dx = dx; e3.lddx = lddx;
+        if (b1x) e3.b1x = *b1x;
+        if (b1c) e3.b1c = *b1c;
+        dt_skinny<SK_BWD3>(tr, dzg, 2 * H, 2 * H, WgT, Wd, e3, B);
+        return T2_OK;
+    }
+    if (stage1_done || b1x || b1c) return fail(T2_ESTATE, "internal: fused GRU backward stages outside the skinny path");
     T2_TRY(dt_gemm(tr, dzc, H, H, WcT, Wd, nullptr, tr->dcatr, Wd, nullptr, 0, B));
-    hipLaunchKernelGGL(v1d_bwd2_kernel, dt_grid((long long)B * H), dim3(256), 0, st, tr->dcatr, cat, ru, X, H, dzg, tr->keep, B);
+    hipLaunchKernelGGL(v1d_bwd2_kernel, dt_grid((long long)B * H), dim3(256), 0, st, tr->dcatr, cat, ru, X, H, dzg, keep, B);
     T2_TRY(dt_gemm(tr, dzg, 2 * H, 2 * H, WgT, Wd, nullptr, tr->dcat, Wd, nullptr, 0, B));
-    hipLaunchKernelGGL(v1d_bwd3_kernel, dt_grid((long long)B * Wd), dim3(256), 0, st, tr->dcatr, tr->dcat, tr->keep, dres, ldres, X, H, carry, dx, lddx, B);
+    hipLaunchKernelGGL(v1d_bwd3_kernel, dt_grid((long long)B * Wd), dim3(256), 0, st, tr->dcatr, tr->dcat, keep, dres, ldres, X, H, carry, dx, lddx, B);
     return T2_OK;
 }
 
@@ -616,29 +721,66 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
     HIP_TRY(hipMemsetAsync(tr->cH1, 0, (size_t)B * D * 4, st)); HIP_TRY(hipMemsetAsync(tr->cH2, 0, (size_t)B * D * 4, st));
     HIP_TRY(hipMemsetAsync(tr->dkeys, 0, (size_t)B * T * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->dvpart, 0, (size_t)B * A * 4, st));
     const size_t attn_lds = (size_t)(E + T + 8 * A) * 4;
+    // every per-step product on the skinny path (B <= 64, widths multiples of 16): stage 1 of the cells fused as well
+    const bool fused = dt_skinny_ok(tr, tr->DZC2, D, D, B) && dt_skinny_ok(tr, tr->DZG2, 2 * D, 2 * D, B) && dt_skinny_ok(tr, tr->DQ, A, A, B) &&
+                       dt_skinny_ok(tr, tr->DZCa, A, A, B) && dt_skinny_ok(tr, tr->DZGa, 2 * A, 2 * A, B) && (B * D) % 4 == 0 && (B * A) % 4 == 0;
     T2_TRY(dt_run_loop(tr, 1, [&]() -> int {
     for (int t = S - 1; t >= 0; --t) {
-        const float *cata = tr->CATA + (size_t)t * B * XA, *cato = tr->CATO + (size_t)t * B * (A + E);
+        const float* cata = tr->CATA + (size_t)t * B * XA;
         const float *cat1 = tr->CAT1 + (size_t)t * B * 2 * D, *cat2 = tr->CAT2 + (size_t)t * B * 2 * D;
         const float* dy2 = tr->DY2 + (size_t)t * B * D;
         // y2 = y1 + h2': d h2' = d y2 + carry; d y1 = d y2 + d x
+        float* dy0 = tr->DY0 + (size_t)t * B * D;
+        if (fused) {
+            // stage 1 of a cell rides in the epilogue that produces its d h': GRU 2 of step t - 1 behind this step's carry,
+            // GRU 1 behind this step's d y1, the attention GRU behind the query layer's product
+            if (t == S - 1)
+                hipLaunchKernelGGL(v1d_bwd1_kernel, dt_grid((long long)B * D), dim3(256), 0, st, dy2, D, tr->cH2, D, cat2, tr->RU2 + (size_t)t * B * 2 * D,
+                                   tr->C2 + (size_t)t * B * D, D, D, tr->DZC2 + (size_t)t * B * D, tr->DZG2 + (size_t)t * B * 2 * D, tr->keep, B);
+            SkBwd1 s1; s1.add = tr->cH1; s1.ldadd = D; s1.cat = cat1; s1.ru = tr->RU1 + (size_t)t * B * 2 * D; s1.cnd = tr->C1 + (size_t)t * B * D; s1.X = D; s1.H = D;
+            s1.dzc = tr->DZC1 + (size_t)t * B * D; s1.dzg = tr->DZG1 + (size_t)t * B * 2 * D; s1.keep = tr->keep1;
+            SkBwd1 s2;
+            if (t > 0) {
+                const size_t u = (size_t)(t - 1);
+                s2.add = tr->DY2 + u * B * D; s2.ldadd = D; s2.cat = tr->CAT2 + u * B * 2 * D; s2.ru = tr->RU2 + u * B * 2 * D; s2.cnd = tr->C2 + u * B * D; s2.X = D; s2.H = D;
+                s2.dzc = tr->DZC2 + u * B * D; s2.dzg = tr->DZG2 + u * B * 2 * D; s2.keep = tr->keep;
+            }
+            T2_TRY(dt_gru_bwd(tr, nullptr, 0, nullptr, 0, cat2, tr->RU2 + (size_t)t * B * 2 * D, tr->C2 + (size_t)t * B * D, D, D, tr->Wc2T, tr->Wg2T,
+                              tr->DZC2 + (size_t)t * B * D, tr->DZG2 + (size_t)t * B * 2 * D, dy2, D, tr->cH2, tr->dy1, D, tr->keep, true, &s1, t > 0 ? &s2 : nullptr));
+            T2_TRY(dt_gru_bwd(tr, nullptr, 0, nullptr, 0, cat1, tr->RU1 + (size_t)t * B * 2 * D, tr->C1 + (size_t)t * B * D, D, D, tr->Wc1T, tr->Wg1T,
+                              tr->DZC1 + (size_t)t * B * D, tr->DZG1 + (size_t)t * B * 2 * D, tr->dy1, D, tr->cH1, dy0, D, tr->keep1, true));
+        } else {
         T2_TRY(dt_gru_bwd(tr, dy2, D, tr->cH2, D, cat2, tr->RU2 + (size_t)t * B * 2 * D, tr->C2 + (size_t)t * B * D, D, D, tr->Wc2T, tr->Wg2T,
                           tr->DZC2 + (size_t)t * B * D, tr->DZG2 + (size_t)t * B * 2 * D, dy2, D, tr->cH2, tr->dy1, D));
-        float* dy0 = tr->DY0 + (size_t)t * B * D;
         T2_TRY(dt_gru_bwd(tr, tr->dy1, D, tr->cH1, D, cat1, tr->RU1 + (size_t)t * B * 2 * D, tr->C1 + (size_t)t * B * D, D, D, tr->Wc1T, tr->Wg1T,
                           tr->DZC1 + (size_t)t * B * D, tr->DZG1 + (size_t)t * B * 2 * D, tr->dy1, D, tr->cH1, dy0, D));
+        }
         // output projection: d [h_att | ctx]
-        T2_TRY(dt_gemm(tr, dy0, D, D, tr->WoT, A + E, nullptr, tr->dcato, A + E, nullptr, 0, B));
         float* dctx_t = tr->DCTX + (size_t)t * E;                       // tape [B][S][E]
-        hipLaunchKernelGGL(v1d_dctx_kernel, dt_grid((long long)B * E), dim3(256), 0, st, tr->dcato, A, E, tr->cCTX, dctx_t, (long long)S * E, B);
+        if (dt_skinny_ok(tr, dy0, D, D, B)) {
+            SkEpi e; e.y = tr->dcato; e.ldy = A + E; e.cin = tr->cCTX; e.dctx = dctx_t; e.row_stride = (long long)S * E; e.A = A;
+            dt_skinny<SK_DCTX>(tr, dy0, D, D, tr->WoT, A + E, e, B);
+        } else {
+            T2_TRY(dt_gemm(tr, dy0, D, D, tr->WoT, A + E, nullptr, tr->dcato, A + E, nullptr, 0, B));
+            hipLaunchKernelGGL(v1d_dctx_kernel, dt_grid((long long)B * E), dim3(256), 0, st, tr->dcato, A, E, tr->cCTX, dctx_t, (long long)S * E, B);
+        }
         float* dq = tr->DQ + (size_t)t * B * A;
         hipLaunchKernelGGL(v1d_attn_bwd_kernel, dim3(B), dim3(V1D_ATT_THREADS), attn_lds, st, tr->keys, tr->values, tr->Q + (size_t)t * B * A, va, tr->lens,
                            tr->ALIGN + (size_t)t * B * T, dctx_t, (long long)S * E, T, A, E, dq, tr->dkeys, tr->dvpart);
         // d h_att = output projection's share + d q . Wq^T (+ the carry, added in stage 1)
-        T2_TRY(dt_gemm(tr, dq, A, A, tr->WqT, A, nullptr, tr->dha, A, tr->dcato, A + E, B));
         // attention GRU on [p1 | ctx_{t-1}]: d ctx_{t-1} -> carry; the p1 share is batched after the loop
+        if (fused) {
+            SkEpi e; e.res = tr->dcato; e.ldr = A + E;
+            e.b1x.add = tr->cHA; e.b1x.ldadd = A; e.b1x.cat = cata; e.b1x.ru = tr->RUa + (size_t)t * B * 2 * A; e.b1x.cnd = tr->Ca + (size_t)t * B * A; e.b1x.X = E; e.b1x.H = A;
+            e.b1x.dzc = tr->DZCa + (size_t)t * B * A; e.b1x.dzg = tr->DZGa + (size_t)t * B * 2 * A; e.b1x.keep = tr->keepA;
+            dt_skinny<SK_BWD1>(tr, dq, A, A, tr->WqT, A, e, B);
+            T2_TRY(dt_gru_bwd(tr, nullptr, 0, nullptr, 0, cata, tr->RUa + (size_t)t * B * 2 * A, tr->Ca + (size_t)t * B * A, E, A, tr->WcaT, tr->WgaT,
+                              tr->DZCa + (size_t)t * B * A, tr->DZGa + (size_t)t * B * 2 * A, nullptr, 0, tr->cHA, tr->cCTX, E, tr->keepA, true));
+        } else {
+        T2_TRY(dt_gemm(tr, dq, A, A, tr->WqT, A, nullptr, tr->dha, A, tr->dcato, A + E, B));
         T2_TRY(dt_gru_bwd(tr, tr->dha, A, tr->cHA, A, cata, tr->RUa + (size_t)t * B * 2 * A, tr->Ca + (size_t)t * B * A, E, A, tr->WcaT, tr->WgaT,
                           tr->DZCa + (size_t)t * B * A, tr->DZGa + (size_t)t * B * 2 * A, nullptr, 0, tr->cHA, tr->cCTX, E));
+        }
     }
     return T2_OK;
     }));
