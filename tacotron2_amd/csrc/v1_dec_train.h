@@ -69,28 +69,41 @@ __global__ __launch_bounds__(256) void v1d_blend_kernel(const float* __restrict_
     }
 }
 // BahdanauAttention.__call__ + AttentionWrapper._compute_attention (App. A5, A6) of one batch row per workgroup of 16 waves:
-// score_j = v . tanh(keys_j + q) (a wave per position), softmax over the live positions (-inf mask), context = sum_j a_j values_j
-// (four position groups per context column, added in group order).  tanh on the hardware exp / rcp (fast_tanhf, ~1e-6); the
-// backward kernel uses the same function.
+// score_j = v . tanh(keys_j + q), softmax over the live positions (-inf mask), context = sum_j a_j values_j.  Wave w owns the
+// positions j = w (mod 16) in both sweeps, a lane the features lane + 64 i; three positions are in flight per wave (the loads of a
+// sweep are independent: issued together, clamped instead of branched), partial contexts of the 16 waves are added in wave order.
+// tanh on the hardware exp / rcp (fast_tanhf, ~1e-6); the backward kernel uses the same function.
 #define V1D_ATT_THREADS 1024
+#define V1D_ATT_U 3
 __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_fwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
                                                                        const float* __restrict__ v, const int* __restrict__ lens, int T, int A, int E,
                                                                        float* __restrict__ align, V1Dst c0, V1Dst c1) {
     extern __shared__ float sm[];
-    float *s_q = sm, *s_v = sm + A, *s_e = sm + 2 * A, *s_part = sm + 2 * A + T;        // s_part [4][E]
+    constexpr int NW = V1D_ATT_THREADS / 64, U = V1D_ATT_U;
+    float *s_q = sm, *s_v = sm + A, *s_e = sm + 2 * A, *s_part = sm + 2 * A + T;        // s_part [NW][E]
     __shared__ float s_red[32];
-    constexpr int NW = V1D_ATT_THREADS / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = lens[b];
     for (int u = tid; u < A; u += V1D_ATT_THREADS) { s_q[u] = q[(size_t)b * A + u]; s_v[u] = v[u]; }
     __syncthreads();
-    for (int j = wave; j < len; j += NW) {
-        const float* k = keys + ((size_t)b * T + j) * A;
-        float p = 0.f;
-        for (int u = lane; u < A; u += 64) p += s_v[u] * fast_tanhf(k[u] + s_q[u]);
+    for (int j0 = wave; j0 < len; j0 += NW * U) {
+        float p[U];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
-        if (lane == 0) s_e[j] = p;
+        for (int i = 0; i < U; ++i) p[i] = 0.f;
+        for (int u = lane; u < A; u += 64) {
+            float kk[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) kk[i] = keys[((size_t)b * T + min(j0 + i * NW, len - 1)) * A + u];
+            const float qv = s_q[u], vv = s_v[u];
+#pragma unroll
+            for (int i = 0; i < U; ++i) p[i] += vv * fast_tanhf(kk[i] + qv);
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) p[i] += __shfl_xor(p[i], off);
+            if (lane == 0 && j0 + i * NW < len) s_e[j0 + i * NW] = p[i];
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -111,40 +124,67 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_fwd_kernel(const flo
     for (int w = 0; w < NW; ++w) sum += s_red[NW + w];
     for (int j = tid; j < T; j += V1D_ATT_THREADS) { const float p = s_e[j] / sum; s_e[j] = p; align[(size_t)b * T + j] = p; }
     __syncthreads();
-    const int g = tid >> 8;
-    for (int e = tid & 255; e < E; e += 256) {
-        float acc = 0.f;
-        for (int j = g; j < len; j += 4) acc = fmaf(s_e[j], values[((size_t)b * T + j) * E + e], acc);
-        s_part[g * E + e] = acc;
+    for (int e0 = 0; e0 < E; e0 += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = wave; j0 < len; j0 += NW * U) {
+            float vv[U][4];
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vv[i][c] = values[((size_t)b * T + min(j0 + i * NW, len - 1)) * E + min(e0 + lane + 64 * c, E - 1)];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const float a = j0 + i * NW < len ? s_e[j0 + i * NW] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(a, vv[i][c], acc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (e0 + lane + 64 * c < E) s_part[wave * E + e0 + lane + 64 * c] = acc[c];
     }
     __syncthreads();
     for (int e = tid; e < E; e += V1D_ATT_THREADS) {
-        const float acc = (s_part[e] + s_part[E + e]) + (s_part[2 * E + e] + s_part[3 * E + e]);
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += s_part[w * E + e];
         if (c0.p) c0.p[(size_t)b * c0.ld + e] = acc;
         if (c1.p) c1.p[(size_t)b * c1.ld + e] = acc;
     }
 }
 // its backward for one row: d a_j = d ctx . values_j; softmax backward; d q = sum_j g_j, d keys_j += g_j, d v += sum_j d e_j tanh_j
 // with g_ju = d e_j v_u (1 - tanh_ju^2).  (d values is a tape-wide product afterwards; the Bahdanau state is not fed back.)
+// Same ownership as the forward kernel; partial d q / d v of the 16 waves are added in wave order.
 __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_bwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
                                                                        const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align,
                                                                        const float* __restrict__ dctx, long long dctx_row_stride, int T, int A, int E,
                                                                        float* __restrict__ dq, float* __restrict__ dkeys, float* __restrict__ dvpart) {
     extern __shared__ float sm[];
-    float *s_dc = sm, *s_de = sm + E, *s_pq = sm + E + T, *s_pv = s_pq + 4 * A;          // partial d q / d v [4][A]
+    constexpr int NW = V1D_ATT_THREADS / 64, U = V1D_ATT_U;
+    float *s_dc = sm, *s_de = sm + E, *s_pq = sm + E + T, *s_pv = s_pq + NW * A;          // partial d q / d v [NW][A]
     __shared__ float s_red[16];
-    constexpr int NW = V1D_ATT_THREADS / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = lens[b];
     for (int e = tid; e < E; e += V1D_ATT_THREADS) s_dc[e] = dctx[(size_t)b * dctx_row_stride + e];
     __syncthreads();
-    for (int j = wave; j < len; j += NW) {
-        const float* vj = values + ((size_t)b * T + j) * E;
-        float p = 0.f;
-        for (int e = lane; e < E; e += 64) p += s_dc[e] * vj[e];
+    for (int j0 = wave; j0 < len; j0 += NW * U) {
+        float p[U];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
-        if (lane == 0) s_de[j] = p;
+        for (int i = 0; i < U; ++i) p[i] = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            float vv[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) vv[i] = values[((size_t)b * T + min(j0 + i * NW, len - 1)) * E + e];
+            const float dc = s_dc[e];
+#pragma unroll
+            for (int i = 0; i < U; ++i) p[i] += dc * vv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) p[i] += __shfl_xor(p[i], off);
+            if (lane == 0 && j0 + i * NW < len) s_de[j0 + i * NW] = p[i];
+        }
     }
     __syncthreads();
     float s = 0.f;
@@ -158,23 +198,43 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_bwd_kernel(const flo
     __syncthreads();
     for (int j = tid; j < len; j += V1D_ATT_THREADS) s_de[j] = align[(size_t)b * T + j] * (s_de[j] - s);
     __syncthreads();
-    const int g = tid >> 8;
-    for (int u = tid & 255; u < A; u += 256) {
-        const float qu = q[(size_t)b * A + u], vu = v[u];
-        float aq = 0.f, av = 0.f;
-        for (int j = g; j < len; j += 4) {
-            const size_t ki = ((size_t)b * T + j) * A + u;
-            const float th = fast_tanhf(keys[ki] + qu), de = s_de[j];
-            const float gg = de * vu * (1.0f - th * th);
-            aq += gg; av += de * th;
-            dkeys[ki] += gg;
+    for (int u0 = 0; u0 < A; u0 += 256) {
+        float aq[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f}, qu[4], vu[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int u = min(u0 + lane + 64 * c, A - 1); qu[c] = q[(size_t)b * A + u]; vu[c] = v[u]; }
+        for (int j0 = wave; j0 < len; j0 += NW * U) {
+            float kk[U][4], dk[U][4];
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const size_t ki = ((size_t)b * T + min(j0 + i * NW, len - 1)) * A + min(u0 + lane + 64 * c, A - 1);
+                    kk[i][c] = keys[ki]; dk[i][c] = dkeys[ki];
+                }
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const bool live = j0 + i * NW < len;
+                const float de = live ? s_de[j0 + i * NW] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float th = fast_tanhf(kk[i][c] + qu[c]);
+                    const float gg = de * vu[c] * (1.0f - th * th);
+                    aq[c] += gg; av[c] += de * th;
+                    if (live && u0 + lane + 64 * c < A) dkeys[((size_t)b * T + j0 + i * NW) * A + u0 + lane + 64 * c] = dk[i][c] + gg;
+                }
+            }
         }
-        s_pq[g * A + u] = aq; s_pv[g * A + u] = av;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (u0 + lane + 64 * c < A) { s_pq[wave * A + u0 + lane + 64 * c] = aq[c]; s_pv[wave * A + u0 + lane + 64 * c] = av[c]; }
     }
     __syncthreads();
     for (int u = tid; u < A; u += V1D_ATT_THREADS) {
-        dq[(size_t)b * A + u] = (s_pq[u] + s_pq[A + u]) + (s_pq[2 * A + u] + s_pq[3 * A + u]);
-        dvpart[(size_t)b * A + u] += (s_pv[u] + s_pv[A + u]) + (s_pv[2 * A + u] + s_pv[3 * A + u]);
+        float aq = 0.f, av = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { aq += s_pq[w * A + u]; av += s_pv[w * A + u]; }
+        dq[(size_t)b * A + u] = aq;
+        dvpart[(size_t)b * A + u] += av;
     }
 }
 // GRU cell backward, stage 1: d h' = d0 (+ d1) -> d zc, d zu, and the part of d h that does not pass a GEMM (d h' u)
@@ -458,6 +518,12 @@ extern "C" int t2v1_decoder_trainer_create(t2v1_model* m, int B, int T_in, int S
     if (!out || S < 1) return fail(T2_EINVAL, "bad argument");
     T2_TRY(check_batch(B, T_in));
     const t2v1_dims& d = m->d;
+    {   // the attention kernels keep a row's query, scores and the 16 waves' partial sums in LDS (64 KB without opting in to more)
+        const size_t NW = V1D_ATT_THREADS / 64, A = d.attention_out_units, E = d.cbhg_out_units;
+        const size_t lds = std::max((2 * A + T_in + NW * E) * 4, (E + T_in + 2 * NW * A) * 4);
+        if (lds > 64 * 1024) return fail(T2_EINVAL, "T_in = %d with attention width %d / memory width %d needs %zu bytes of LDS per attention workgroup (limit 65536)",
+                                         T_in, (int)A, (int)E, lds);
+    }
     HIP_TRY(hipSetDevice(m->base.ctx->device));
     t2v1_dtrainer* tr = new t2v1_dtrainer();
     tr->m = m; tr->B = B; tr->T = T_in; tr->S = S;
@@ -607,7 +673,7 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
     HIP_TRY(hipMemsetAsync(tr->CAT1, 0, (size_t)B * 2 * D * 4, st));
     HIP_TRY(hipMemsetAsync(tr->CAT2, 0, (size_t)B * 2 * D * 4, st));
     const int XA = E + A;
-    const size_t attn_lds = (size_t)(2 * A + T + 4 * E) * 4;
+    const size_t attn_lds = (size_t)(2 * A + T + (V1D_ATT_THREADS / 64) * E) * 4;
     T2_TRY(dt_run_loop(tr, 0, [&]() -> int {
     for (int t = 0; t < S; ++t) {
         float *cata = tr->CATA + (size_t)t * B * XA, *cata_n = cata + (size_t)B * XA, *catar = tr->CATAR + (size_t)t * B * XA;
@@ -720,7 +786,7 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
     HIP_TRY(hipMemsetAsync(tr->cHA, 0, (size_t)B * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->cCTX, 0, (size_t)B * E * 4, st));
     HIP_TRY(hipMemsetAsync(tr->cH1, 0, (size_t)B * D * 4, st)); HIP_TRY(hipMemsetAsync(tr->cH2, 0, (size_t)B * D * 4, st));
     HIP_TRY(hipMemsetAsync(tr->dkeys, 0, (size_t)B * T * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->dvpart, 0, (size_t)B * A * 4, st));
-    const size_t attn_lds = (size_t)(E + T + 8 * A) * 4;
+    const size_t attn_lds = (size_t)(E + T + 2 * (V1D_ATT_THREADS / 64) * A) * 4;
     // every per-step product on the skinny path (B <= 64, widths multiples of 16): stage 1 of the cells fused as well
     const bool fused = dt_skinny_ok(tr, tr->DZC2, D, D, B) && dt_skinny_ok(tr, tr->DZG2, 2 * D, 2 * D, B) && dt_skinny_ok(tr, tr->DQ, A, A, B) &&
                        dt_skinny_ok(tr, tr->DZCa, A, A, B) && dt_skinny_ok(tr, tr->DZGa, 2 * A, 2 * A, B) && (B * D) % 4 == 0 && (B * A) % 4 == 0;
