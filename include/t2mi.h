@@ -322,7 +322,11 @@ int t2v1_model_create(t2_ctx* ctx, const t2v1_dims* dims, t2v1_model** out);
 int t2v1_model_set_weight(t2v1_model* m, const char* name, const float* host_ptr, const int64_t* shape, int rank);
 int t2v1_model_finalize(t2v1_model* m);
 int t2v1_model_destroy(t2v1_model* m);
-int t2v1_model_set_option(t2v1_model* m, const char* name, int value);     /* "graph", "chunk" */
+int t2v1_model_set_option(t2v1_model* m, const char* name, int value);     /* "graph", "chunk", "gruseq", "tfbatch"; trainers: "skinny",
+                                                                               "train_persist" (1: each decoder-trainer recurrence is one
+                                                                               persistent launch), "inject_timeout" (tests) */
+/* counters: "train_persist_launches", "persist_timeouts" (as t2_model_get_stat; no counterpart in the reference) */
+int t2v1_model_get_stat(t2v1_model* m, const char* name, double* out);
 
 /* Embedding.call + EncoderV1.call (tacotron_v1.py:46-49): PreNets -> CBHG.  lens NULL = no sequence_length, which
  * is how the V1 model_fn calls it (models.py:47).  memory_out dev [B,T_in,cbhg_out_units]. */

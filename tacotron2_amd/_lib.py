@@ -78,6 +78,7 @@ _SIGS = {
     "t2v1_model_finalize": (C.c_int, [_p]),
     "t2v1_model_destroy": (C.c_int, [_p]),
     "t2v1_model_set_option": (C.c_int, [_p, C.c_char_p, C.c_int]),
+    "t2v1_model_get_stat": (C.c_int, [_p, C.c_char_p, C.POINTER(C.c_double)]),
     "t2v1_encode": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p]),
     "t2v1_encode_embedded": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p]),
     "t2v1_cbhg": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, _p]),

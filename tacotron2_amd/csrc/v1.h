@@ -36,6 +36,8 @@ struct t2v1_model {
     int opt_tfbatch = 1;
     int opt_gruseq = 1;                   // CBHG BiGRU of 128 units per direction as one persistent launch (gru_seq_kernel)
     int opt_skinny = 1;                   // training recurrence: per-step products on v1d_skinny_gemm_kernel (0: conv_gemm tiles)
+    int opt_train_persist = 1;            // decoder trainer: each recurrence as one persistent launch (v1_dec_train.h)
+    long long n_train_persist = 0;        // such launches so far (t2v1_model_get_stat "train_persist_launches")
     bool gru_packed_stale = false;        // a trainer exported new variables: only the whole-sequence GRU operands were rebuilt
     GruPacked att_gru, gru1, gru2;
     float* v_a = nullptr;
@@ -193,6 +195,8 @@ extern "C" int t2v1_model_set_option(t2v1_model* m, const char* name, int value)
     if (!strcmp(name, "graph")) m->opt_graph = value;
     else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
     else if (!strcmp(name, "skinny")) m->opt_skinny = value;
+    else if (!strcmp(name, "train_persist")) { m->opt_train_persist = value; m->base.persist_holdoff = 0; }
+    else if (!strcmp(name, "inject_timeout")) m->base.opt_inject_timeout = value;
     else if (!strcmp(name, "gruseq")) {
         if (!value && m->gru_packed_stale) return fail(T2_ESTATE, "gruseq = 0 after a trainer export: the launch-per-step GRU operands hold the variables of before the training");
         m->opt_gruseq = value;

@@ -68,6 +68,18 @@ __global__ __launch_bounds__(256) void v1d_blend_kernel(const float* __restrict_
         }
     }
 }
+// Accessors of data that crosses workgroups.  COH = false: one launch per stage, plain loads and stores.  COH = true: the stages of
+// a whole recurrence run inside ONE launch (v1d_*_persist_kernel below) and hand their results to other workgroups between hops
+// (persist.h's protocol): such words are stored write-through and loaded past the non-coherent caches (agent-scope relaxed atomics
+// = global_store / global_load ... sc1 on gfx950).
+template <bool COH> __device__ __forceinline__ float v1_ld(const float* p) {
+    if constexpr (COH) return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+}
+template <bool COH> __device__ __forceinline__ void v1_st(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 // BahdanauAttention.__call__ + AttentionWrapper._compute_attention (App. A5, A6) of one batch row per workgroup of 16 waves:
 // score_j = v . tanh(keys_j + q), softmax over the live positions (-inf mask), context = sum_j a_j values_j.  Wave w owns the
 // positions j = w (mod 16) in both sweeps, a lane the features lane + 64 i; three positions are in flight per wave (the loads of a
@@ -75,16 +87,17 @@ __global__ __launch_bounds__(256) void v1d_blend_kernel(const float* __restrict_
 // tanh on the hardware exp / rcp (fast_tanhf, ~1e-6); the backward kernel uses the same function.
 #define V1D_ATT_THREADS 1024
 #define V1D_ATT_U 3
-__global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_fwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
-                                                                       const float* __restrict__ v, const int* __restrict__ lens, int T, int A, int E,
-                                                                       float* __restrict__ align, V1Dst c0, V1Dst c1) {
-    extern __shared__ float sm[];
+template <bool COH>
+__device__ __forceinline__ void v1d_attn_fwd_body(const float* __restrict__ keys, const float* __restrict__ values, const float* q,
+                                                  const float* __restrict__ v, const int* __restrict__ lens, int T, int A, int E,
+                                                  float* __restrict__ align, V1Dst c0, V1Dst c1, int b, float* sm, float* s_red) {
     constexpr int NW = V1D_ATT_THREADS / 64, U = V1D_ATT_U;
     float *s_q = sm, *s_v = sm + A, *s_e = sm + 2 * A, *s_part = sm + 2 * A + T;        // s_part [NW][E]
-    __shared__ float s_red[32];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    if constexpr (COH) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int len = lens[b];
-    for (int u = tid; u < A; u += V1D_ATT_THREADS) { s_q[u] = q[(size_t)b * A + u]; s_v[u] = v[u]; }
+    for (int u = tid; u < A; u += V1D_ATT_THREADS) { s_q[u] = v1_ld<COH>(q + (size_t)b * A + u); s_v[u] = v[u]; }
     __syncthreads();
     for (int j0 = wave; j0 < len; j0 += NW * U) {
         float p[U];
@@ -148,24 +161,32 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_fwd_kernel(const flo
         float acc = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) acc += s_part[w * E + e];
-        if (c0.p) c0.p[(size_t)b * c0.ld + e] = acc;
-        if (c1.p) c1.p[(size_t)b * c1.ld + e] = acc;
+        if (c0.p) v1_st<COH>(c0.p + (size_t)b * c0.ld + e, acc);
+        if (c1.p) v1_st<COH>(c1.p + (size_t)b * c1.ld + e, acc);
     }
+}
+__global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_fwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
+                                                                       const float* __restrict__ v, const int* __restrict__ lens, int T, int A, int E,
+                                                                       float* __restrict__ align, V1Dst c0, V1Dst c1) {
+    extern __shared__ float sm[];
+    __shared__ float s_red[32];
+    v1d_attn_fwd_body<false>(keys, values, q, v, lens, T, A, E, align, c0, c1, blockIdx.x, sm, s_red);
 }
 // its backward for one row: d a_j = d ctx . values_j; softmax backward; d q = sum_j g_j, d keys_j += g_j, d v += sum_j d e_j tanh_j
 // with g_ju = d e_j v_u (1 - tanh_ju^2).  (d values is a tape-wide product afterwards; the Bahdanau state is not fed back.)
 // Same ownership as the forward kernel; partial d q / d v of the 16 waves are added in wave order.
-__global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_bwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
-                                                                       const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align,
-                                                                       const float* __restrict__ dctx, long long dctx_row_stride, int T, int A, int E,
-                                                                       float* __restrict__ dq, float* __restrict__ dkeys, float* __restrict__ dvpart) {
-    extern __shared__ float sm[];
+template <bool COH>
+__device__ __forceinline__ void v1d_attn_bwd_body(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
+                                                  const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align,
+                                                  const float* dctx, long long dctx_row_stride, int T, int A, int E,
+                                                  float* dq, float* dkeys, float* dvpart, int b, float* sm, float* s_red) {
     constexpr int NW = V1D_ATT_THREADS / 64, U = V1D_ATT_U;
     float *s_dc = sm, *s_de = sm + E, *s_pq = sm + E + T, *s_pv = s_pq + NW * A;          // partial d q / d v [NW][A]
-    __shared__ float s_red[16];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    if constexpr (COH) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int len = lens[b];
-    for (int e = tid; e < E; e += V1D_ATT_THREADS) s_dc[e] = dctx[(size_t)b * dctx_row_stride + e];
+    for (int e = tid; e < E; e += V1D_ATT_THREADS) s_dc[e] = v1_ld<COH>(dctx + (size_t)b * dctx_row_stride + e);
     __syncthreads();
     for (int j0 = wave; j0 < len; j0 += NW * U) {
         float p[U];
@@ -233,9 +254,17 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_bwd_kernel(const flo
         float aq = 0.f, av = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { aq += s_pq[w * A + u]; av += s_pv[w * A + u]; }
-        dq[(size_t)b * A + u] = aq;
-        dvpart[(size_t)b * A + u] += av;
+        v1_st<COH>(dq + (size_t)b * A + u, aq);
+        dvpart[(size_t)b * A + u] += av;              // a row's d keys / d v words belong to the same thread in every step
     }
+}
+__global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_bwd_kernel(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
+                                                                       const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align,
+                                                                       const float* __restrict__ dctx, long long dctx_row_stride, int T, int A, int E,
+                                                                       float* __restrict__ dq, float* __restrict__ dkeys, float* __restrict__ dvpart) {
+    extern __shared__ float sm[];
+    __shared__ float s_red[32];
+    v1d_attn_bwd_body<false>(keys, values, q, v, lens, align, dctx, dctx_row_stride, T, A, E, dq, dkeys, dvpart, blockIdx.x, sm, s_red);
 }
 // GRU cell backward, stage 1: d h' = d0 (+ d1) -> d zc, d zu, and the part of d h that does not pass a GEMM (d h' u)
 __global__ __launch_bounds__(256) void v1d_bwd1_kernel(const float* __restrict__ d0, int ld0, const float* __restrict__ d1, int ld1, const float* __restrict__ cat,
@@ -356,96 +385,367 @@ struct SkEpi {
     const float* cin = nullptr; float* dctx = nullptr; long long row_stride = 0; int A = 0;      // DCTX (as v1d_dctx_kernel)
     SkBwd1 b1x, b1c;   // BWD3: stage 1 of the cell fed by d x (same step) / of this cell one step earlier (fed by the carry); BWD1: b1x on v
 };
-#define V1D_SK_WAVES 8
-template <int MB, int EPI>
-__global__ __launch_bounds__(64 * V1D_SK_WAVES) void v1d_skinny_gemm_kernel(const float* __restrict__ x, int ldx, int K, const float* __restrict__ w, int N,
-                                                                            SkEpi e, int rows) {
-    __shared__ f32x4 red[V1D_SK_WAVES][MB][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, c16 = lane & 15;
-    const int n0 = blockIdx.x * 16, n = n0 + c16;
-    const bool n_ok = n < N;
+// what an output element's epilogue reads besides the product, fetched before the K loop so that its latency hides behind it
+struct SkPre { float f[6]; };
+template <bool COH>
+__device__ __forceinline__ void sk_bwd1_load(const SkBwd1& q, int row, int u, float* o) {
+    o[0] = q.add ? v1_ld<COH>(q.add + (size_t)row * q.ldadd + u) : 0.f;
+    o[1] = v1_ld<COH>(q.ru + (size_t)row * 2 * q.H + q.H + u); o[2] = v1_ld<COH>(q.cnd + (size_t)row * q.H + u);
+    o[3] = v1_ld<COH>(q.cat + (size_t)row * (q.X + q.H) + q.X + u);
+}
+template <bool COH>
+__device__ __forceinline__ void sk_bwd1_apply(const SkBwd1& q, int row, int u, float dh, const float* o) {
+    dh += o[0];
+    const float uu = o[1], c = o[2], h = o[3];
+    v1_st<COH>(q.dzc + (size_t)row * q.H + u, dh * (1.0f - uu) * (1.0f - c * c));
+    v1_st<COH>(q.dzg + (size_t)row * 2 * q.H + q.H + u, dh * (h - c) * uu * (1.0f - uu));
+    v1_st<COH>(q.keep + (size_t)row * q.H + u, dh * uu);
+}
+template <int EPI, bool COH>
+__device__ __forceinline__ SkPre sk_pre(const SkEpi& e, int row, int col, int N) {
+    SkPre p;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p.f[i] = 0.f;
+    if (e.bias) p.f[0] = e.bias[col];
+    if (e.res) p.f[0] += v1_ld<COH>(e.res + (size_t)row * e.ldr + col);
+    const int X = e.X, H = e.H, Wd = X + H;
+    if constexpr (EPI == SK_GATE) {
+        if (col < H) p.f[1] = v1_ld<COH>(e.cat + (size_t)row * Wd + X + col);
+    } else if constexpr (EPI == SK_BLEND) {
+        p.f[1] = v1_ld<COH>(e.ru + (size_t)row * 2 * H + H + col); p.f[2] = v1_ld<COH>(e.cat + (size_t)row * Wd + X + col);
+        if (e.y0.p || e.y1.p) p.f[3] = v1_ld<COH>(e.cat + (size_t)row * Wd + col);
+    } else if constexpr (EPI == SK_BWD2) {
+        if (col >= X) {
+            p.f[1] = v1_ld<COH>(e.ru + (size_t)row * 2 * H + col - X); p.f[2] = v1_ld<COH>(e.cat + (size_t)row * Wd + col);
+            p.f[3] = v1_ld<COH>(e.keep + (size_t)row * H + col - X);
+        }
+    } else if constexpr (EPI == SK_BWD3) {
+        if (col < X) {
+            p.f[1] = v1_ld<COH>(e.dcatr + (size_t)row * Wd + col);
+            if (e.dres) p.f[1] += v1_ld<COH>(e.dres + (size_t)row * e.ldres + col);
+            if (e.b1x.dzc) sk_bwd1_load<COH>(e.b1x, row, col, p.f + 2);
+        } else {
+            p.f[1] = v1_ld<COH>(e.keep + (size_t)row * H + col - X);
+            if (e.b1c.dzc) sk_bwd1_load<COH>(e.b1c, row, col - X, p.f + 2);
+        }
+    } else if constexpr (EPI == SK_DCTX) {
+        if (col >= e.A) p.f[1] = v1_ld<COH>(e.cin + (size_t)row * (N - e.A) + col - e.A);
+    } else if constexpr (EPI == SK_BWD1) {
+        sk_bwd1_load<COH>(e.b1x, row, col, p.f + 2);
+    }
+    return p;
+}
+template <int EPI, bool COH>
+__device__ __forceinline__ void sk_post(const SkEpi& e, int row, int col, float v, const SkPre& p) {
+    v += p.f[0];
+    if (e.y) v1_st<COH>(e.y + (size_t)row * e.ldy + col, v);
+    const int X = e.X, H = e.H, Wd = X + H;
+    if constexpr (EPI == SK_GATE) {                   // N = 2H: [r | u] = sigmoid(v); [x | r h]
+        const float sg = sigmoidf_(v);
+        v1_st<COH>(e.ru + (size_t)row * 2 * H + col, sg);
+        if (col < H) v1_st<COH>(e.catr + (size_t)row * Wd + X + col, sg * p.f[1]);
+    } else if constexpr (EPI == SK_BLEND) {           // N = H: c = tanh(v); h' = u h + (1 - u) c; residual y = x + h'
+        const float cc = tanhf(v), uu = p.f[1], h = p.f[2];
+        const float hn = uu * h + (1.0f - uu) * cc;
+        v1_st<COH>(e.cnd + (size_t)row * H + col, cc);
+        if (e.h0.p) v1_st<COH>(e.h0.p + (size_t)row * e.h0.ld + col, hn);
+        if (e.h1.p) v1_st<COH>(e.h1.p + (size_t)row * e.h1.ld + col, hn);
+        if (e.y0.p || e.y1.p) {
+            const float yy = p.f[3] + hn;
+            if (e.y0.p) v1_st<COH>(e.y0.p + (size_t)row * e.y0.ld + col, yy);
+            if (e.y1.p) v1_st<COH>(e.y1.p + (size_t)row * e.y1.ld + col, yy);
+        }
+    } else if constexpr (EPI == SK_BWD2) {            // N = X + H: v = d [x | r h]; d zr, keep += d(r h) r
+        if (col >= X) {
+            const float rg = p.f[1], h = p.f[2];
+            v1_st<COH>(e.dzg + (size_t)row * 2 * H + col - X, v * h * rg * (1.0f - rg));
+            v1_st<COH>(e.keep + (size_t)row * H + col - X, p.f[3] + v * rg);
+        }
+    } else if constexpr (EPI == SK_BWD3) {            // N = X + H: v = d [x | h] of the gates' product
+        if (col < X) {
+            const float g = p.f[1] + v;
+            v1_st<COH>(e.dx + (size_t)row * e.lddx + col, g);
+            if (e.b1x.dzc) sk_bwd1_apply<COH>(e.b1x, row, col, g, p.f + 2);
+        } else {
+            const float cr = p.f[1] + v;
+            v1_st<COH>(e.carry + (size_t)row * H + col - X, cr);
+            if (e.b1c.dzc) sk_bwd1_apply<COH>(e.b1c, row, col - X, cr, p.f + 2);
+        }
+    } else if constexpr (EPI == SK_DCTX) {            // N = A + E: v = d [h_att | ctx] of the output projection
+        if (col >= e.A) v1_st<COH>(e.dctx + (size_t)row * e.row_stride + col - e.A, v + p.f[1]);
+    } else if constexpr (EPI == SK_BWD1) {
+        sk_bwd1_apply<COH>(e.b1x, row, col, v, p.f + 2);
+    }
+}
+// one product + epilogue by workgroup `wg` of `nwg` (16 columns each) with NWV waves; red: LDS [NWV][MB][64] float4
+template <int MB, int EPI, int NWV, bool COH>
+__device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const float* __restrict__ w, int N, const SkEpi& e, int rows, int wg, int nwg,
+                                        f32x4* red) {
+    constexpr int NT_ = 64 * NWV, UK = NWV >= 16 ? 2 : 4, EL = (MB * 256 + NT_ - 1) / NT_;       // UK k-blocks in flight per wave: K <= 512 is one batch
+    int tid = threadIdx.x;
+    // inside the persistent loops: an opaque copy of the thread index, or every stage's step-invariant addresses are hoisted out of
+    // the step loop, stay live across all stages and push the K loop's loads into a wait-per-load schedule (persist.h, fresh())
+    if constexpr (COH) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = lane >> 4, c16 = lane & 15;
+    const int n0 = wg * 16, n = min(n0 + c16, N - 1);
+    // epilogue ownership: element i = tid + NT_ * el -> (row, column) with the column fastest
+    SkPre pre[EL];
+#pragma unroll
+    for (int el = 0; el < EL; ++el) {
+        const int i = tid + NT_ * el, row = i >> 4, col = n0 + (i & 15);
+        if (i < MB * 256 && row < rows && col < N) pre[el] = sk_pre<EPI, COH>(e, row, col, N);
+    }
     f32x4 acc[MB];
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nkb = K >> 4;
-    for (int kb = wave; kb < nkb; kb += V1D_SK_WAVES) {
-        const int k0 = kb * 16 + 4 * kg;
-        f32x4 a[MB];
+    [[maybe_unused]] const pz::rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7ffffff0, 0x00020000);
+    for (int kb0 = wave; kb0 < nkb; kb0 += NWV * UK) {
+        f32x4 a[UK][MB];
+        float bw[UK][4];
 #pragma unroll
-        for (int rb = 0; rb < MB; ++rb) {
-            const int row = rb * 16 + c16;
-            a[rb] = row < rows ? *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < UK; ++i) {
+            const int kb = min(kb0 + NWV * i, nkb - 1), k0 = kb * 16 + 4 * kg;
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb) {
+                const size_t off = (size_t)min(rb * 16 + c16, rows - 1) * ldx + k0;
+                if constexpr (COH) a[i][rb] = pz::ld16(xr, (unsigned)(off * 4));
+                else a[i][rb] = *reinterpret_cast<const f32x4*>(x + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bw[i][j] = w[(size_t)(k0 + j) * N + n];
         }
-        float bw[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bw[j] = n_ok ? w[(size_t)(k0 + j) * N + n] : 0.f;
+        for (int i = 0; i < UK; ++i) {
+            const bool live = kb0 + NWV * i < nkb;           // a clamped (repeated) k-block contributes nothing
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const float bj = live ? bw[i][j] : 0.f;
 #pragma unroll
-            for (int rb = 0; rb < MB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][j], bw[j], acc[rb], 0, 0, 0);
+                for (int rb = 0; rb < MB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rb][j], bj, acc[rb], 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
-    for (int rb = 0; rb < MB; ++rb) red[wave][rb][lane] = acc[rb];
+    for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
     if constexpr (EPI == SK_GATE) {
         // the x half of the candidate's operand is a copy: every workgroup moves its share of the rows * X words
-        const int total = rows * e.X, per = (total + (int)gridDim.x - 1) / (int)gridDim.x, Wd = e.X + e.H;
-        for (int i = blockIdx.x * per + tid; i < min(total, (int)(blockIdx.x + 1) * per); i += 64 * V1D_SK_WAVES) {
+        const int total = rows * e.X, per = (total + nwg - 1) / nwg, Wd = e.X + e.H;
+        for (int i = wg * per + tid; i < min(total, (wg + 1) * per); i += NT_) {
             const int b = i / e.X, c = i - b * e.X;
-            e.catr[(size_t)b * Wd + c] = e.cat[(size_t)b * Wd + c];
+            v1_st<COH>(e.catr + (size_t)b * Wd + c, v1_ld<COH>(e.cat + (size_t)b * Wd + c));
         }
     }
     __syncthreads();
-    // D layout: reg r of lane (kg, c16) = row 4 kg + r, column c16; thread -> (row, column) with the column fastest
-    for (int i = tid; i < MB * 256; i += 64 * V1D_SK_WAVES) {
-        const int c = i & 15, rr = i >> 4, rb = rr >> 4, l = ((rr >> 2) & 3) * 16 + c, r = rr & 3;
+    // D layout: reg r of lane (kg, c16) = row 4 kg + r, column c16
+#pragma unroll
+    for (int el = 0; el < EL; ++el) {
+        const int i = tid + NT_ * el, c = i & 15, rr = i >> 4, rb = rr >> 4, l = ((rr >> 2) & 3) * 16 + c, r = rr & 3;
         const int row = rr, col = n0 + c;
-        if (row >= rows || col >= N) continue;
+        if (i >= MB * 256 || row >= rows || col >= N) continue;
         float v = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < V1D_SK_WAVES; ++wv) v += red[wv][rb][l][r];
-        if (e.bias) v += e.bias[col];
-        if (e.res) v += e.res[(size_t)row * e.ldr + col];
-        if (e.y) e.y[(size_t)row * e.ldy + col] = v;
-        const int X = e.X, H = e.H, Wd = X + H;
-        if constexpr (EPI == SK_GATE) {                   // N = 2H: [r | u] = sigmoid(v); [x | r h]
-            const float sg = sigmoidf_(v);
-            e.ru[(size_t)row * 2 * H + col] = sg;
-            if (col < H) e.catr[(size_t)row * Wd + X + col] = sg * e.cat[(size_t)row * Wd + X + col];
-        } else if constexpr (EPI == SK_BLEND) {           // N = H: c = tanh(v); h' = u h + (1 - u) c; residual y = x + h'
-            const float cc = tanhf(v), uu = e.ru[(size_t)row * 2 * H + H + col], h = e.cat[(size_t)row * Wd + X + col];
-            const float hn = uu * h + (1.0f - uu) * cc;
-            e.cnd[(size_t)row * H + col] = cc;
-            if (e.h0.p) e.h0.p[(size_t)row * e.h0.ld + col] = hn;
-            if (e.h1.p) e.h1.p[(size_t)row * e.h1.ld + col] = hn;
-            if (e.y0.p || e.y1.p) {
-                const float yy = e.cat[(size_t)row * Wd + col] + hn;
-                if (e.y0.p) e.y0.p[(size_t)row * e.y0.ld + col] = yy;
-                if (e.y1.p) e.y1.p[(size_t)row * e.y1.ld + col] = yy;
-            }
-        } else if constexpr (EPI == SK_BWD2) {            // N = X + H: v = d [x | r h]; d zr, keep += d(r h) r
-            if (col >= X) {
-                const int u = col - X;
-                const float rg = e.ru[(size_t)row * 2 * H + u], h = e.cat[(size_t)row * Wd + col];
-                e.dzg[(size_t)row * 2 * H + u] = v * h * rg * (1.0f - rg);
-                e.keep[(size_t)row * H + u] += v * rg;
-            }
-        } else if constexpr (EPI == SK_BWD3) {            // N = X + H: v = d [x | h] of the gates' product
-            if (col < X) {
-                float g = e.dcatr[(size_t)row * Wd + col] + v;
-                if (e.dres) g += e.dres[(size_t)row * e.ldres + col];
-                e.dx[(size_t)row * e.lddx + col] = g;
-                if (e.b1x.dzc) sk_bwd1(e.b1x, row, col, g);
-            } else {
-                const float cr = e.keep[(size_t)row * H + col - X] + v;
-                e.carry[(size_t)row * H + col - X] = cr;
-                if (e.b1c.dzc) sk_bwd1(e.b1c, row, col - X, cr);
-            }
-        } else if constexpr (EPI == SK_DCTX) {            // N = A + E: v = d [h_att | ctx] of the output projection
-            if (col >= e.A) e.dctx[(size_t)row * e.row_stride + col - e.A] = v + e.cin[(size_t)row * (N - e.A) + col - e.A];
-        } else if constexpr (EPI == SK_BWD1) {
-            sk_bwd1(e.b1x, row, col, v);
-        }
+        for (int wv = 0; wv < NWV; ++wv) v += red[(wv * MB + rb) * 64 + l][r];
+        sk_post<EPI, COH>(e, row, col, v, pre[el]);
     }
+}
+#define V1D_SK_WAVES 8
+template <int MB, int EPI>
+__global__ __launch_bounds__(64 * V1D_SK_WAVES) void v1d_skinny_gemm_kernel(const float* __restrict__ x, int ldx, int K, const float* __restrict__ w, int N,
+                                                                            SkEpi e, int rows) {
+    __shared__ f32x4 red[V1D_SK_WAVES * MB * 64];
+    sk_body<MB, EPI, V1D_SK_WAVES, false>(x, ldx, K, w, N, e, rows, blockIdx.x, gridDim.x, red);
+}
+
+// ---- both recurrences as ONE launch each -------------------------------------------------------------------------------------
+// The stages of a decoder step (the launches of the loops below, same device code) run inside one resident grid of G workgroups x
+// 16 waves, in two independent chains on the two halves of the grid; a stage hands its results to the next through persist.h's hop (write-through stores, drained, one
+// counter add per workgroup; polled shards), ~2 us instead of a launch boundary plus the fixed cost of a launch.  Workgroup g
+// owns output columns 16 g .. 16 g + 15 of a product (or batch row g of the attention); workgroups beyond a stage's width only
+// hop.  Every spin is bounded (persist.h SPIN_LIMIT_TICKS): a timeout leaves the loop with the error word set and the caller
+// re-runs the recurrence on the launch-per-stage schedule.
+struct V1PFwd {
+    int B, T, S, A, E, D;
+    const float *Wga, *Wca;                    // rows [P1, P1 + E + A) of the attention GRU's kernels (the PreNet rows are batched)
+    const float *Wq, *va, *Wo, *bo, *Wg1, *bg1, *Wc1, *bc1, *Wg2, *bg2, *Wc2, *bc2;
+    const float *zgp, *zcp, *keys, *values;
+    const int* lens;
+    float *CATA, *CATAR, *RUa, *Ca, *Q, *ALIGN, *CATO, *CAT1, *CAT1R, *RU1, *C1, *CAT2, *CAT2R, *RU2, *C2, *Y2;
+    unsigned* bar; int* err;
+};
+// Forward: two chains run side by side on the two halves of the grid, one stage per hop --
+//   attention chain of step i      : attention GRU gates | candidate | query layer | attention        (needs ctx, h_att of step i - 1)
+//   decoder chain of step i - 1    : output projection   | GRU 1 gates | candidate | GRU 2 gates | candidate   (needs [h_att | ctx] of step i - 1)
+// so a decoder step costs five hops instead of nine.
+template <int MB>
+__global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_fwd_persist_kernel(V1PFwd a) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    __shared__ float s_red[32];
+    __shared__ int s_abort;
+    constexpr int NWV = V1D_ATT_THREADS / 64;
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+    const int B = a.B, T = a.T, S = a.S, A = a.A, E = a.E, D = a.D, XA = E + A;
+    const int half = gridDim.x / 2, grp = blockIdx.x >= half ? 1 : 0, lw = blockIdx.x - grp * half;
+    const unsigned per = gridDim.x / pz::NSHARD;
+    unsigned epoch = 0;
+    f32x4* red = reinterpret_cast<f32x4*>(dsm);
+    auto hop = [&]() -> bool { pz::hop_arrive(a.bar); ++epoch; return pz::hop_wait(a.bar, per * epoch, &s_abort); };
+    auto gates = [&](const float* cat, float* catr, int X, int H, const float* Wg, const float* bg, const float* zgp, float* ru) {
+        const int Wd = X + H, ng = (2 * H + 15) / 16;
+        if (lw >= ng) return;
+        SkEpi g; g.bias = bg; g.res = zgp; g.ldr = 2 * H; g.cat = cat; g.X = X; g.H = H; g.ru = ru; g.catr = catr;
+        sk_body<MB, SK_GATE, NWV, true>(cat, Wd, Wd, Wg, 2 * H, g, B, lw, ng, red);
+    };
+    auto blend = [&](const float* cat, const float* catr, int X, int H, const float* Wc, const float* bc, const float* zcp, float* ru, float* cnd, V1Dst h0, V1Dst h1,
+                     V1Dst y0) {
+        const int Wd = X + H, nc = (H + 15) / 16;
+        if (lw >= nc) return;
+        SkEpi c; c.bias = bc; c.res = zcp; c.ldr = H; c.cat = cat; c.X = X; c.H = H; c.ru = ru; c.cnd = cnd; c.h0 = h0; c.h1 = h1; c.y0 = y0;
+        sk_body<MB, SK_BLEND, NWV, true>(catr, Wd, Wd, Wc, H, c, B, lw, nc, red);
+    };
+    auto plain = [&](const float* x, int ldx, int K, const float* w, int N, const float* bias, float* y, int ldy) {
+        const int nw = (N + 15) / 16;
+        if (lw >= nw) return;
+        SkEpi e; e.bias = bias; e.y = y; e.ldy = ldy;
+        sk_body<MB, SK_PLAIN, NWV, true>(x, ldx, K, w, N, e, B, lw, nw, red);
+    };
+    bool ok = true;
+    for (int i = 0; i <= S; ++i) {
+        const int t = grp ? i : i - 1;                        // this half's step
+        const bool act = grp ? i < S : i >= 1;
+        const size_t tt = act ? (size_t)t : 0;
+        float *cata = a.CATA + tt * B * XA, *cata_n = cata + (size_t)B * XA, *catar = a.CATAR + tt * B * XA;
+        float* cato = a.CATO + tt * B * (A + E);
+        float *cat1 = a.CAT1 + tt * B * 2 * D, *cat1_n = cat1 + (size_t)B * 2 * D, *cat1r = a.CAT1R + tt * B * 2 * D;
+        float *cat2 = a.CAT2 + tt * B * 2 * D, *cat2_n = cat2 + (size_t)B * 2 * D, *cat2r = a.CAT2R + tt * B * 2 * D;
+        float *rua = a.RUa + tt * B * 2 * A, *ru1 = a.RU1 + tt * B * 2 * D, *ru2 = a.RU2 + tt * B * 2 * D, *q = a.Q + tt * B * A;
+        if (act) {
+            if (grp) gates(cata, catar, E, A, a.Wga, nullptr, a.zgp + tt * B * 2 * A, rua);
+            else plain(cato, A + E, A + E, a.Wo, D, a.bo, cat1, 2 * D);
+        }
+        if (!(ok = hop())) break;
+        if (act) {
+            if (grp) blend(cata, catar, E, A, a.Wca, nullptr, a.zcp + tt * B * A, rua, a.Ca + tt * B * A, V1Dst{cato, A + E}, V1Dst{cata_n + E, XA}, V1Dst{nullptr, 0});
+            else gates(cat1, cat1r, D, D, a.Wg1, a.bg1, nullptr, ru1);
+        }
+        if (!(ok = hop())) break;
+        if (act) {
+            if (grp) plain(cato, A + E, A, a.Wq, A, nullptr, q, A);
+            else blend(cat1, cat1r, D, D, a.Wc1, a.bc1, nullptr, ru1, a.C1 + tt * B * D, V1Dst{cat1_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{cat2, 2 * D});
+        }
+        if (!(ok = hop())) break;
+        if (act) {
+            if (grp) {
+                if (lw < B) v1d_attn_fwd_body<true>(a.keys, a.values, q, a.va, a.lens, T, A, E, a.ALIGN + tt * B * T, V1Dst{cato + A, A + E}, V1Dst{cata_n, XA}, lw, dsm, s_red);
+            } else gates(cat2, cat2r, D, D, a.Wg2, a.bg2, nullptr, ru2);
+        }
+        if (!(ok = hop())) break;
+        if (act && !grp) blend(cat2, cat2r, D, D, a.Wc2, a.bc2, nullptr, ru2, a.C2 + tt * B * D, V1Dst{cat2_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{a.Y2 + tt * B * D, D});
+        if (!(ok = hop())) break;
+    }
+    if (!ok && threadIdx.x == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct V1PBwd {
+    int B, T, S, A, E, D;
+    const float *Wc2T, *Wg2T, *Wc1T, *Wg1T, *WoT, *WqT, *WcaT, *WgaT, *va, *keys, *values;
+    const int* lens;
+    const float *CATA, *RUa, *Ca, *Q, *ALIGN, *CAT1, *RU1, *C1, *CAT2, *RU2, *C2, *DY2;
+    float *DZC2, *DZG2, *DZC1, *DZG1, *DY0, *DQ, *DZCa, *DZGa, *DCTX, *dkeys, *dvpart;
+    float *cHA, *cCTX, *cH1, *cH2, *keep, *keep1, *keepA, *dcatr, *dcatrA, *dy1, *dcato;
+    unsigned* bar; int* err;
+};
+// Backward, last step first: the same split --
+//   decoder chain of step S - 1 - i  : GRU 2 stages 2, 3 | GRU 1 stages 2, 3                          (needs only its own carries and d y2)
+//   attention chain of step S - i    : output projection | attention | query layer + stage 1 | attention GRU stages 2, 3   (needs d y0 of its step)
+template <int MB>
+__global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd a) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    __shared__ float s_red[32];
+    __shared__ int s_abort;
+    constexpr int NWV = V1D_ATT_THREADS / 64;
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+    const int B = a.B, T = a.T, S = a.S, A = a.A, E = a.E, D = a.D, XA = E + A;
+    const int half = gridDim.x / 2, grp = blockIdx.x >= half ? 1 : 0, lw = blockIdx.x - grp * half;
+    const unsigned per = gridDim.x / pz::NSHARD;
+    unsigned epoch = 0;
+    f32x4* red = reinterpret_cast<f32x4*>(dsm);
+    auto hop = [&]() -> bool { pz::hop_arrive(a.bar); ++epoch; return pz::hop_wait(a.bar, per * epoch, &s_abort); };
+    // stages 2 and 3 of a GRU cell's backward (stage 1 rode in the epilogue that produced the cell's d h')
+    auto stage2 = [&](const float* cat, const float* ru, int X, int H, const float* WcT, const float* dzc, float* dzg, float* keep, float* dcatr) {
+        const int Wd = X + H, nw = (Wd + 15) / 16;
+        if (lw >= nw) return;
+        SkEpi e2; e2.y = dcatr; e2.ldy = Wd; e2.cat = cat; e2.X = X; e2.H = H; e2.ru = const_cast<float*>(ru); e2.dzg = dzg; e2.keep = keep;
+        sk_body<MB, SK_BWD2, NWV, true>(dzc, H, H, WcT, Wd, e2, B, lw, nw, red);
+    };
+    auto stage3 = [&](int X, int H, const float* WgT, const float* dzg, const float* dres, int ldres, float* carry, float* dx, int lddx, float* keep, const float* dcatr,
+                      const SkBwd1* b1x, const SkBwd1* b1c) {
+        const int Wd = X + H, nw = (Wd + 15) / 16;
+        if (lw >= nw) return;
+        SkEpi e3; e3.X = X; e3.H = H; e3.dcatr = dcatr; e3.dres = dres; e3.ldres = ldres; e3.keep = keep; e3.carry = carry; e3.dx = dx; e3.lddx = lddx;
+        if (b1x) e3.b1x = *b1x;
+        if (b1c) e3.b1c = *b1c;
+        sk_body<MB, SK_BWD3, NWV, true>(dzg, 2 * H, 2 * H, WgT, Wd, e3, B, lw, nw, red);
+    };
+    bool ok = true;
+    for (int i = 0; i <= S; ++i) {
+        const int t = grp ? S - i : S - 1 - i;
+        const bool act = grp ? i >= 1 : i < S;
+        const size_t tt = act ? (size_t)t : 0;
+        const float* cata = a.CATA + tt * B * XA;
+        const float *cat1 = a.CAT1 + tt * B * 2 * D, *cat2 = a.CAT2 + tt * B * 2 * D;
+        const float* dy2 = a.DY2 + tt * B * D;
+        float *dy0 = a.DY0 + tt * B * D, *dctx_t = a.DCTX + tt * E, *dq = a.DQ + tt * B * A;
+        // stage 0: GRU 2 stage 2 | output projection backward (+ d ctx)
+        if (act) {
+            if (!grp) stage2(cat2, a.RU2 + tt * B * 2 * D, D, D, a.Wc2T, a.DZC2 + tt * B * D, a.DZG2 + tt * B * 2 * D, a.keep, a.dcatr);
+            else if (lw < (A + E + 15) / 16) {
+                SkEpi e; e.y = a.dcato; e.ldy = A + E; e.cin = a.cCTX; e.dctx = dctx_t; e.row_stride = (long long)S * E; e.A = A;
+                sk_body<MB, SK_DCTX, NWV, true>(dy0, D, D, a.WoT, A + E, e, B, lw, (A + E + 15) / 16, red);
+            }
+        }
+        if (!(ok = hop())) break;
+        // stage 1: GRU 2 stage 3 (+ stage 1 of GRU 1 at this step and of GRU 2 one step earlier) | attention backward
+        if (act) {
+            if (!grp) {
+                SkBwd1 s1; s1.add = a.cH1; s1.ldadd = D; s1.cat = cat1; s1.ru = a.RU1 + tt * B * 2 * D; s1.cnd = a.C1 + tt * B * D; s1.X = D; s1.H = D;
+                s1.dzc = a.DZC1 + tt * B * D; s1.dzg = a.DZG1 + tt * B * 2 * D; s1.keep = a.keep1;
+                SkBwd1 s2;
+                if (t > 0) {
+                    const size_t u = tt - 1;
+                    s2.add = a.DY2 + u * B * D; s2.ldadd = D; s2.cat = a.CAT2 + u * B * 2 * D; s2.ru = a.RU2 + u * B * 2 * D; s2.cnd = a.C2 + u * B * D; s2.X = D; s2.H = D;
+                    s2.dzc = a.DZC2 + u * B * D; s2.dzg = a.DZG2 + u * B * 2 * D; s2.keep = a.keep;
+                }
+                stage3(D, D, a.Wg2T, a.DZG2 + tt * B * 2 * D, dy2, D, a.cH2, a.dy1, D, a.keep, a.dcatr, &s1, t > 0 ? &s2 : nullptr);
+            } else if (lw < B) {
+                v1d_attn_bwd_body<true>(a.keys, a.values, a.Q + tt * B * A, a.va, a.lens, a.ALIGN + tt * B * T, dctx_t, (long long)S * E, T, A, E, dq, a.dkeys, a.dvpart, lw,
+                                        dsm, s_red);
+            }
+        }
+        if (!(ok = hop())) break;
+        // stage 2: GRU 1 stage 2 | query layer backward + stage 1 of the attention GRU
+        if (act) {
+            if (!grp) stage2(cat1, a.RU1 + tt * B * 2 * D, D, D, a.Wc1T, a.DZC1 + tt * B * D, a.DZG1 + tt * B * 2 * D, a.keep1, a.dcatr);
+            else if (lw < (A + 15) / 16) {
+                SkEpi e; e.res = a.dcato; e.ldr = A + E;
+                e.b1x.add = a.cHA; e.b1x.ldadd = A; e.b1x.cat = cata; e.b1x.ru = a.RUa + tt * B * 2 * A; e.b1x.cnd = a.Ca + tt * B * A; e.b1x.X = E; e.b1x.H = A;
+                e.b1x.dzc = a.DZCa + tt * B * A; e.b1x.dzg = a.DZGa + tt * B * 2 * A; e.b1x.keep = a.keepA;
+                sk_body<MB, SK_BWD1, NWV, true>(dq, A, A, a.WqT, A, e, B, lw, (A + 15) / 16, red);
+            }
+        }
+        if (!(ok = hop())) break;
+        // stage 3: GRU 1 stage 3 -> d y0 of this step | attention GRU stage 2
+        if (act) {
+            if (!grp) stage3(D, D, a.Wg1T, a.DZG1 + tt * B * 2 * D, a.dy1, D, a.cH1, dy0, D, a.keep1, a.dcatr, nullptr, nullptr);
+            else stage2(cata, a.RUa + tt * B * 2 * A, E, A, a.WcaT, a.DZCa + tt * B * A, a.DZGa + tt * B * 2 * A, a.keepA, a.dcatrA);
+        }
+        if (!(ok = hop())) break;
+        // stage 4: - | attention GRU stage 3 -> the carries d h_att, d ctx of the step before
+        if (act && grp) stage3(E, A, a.WgaT, a.DZGa + tt * B * 2 * A, nullptr, 0, a.cHA, a.cCTX, E, a.keepA, a.dcatrA, nullptr, nullptr);
+        if (!(ok = hop())) break;
+    }
+    if (!ok && threadIdx.x == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct t2v1_dtrainer {
@@ -468,6 +768,7 @@ struct t2v1_dtrainer {
     float *WmT, *WsT, *Wg2T, *Wc2T, *Wg1T, *Wc1T, *WoT, *WqT, *WgaT, *WcaT, *WgpT, *WcpT, *Wp1T, *WmemT;
     // the two recurrence loops as hipGraphs (S x 15 / S x 17 launches each): every pointer in them is the trainer's own or lies in
     // the flat parameter buffer, so a graph stays valid as long as that buffer's address does
+    unsigned* pbar = nullptr;           // hop counters + error word of the persistent recurrences
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     const float* gparams[2] = {nullptr, nullptr};
 };
@@ -552,11 +853,12 @@ extern "C" int t2v1_decoder_trainer_create(t2v1_model* m, int B, int T_in, int S
     want(&tr->WmT, rM * D); want(&tr->WsT, D); want(&tr->Wg2T, 2 * D * 2 * D); want(&tr->Wc2T, D * 2 * D); want(&tr->Wg1T, 2 * D * 2 * D); want(&tr->Wc1T, D * 2 * D);
     want(&tr->WoT, D * (A + E)); want(&tr->WqT, A * A); want(&tr->WgaT, 2 * A * (E + A)); want(&tr->WcaT, A * (E + A)); want(&tr->WgpT, 2 * A * P1);
     want(&tr->WcpT, A * P1); want(&tr->Wp1T, P1 * P0); want(&tr->WmemT, A * E);
-    const size_t o_lens = cv.take((size_t)B * 4);
+    const size_t o_lens = cv.take((size_t)B * 4), o_bar = cv.take((size_t)(pz::NSHARD * 32 + 64) * 4);
     hipError_t e = hipMalloc((void**)&tr->slab, cv.off);
     if (e != hipSuccess) { delete tr; return fail(T2_ENOMEM, "hipMalloc(V1 decoder trainer, %zu bytes) failed: %s", cv.off, hipGetErrorString(e)); }
     for (auto& pr : plan) *pr.first = (float*)(tr->slab + pr.second);
     tr->lens = (int*)(tr->slab + o_lens);
+    tr->pbar = (unsigned*)(tr->slab + o_bar);
     *out = tr;
     return T2_OK;
 }
@@ -575,6 +877,60 @@ extern "C" int t2v1_decoder_trainer_set_loss_counts(t2v1_dtrainer* tr, const flo
 
 static inline bool dt_skinny_ok(t2v1_dtrainer* tr, const float* x, int ldx, int K, int rows) {
     return rows <= 64 && K % 16 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && tr->m->opt_skinny;
+}
+// The recurrences as one launch each (v1d_*_persist_kernel): B <= 48 (LDS of the 16-wave reduction), every per-step product on the
+// skinny path, a whole chip (the grid must be resident: one 1024-thread workgroup per CU, G <= 64 of them)
+static size_t dt_persist_lds(t2v1_dtrainer* tr) {
+    const t2v1_dims& d = tr->m->d;
+    const size_t NW = V1D_ATT_THREADS / 64, A = d.attention_out_units, E = d.cbhg_out_units, MB = ceil_div(tr->B, 16);
+    return std::max({NW * MB * 64 * 16, (2 * A + tr->T + NW * E) * 4, (E + tr->T + 2 * NW * A) * 4});
+}
+static int dt_persist_grid(t2v1_dtrainer* tr) {
+    const t2v1_dims& d = tr->m->d;
+    const int A = d.attention_out_units, E = d.cbhg_out_units, D = d.decoder_out_units;
+    const int wmax = std::max({2 * A, 2 * D, A + E, tr->B * 16});
+    return 2 * ceil_div(ceil_div(wmax, 16), pz::NSHARD) * pz::NSHARD;          // two halves, one per chain
+}
+static bool dt_persist_ok(t2v1_dtrainer* tr) {
+    t2v1_model* m = tr->m;
+    const t2v1_dims& d = m->d;
+    const int A = d.attention_out_units, E = d.cbhg_out_units, D = d.decoder_out_units, B = tr->B;
+    return m->opt_train_persist && m->opt_skinny && m->base.persist_holdoff == 0 && B <= 48 && A % 16 == 0 && E % 16 == 0 && D % 16 == 0 &&
+           dt_persist_lds(tr) + 256 <= 64 * 1024 && m->base.n_cu >= dt_persist_grid(tr) && m->base.n_cu >= 64;
+}
+// launches kernel `which` (0 forward, 1 backward) of the persistent pair; *timed_out: the caller re-runs the loop launch by launch
+template <typename ARGS>
+static int dt_persist_launch(t2v1_dtrainer* tr, int which, ARGS& a, bool* timed_out) {
+    t2_model* b = &tr->m->base;
+    hipStream_t st = b->ctx->stream;
+    HIP_TRY(hipMemsetAsync(tr->pbar, 0, (size_t)(pz::NSHARD * 32 + 64) * 4, st));
+    a.bar = tr->pbar; a.err = (int*)(tr->pbar + pz::NSHARD * 32);
+    const dim3 grid(dt_persist_grid(tr)), blk(V1D_ATT_THREADS);
+    const size_t lds = dt_persist_lds(tr);
+    const int MB = ceil_div(tr->B, 16);
+    {
+        XwgGate gate;
+        T2_TRY(gate.begin(b->ctx));
+        if constexpr (std::is_same<ARGS, V1PFwd>::value) {
+            if (MB == 1) hipLaunchKernelGGL(v1d_fwd_persist_kernel<1>, grid, blk, lds, st, a);
+            else if (MB == 2) hipLaunchKernelGGL(v1d_fwd_persist_kernel<2>, grid, blk, lds, st, a);
+            else hipLaunchKernelGGL(v1d_fwd_persist_kernel<3>, grid, blk, lds, st, a);
+        } else {
+            if (MB == 1) hipLaunchKernelGGL(v1d_bwd_persist_kernel<1>, grid, blk, lds, st, a);
+            else if (MB == 2) hipLaunchKernelGGL(v1d_bwd_persist_kernel<2>, grid, blk, lds, st, a);
+            else hipLaunchKernelGGL(v1d_bwd_persist_kernel<3>, grid, blk, lds, st, a);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    (void)which;
+    T2_TRY(inject_timeout(b, a.err));
+    ++tr->m->n_train_persist;
+    int h_err = 0;
+    HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *timed_out = h_err != 0;
+    if (h_err) note_persist_timeout(b);
+    return T2_OK;
 }
 template <int EPI>
 static void dt_skinny(t2v1_dtrainer* tr, const float* x, int ldx, int K, const float* w, int N, const SkEpi& e, int rows) {
@@ -621,6 +977,13 @@ static int dt_gru_fwd(t2v1_dtrainer* tr, const float* cat, float* catr, int X, i
 }
 static void dt_transpose(t2v1_dtrainer* tr, const float* src, float* dst, int R, int C) {      // src [R][C] -> dst [C][R]
     hipLaunchKernelGGL(transpose_kernel, dt_grid((long long)R * C), dim3(256), 0, tr->m->base.ctx->stream, dst, R, src, C, C, R);
+}
+
+extern "C" int t2v1_model_get_stat(t2v1_model* m, const char* name, double* out) {
+    if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
+    if (!strcmp(name, "train_persist_launches")) { *out = (double)m->n_train_persist; return T2_OK; }
+    if (!strcmp(name, "persist_timeouts")) { *out = (double)m->base.n_persist_timeouts; return T2_OK; }
+    return fail(T2_EINVAL, "unknown stat %s", name);
 }
 
 // memory dev [B][T_in][E]; lens host [B] or null; target dev [B][S*r][M] (labels.mel); mel_out dev [B][S*r][M], stop_out dev [B][S],
@@ -674,7 +1037,21 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
     HIP_TRY(hipMemsetAsync(tr->CAT2, 0, (size_t)B * 2 * D * 4, st));
     const int XA = E + A;
     const size_t attn_lds = (size_t)(2 * A + T + (V1D_ATT_THREADS / 64) * E) * 4;
-    T2_TRY(dt_run_loop(tr, 0, [&]() -> int {
+    bool looped = false;
+    holdoff_tick(b);
+    if (dt_persist_ok(tr)) {
+        V1PFwd a{};
+        a.B = B; a.T = T; a.S = S; a.A = A; a.E = E; a.D = D;
+        a.Wga = Wga + (size_t)P1 * 2 * A; a.Wca = Wca + (size_t)P1 * A; a.Wq = Wq; a.va = va; a.Wo = Wo; a.bo = bo;
+        a.Wg1 = Wg1; a.bg1 = bg1; a.Wc1 = Wc1; a.bc1 = bc1; a.Wg2 = Wg2; a.bg2 = bg2; a.Wc2 = Wc2; a.bc2 = bc2;
+        a.zgp = tr->zgp; a.zcp = tr->zcp; a.keys = tr->keys; a.values = tr->values; a.lens = tr->lens;
+        a.CATA = tr->CATA; a.CATAR = tr->CATAR; a.RUa = tr->RUa; a.Ca = tr->Ca; a.Q = tr->Q; a.ALIGN = tr->ALIGN; a.CATO = tr->CATO;
+        a.CAT1 = tr->CAT1; a.CAT1R = tr->CAT1R; a.RU1 = tr->RU1; a.C1 = tr->C1; a.CAT2 = tr->CAT2; a.CAT2R = tr->CAT2R; a.RU2 = tr->RU2; a.C2 = tr->C2; a.Y2 = tr->Y2;
+        bool timed_out = false;
+        T2_TRY(dt_persist_launch(tr, 0, a, &timed_out));
+        looped = !timed_out;          // every word of the tapes is rewritten by the launch-per-stage loop: nothing to reset
+    }
+    if (!looped) T2_TRY(dt_run_loop(tr, 0, [&]() -> int {
     for (int t = 0; t < S; ++t) {
         float *cata = tr->CATA + (size_t)t * B * XA, *cata_n = cata + (size_t)B * XA, *catar = tr->CATAR + (size_t)t * B * XA;
         float *cato = tr->CATO + (size_t)t * B * (A + E);
@@ -783,14 +1160,38 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
     // d y2 of all steps: the projections do not depend on the recurrence
     T2_TRY(dt_gemm(tr, tr->dmel_sb, rM, rM, tr->WmT, D, nullptr, tr->DY2, D, nullptr, 0, SB));
     T2_TRY(dt_gemm(tr, tr->dstop_sb, 1, 1, tr->WsT, D, nullptr, tr->DY2, D, tr->DY2, D, SB));
-    HIP_TRY(hipMemsetAsync(tr->cHA, 0, (size_t)B * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->cCTX, 0, (size_t)B * E * 4, st));
-    HIP_TRY(hipMemsetAsync(tr->cH1, 0, (size_t)B * D * 4, st)); HIP_TRY(hipMemsetAsync(tr->cH2, 0, (size_t)B * D * 4, st));
-    HIP_TRY(hipMemsetAsync(tr->dkeys, 0, (size_t)B * T * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->dvpart, 0, (size_t)B * A * 4, st));
+    auto zero_carries = [&]() -> int {
+        HIP_TRY(hipMemsetAsync(tr->cHA, 0, (size_t)B * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->cCTX, 0, (size_t)B * E * 4, st));
+        HIP_TRY(hipMemsetAsync(tr->cH1, 0, (size_t)B * D * 4, st)); HIP_TRY(hipMemsetAsync(tr->cH2, 0, (size_t)B * D * 4, st));
+        HIP_TRY(hipMemsetAsync(tr->dkeys, 0, (size_t)B * T * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->dvpart, 0, (size_t)B * A * 4, st));
+        return T2_OK;
+    };
+    T2_TRY(zero_carries());
     const size_t attn_lds = (size_t)(E + T + 2 * (V1D_ATT_THREADS / 64) * A) * 4;
     // every per-step product on the skinny path (B <= 64, widths multiples of 16): stage 1 of the cells fused as well
     const bool fused = dt_skinny_ok(tr, tr->DZC2, D, D, B) && dt_skinny_ok(tr, tr->DZG2, 2 * D, 2 * D, B) && dt_skinny_ok(tr, tr->DQ, A, A, B) &&
                        dt_skinny_ok(tr, tr->DZCa, A, A, B) && dt_skinny_ok(tr, tr->DZGa, 2 * A, 2 * A, B) && (B * D) % 4 == 0 && (B * A) % 4 == 0;
-    T2_TRY(dt_run_loop(tr, 1, [&]() -> int {
+    bool looped = false;
+    if (fused && dt_persist_ok(tr)) {
+        const size_t u = (size_t)(S - 1);            // stage 1 of GRU 2 at the last step; every other stage 1 rides in an epilogue
+        hipLaunchKernelGGL(v1d_bwd1_kernel, dt_grid((long long)B * D), dim3(256), 0, st, tr->DY2 + u * B * D, D, tr->cH2, D, tr->CAT2 + u * B * 2 * D,
+                           tr->RU2 + u * B * 2 * D, tr->C2 + u * B * D, D, D, tr->DZC2 + u * B * D, tr->DZG2 + u * B * 2 * D, tr->keep, B);
+        V1PBwd a{};
+        a.B = B; a.T = T; a.S = S; a.A = A; a.E = E; a.D = D;
+        a.Wc2T = tr->Wc2T; a.Wg2T = tr->Wg2T; a.Wc1T = tr->Wc1T; a.Wg1T = tr->Wg1T; a.WoT = tr->WoT; a.WqT = tr->WqT; a.WcaT = tr->WcaT; a.WgaT = tr->WgaT;
+        a.va = va; a.keys = tr->keys; a.values = tr->values; a.lens = tr->lens;
+        a.CATA = tr->CATA; a.RUa = tr->RUa; a.Ca = tr->Ca; a.Q = tr->Q; a.ALIGN = tr->ALIGN; a.CAT1 = tr->CAT1; a.RU1 = tr->RU1; a.C1 = tr->C1;
+        a.CAT2 = tr->CAT2; a.RU2 = tr->RU2; a.C2 = tr->C2; a.DY2 = tr->DY2;
+        a.DZC2 = tr->DZC2; a.DZG2 = tr->DZG2; a.DZC1 = tr->DZC1; a.DZG1 = tr->DZG1; a.DY0 = tr->DY0; a.DQ = tr->DQ; a.DZCa = tr->DZCa; a.DZGa = tr->DZGa;
+        a.DCTX = tr->DCTX; a.dkeys = tr->dkeys; a.dvpart = tr->dvpart;
+        a.cHA = tr->cHA; a.cCTX = tr->cCTX; a.cH1 = tr->cH1; a.cH2 = tr->cH2; a.keep = tr->keep; a.keep1 = tr->keep1; a.keepA = tr->keepA;
+        a.dcatr = tr->dcatr; a.dcatrA = tr->dcat; a.dy1 = tr->dy1; a.dcato = tr->dcato;
+        bool timed_out = false;
+        T2_TRY(dt_persist_launch(tr, 1, a, &timed_out));
+        looped = !timed_out;
+        if (timed_out) T2_TRY(zero_carries());       // the accumulators start again; the tapes are rewritten
+    }
+    if (!looped) T2_TRY(dt_run_loop(tr, 1, [&]() -> int {
     for (int t = S - 1; t >= 0; --t) {
         const float* cata = tr->CATA + (size_t)t * B * XA;
         const float *cat1 = tr->CAT1 + (size_t)t * B * 2 * D, *cat2 = tr->CAT2 + (size_t)t * B * 2 * D;

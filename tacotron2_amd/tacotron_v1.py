@@ -61,6 +61,11 @@ class EngineV1:
     def set_option(self, name: str, value: int):
         _lib.check(self.lib.t2v1_model_set_option(self._model, name.encode(), int(value)))
 
+    def get_stat(self, name: str) -> float:
+        out = C.c_double(0.0)
+        _lib.check(self.lib.t2v1_model_get_stat(self._model, name.encode(), C.byref(out)))
+        return out.value
+
     def _f32(self, x):
         return self.context.f32(x)
 

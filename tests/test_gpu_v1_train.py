@@ -443,6 +443,64 @@ def test_decoder_v1_training_forward_and_every_gradient_against_autograd(name, B
     eng.close()
 
 
+def test_decoder_v1_persistent_recurrences_equal_the_launch_per_stage_loops_and_fall_back_on_a_timeout():
+    """Both recurrences of the decoder trainer as one persistent launch each (csrc/v1_dec_train.h, two chains per launch) against
+    the same stages launched one by one (hipGraph loops): same device code, another summation order of the K split (16 waves
+    instead of 8).  A hop timeout (injected) in either launch re-runs that recurrence launch by launch: same numbers as that path."""
+    import torch
+    from tests.test_gpu_v1 import DIMS
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import DecoderV1Trainer, EngineV1
+    d = DIMS["ref"]
+    B, T, S, drop = 20, 37, 7, 0.5
+    w = init_weights_v1(d, 9, perturb=True)
+    eng = EngineV1(d, w)
+    dw = DecoderV1Trainer.decoder_weights(w)
+    spec = TR.flatten_spec(dw)
+    flat = torch.tensor(TR.flatten(dw, spec), device="cuda")
+    mem, lens, labels = _dec_case(d, B, T, S, 77)
+    tr = DecoderV1Trainer(eng, B, T, S, spec)
+
+    def run(inject_fwd=0, inject_bwd=0):
+        if inject_fwd:
+            eng.set_option("inject_timeout", inject_fwd)
+        mel, stop, align = tr.forward(flat, mem, lens, labels["mel"], drop_rate=drop, seed=5)
+        if inject_bwd:
+            eng.set_option("inject_timeout", inject_bwd)
+        grads = torch.zeros_like(flat)                                       # (alignment padding between variables is never written)
+        dmem, losses = tr.backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], grads)
+        return [_np(x).copy() for x in (mel, stop, align, grads, dmem, losses)]
+
+    n0 = eng.get_stat("train_persist_launches")
+    pers = run()
+    assert eng.get_stat("train_persist_launches") == n0 + 2 and eng.get_stat("persist_timeouts") == 0
+    eng.set_option("train_persist", 0)
+    loop = run()
+    assert eng.get_stat("train_persist_launches") == n0 + 2
+    for a, b_ in zip(pers, loop):
+        scale = float(np.abs(b_).max())
+        assert np.isfinite(a).all() and float(np.abs(a - b_).max()) <= 2e-5 * scale + 1e-9
+    # a timed-out forward launch: the forward loop runs again launch by launch, and the next 16 calls stay on that schedule
+    eng.set_option("train_persist", 1)
+    got = run(inject_fwd=1)
+    assert eng.get_stat("persist_timeouts") == 1 and eng.get_stat("train_persist_launches") == n0 + 3
+    for a, b_ in zip(got, loop):
+        np.testing.assert_array_equal(a, b_)
+    # a timed-out backward launch after a good forward launch: accumulators start again, same numbers as the loops
+    eng.set_option("train_persist", 1)
+    got = run(inject_bwd=1)
+    assert eng.get_stat("persist_timeouts") == 2 and eng.get_stat("train_persist_launches") == n0 + 5
+    for i, (a, b_) in enumerate(zip(got, loop)):
+        if i < 3:                                                            # forward: persistent launch
+            scale = float(np.abs(b_).max())
+            assert float(np.abs(a - b_).max()) <= 2e-5 * scale + 1e-9
+        else:                                                                # backward: loops on the persistent forward's tape
+            scale = float(np.abs(b_).max())
+            assert np.isfinite(a).all() and float(np.abs(a - b_).max()) <= 2e-5 * scale + 1e-9
+    tr.close()
+    eng.close()
+
+
 def test_single_speaker_v1_model_fn_train_loop_against_oracle():
     """SingleSpeakerTacotronV1Model.model_fn(TRAIN) (models.py:40-76) twice against the oracle loop (encoder oracle o decoder
     oracle through d memory, clip_by_global_norm(1.0), TF-form Adam at the Noam rate, UPDATE_OPS), then PREDICT with the trained
