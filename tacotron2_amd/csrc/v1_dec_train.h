@@ -82,11 +82,11 @@ template <bool COH> __device__ __forceinline__ void v1_st(float* p, float v) {
 }
 // BahdanauAttention.__call__ + AttentionWrapper._compute_attention (App. A5, A6) of one batch row per workgroup of 16 waves:
 // score_j = v . tanh(keys_j + q), softmax over the live positions (-inf mask), context = sum_j a_j values_j.  Wave w owns the
-// positions j = w (mod 16) in both sweeps, a lane the features lane + 64 i; three positions are in flight per wave (the loads of a
+// positions j = w (mod 16) in both sweeps, a lane the features lane + 64 i; five positions are in flight per wave (the loads of a
 // sweep are independent: issued together, clamped instead of branched), partial contexts of the 16 waves are added in wave order.
 // tanh on the hardware exp / rcp (fast_tanhf, ~1e-6); the backward kernel uses the same function.
 #define V1D_ATT_THREADS 1024
-#define V1D_ATT_U 3
+#define V1D_ATT_U 5
 template <bool COH>
 __device__ __forceinline__ void v1d_attn_fwd_body(const float* __restrict__ keys, const float* __restrict__ values, const float* q,
                                                   const float* __restrict__ v, const int* __restrict__ lens, int T, int A, int E,
@@ -103,13 +103,19 @@ __device__ __forceinline__ void v1d_attn_fwd_body(const float* __restrict__ keys
         float p[U];
 #pragma unroll
         for (int i = 0; i < U; ++i) p[i] = 0.f;
-        for (int u = lane; u < A; u += 64) {
-            float kk[U];
+        for (int u0 = 0; u0 < A; u0 += 256) {
+            float kk[U][4];
 #pragma unroll
-            for (int i = 0; i < U; ++i) kk[i] = keys[((size_t)b * T + min(j0 + i * NW, len - 1)) * A + u];
-            const float qv = s_q[u], vv = s_v[u];
+            for (int i = 0; i < U; ++i)
 #pragma unroll
-            for (int i = 0; i < U; ++i) p[i] += vv * fast_tanhf(kk[i] + qv);
+                for (int c = 0; c < 4; ++c) kk[i][c] = keys[((size_t)b * T + min(j0 + i * NW, len - 1)) * A + min(u0 + lane + 64 * c, A - 1)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int u = u0 + lane + 64 * c;
+                const float qv = s_q[min(u, A - 1)], vv = u < A ? s_v[u] : 0.f;
+#pragma unroll
+                for (int i = 0; i < U; ++i) p[i] += vv * fast_tanhf(kk[i][c] + qv);
+            }
         }
 #pragma unroll
         for (int i = 0; i < U; ++i) {
@@ -192,13 +198,19 @@ __device__ __forceinline__ void v1d_attn_bwd_body(const float* __restrict__ keys
         float p[U];
 #pragma unroll
         for (int i = 0; i < U; ++i) p[i] = 0.f;
-        for (int e = lane; e < E; e += 64) {
-            float vv[U];
+        for (int e0 = 0; e0 < E; e0 += 256) {
+            float vv[U][4];
 #pragma unroll
-            for (int i = 0; i < U; ++i) vv[i] = values[((size_t)b * T + min(j0 + i * NW, len - 1)) * E + e];
-            const float dc = s_dc[e];
+            for (int i = 0; i < U; ++i)
 #pragma unroll
-            for (int i = 0; i < U; ++i) p[i] += dc * vv[i];
+                for (int c = 0; c < 4; ++c) vv[i][c] = values[((size_t)b * T + min(j0 + i * NW, len - 1)) * E + min(e0 + lane + 64 * c, E - 1)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = e0 + lane + 64 * c;
+                const float dc = e < E ? s_dc[e] : 0.f;
+#pragma unroll
+                for (int i = 0; i < U; ++i) p[i] += dc * vv[i][c];
+            }
         }
 #pragma unroll
         for (int i = 0; i < U; ++i) {
@@ -515,6 +527,7 @@ __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const fl
 #pragma unroll
             for (int j = 0; j < 4; ++j) bw[i][j] = w[(size_t)(k0 + j) * N + n];
         }
+        if constexpr (COH) __builtin_amdgcn_sched_barrier(0);     // every load of the batch is in flight before the first product waits
 #pragma unroll
         for (int i = 0; i < UK; ++i) {
             const bool live = kb0 + NWV * i < nkb;           // a clamped (repeated) k-block contributes nothing
