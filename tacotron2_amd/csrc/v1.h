@@ -46,7 +46,15 @@ struct t2v1_model {
     std::vector<t2v1_state*> states;
     int* h_ctl = nullptr;
     int opt_graph = 1, opt_chunk = 16;
+    // teacher-forced decodes on the training forward's persistent launch (v1_dec_train.h, v1_teacher_via_trainer)
+    int opt_tf_persist = 1;
+    float* tf_flat = nullptr;                              // flat copy of the v1/decoder/ and v1/attention/ variables (TF layouts)
+    std::map<std::string, long long> tf_offsets;
+    std::vector<struct t2v1_dtrainer*> tf_trainers;
 };
+static int v1_teacher_via_trainer(t2v1_model* m, const float* memory, const int64_t* lens, const float* targets, int B, int T_in, int S, float* mel, float* stop,
+                                  float* align, bool* done);
+static void v1_tf_trainers_free(t2v1_model* m);
 
 struct t2v1_state {
     t2v1_model* m = nullptr;
@@ -195,6 +203,7 @@ extern "C" int t2v1_model_set_option(t2v1_model* m, const char* name, int value)
     if (!strcmp(name, "graph")) m->opt_graph = value;
     else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
     else if (!strcmp(name, "skinny")) m->opt_skinny = value;
+    else if (!strcmp(name, "tf_persist")) m->opt_tf_persist = value;
     else if (!strcmp(name, "train_persist")) { m->opt_train_persist = value; m->base.persist_holdoff = 0; }
     else if (!strcmp(name, "inject_timeout")) m->base.opt_inject_timeout = value;
     else if (!strcmp(name, "gruseq")) {
@@ -270,6 +279,16 @@ extern "C" int t2v1_model_finalize(t2v1_model* m) {
     T2_TRY(upload(b, &m->zeros, std::vector<float>((size_t)std::max(A, 16) + 16, 0.f)));
     HIP_TRY(hipHostMalloc((void**)&m->h_ctl, 8 * sizeof(int), hipHostMallocDefault));
     T2_TRY(set_attention_func_attributes());
+    {   // the decoder's variables once more as one flat buffer in TF layouts: what the training forward reads (teacher-forced decodes)
+        std::vector<float> flat;
+        for (const auto& kv : b->hw) {
+            if (kv.first.rfind("v1/decoder/", 0) != 0 && kv.first.rfind("v1/attention/", 0) != 0) continue;
+            m->tf_offsets[kv.first] = (long long)flat.size();
+            flat.insert(flat.end(), kv.second.data.begin(), kv.second.data.end());
+            flat.resize((flat.size() + 3) & ~(size_t)3, 0.f);
+        }
+        T2_TRY(upload(b, &m->tf_flat, flat));
+    }
     b->hw.clear();
     b->finalized = true;
     return T2_OK;
@@ -290,6 +309,7 @@ extern "C" int t2v1_model_destroy(t2v1_model* m) {
     (void)hipSetDevice(m->base.ctx->device);
     (void)hipStreamSynchronize(m->base.ctx->stream);
     for (t2v1_state* s : m->states) v1_state_free(s);
+    v1_tf_trainers_free(m);
     for (void* p : m->base.allocs) (void)hipFree(p);
     if (m->ws) (void)hipFree(m->ws);
     if (m->h_ctl) (void)hipHostFree(m->h_ctl);
@@ -808,6 +828,11 @@ extern "C" int t2v1_decode_teacher(t2v1_model* m, const float* memory, const int
     if (T_out < r || T_out % r != 0) return fail(T2_EINVAL, "T_out must be a positive multiple of outputs_per_step");
     hipStream_t st = m->base.ctx->stream;
     const int S = T_out / r;
+    if (teacher_forcing) {                          // the training forward's persistent launch where the shape allows
+        bool done = false;
+        T2_TRY(v1_teacher_via_trainer(m, memory, lens, targets, B, T_in, S, mel, stop, align, &done));
+        if (done) return T2_OK;
+    }
     t2v1_state* s = nullptr;
     T2_TRY(v1_get_state(m, B, T_in, S, &s));
     T2_TRY(v1_state_init(s, memory, lens, S, 0, 0));

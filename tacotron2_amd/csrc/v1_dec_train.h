@@ -397,11 +397,22 @@ struct SkEpi {
     const float* cin = nullptr; float* dctx = nullptr; long long row_stride = 0; int A = 0;      // DCTX (as v1d_dctx_kernel)
     SkBwd1 b1x, b1c;   // BWD3: stage 1 of the cell fed by d x (same step) / of this cell one step earlier (fed by the carry); BWD1: b1x on v
 };
+#ifdef V1D_STAMPS
+__device__ unsigned long long g_v1d_body[8];                // diagnostic: ticks of a product stage up to [0] loads issued, [1] K loop done, [2] reduced (barrier), [3] end
+#endif
 // what an output element's epilogue reads besides the product, fetched before the K loop so that its latency hides behind it
 struct SkPre { float f[6]; };
-template <bool COH>
+// Which optional parts of SkEpi a stage uses: SKF_DYN = look at the pointers (the one-launch-per-stage kernels), otherwise a
+// compile-time set (the persistent kernels: no branches around the loads, so that all of them are in flight together).
+enum { SKF_DYN = 1 << 15, SKF_BIAS = 1, SKF_RES = 2, SKF_Y = 4, SKF_H0 = 8, SKF_H1 = 16, SKF_Y0 = 32, SKF_Y1 = 64, SKF_DRES = 128, SKF_B1X = 256, SKF_B1C = 512,
+       SKF_ADD = 1024 };
+template <int FL, int F> __device__ __forceinline__ bool sk_has(const void* p) {
+    if constexpr ((FL & SKF_DYN) != 0) return p != nullptr;
+    else return (FL & F) != 0;
+}
+template <bool COH, int FL>
 __device__ __forceinline__ void sk_bwd1_load(const SkBwd1& q, int row, int u, float* o) {
-    o[0] = q.add ? v1_ld<COH>(q.add + (size_t)row * q.ldadd + u) : 0.f;
+    o[0] = sk_has<FL, SKF_ADD>(q.add) ? v1_ld<COH>(q.add + (size_t)row * q.ldadd + u) : 0.f;
     o[1] = v1_ld<COH>(q.ru + (size_t)row * 2 * q.H + q.H + u); o[2] = v1_ld<COH>(q.cnd + (size_t)row * q.H + u);
     o[3] = v1_ld<COH>(q.cat + (size_t)row * (q.X + q.H) + q.X + u);
 }
@@ -413,19 +424,19 @@ __device__ __forceinline__ void sk_bwd1_apply(const SkBwd1& q, int row, int u, f
     v1_st<COH>(q.dzg + (size_t)row * 2 * q.H + q.H + u, dh * (h - c) * uu * (1.0f - uu));
     v1_st<COH>(q.keep + (size_t)row * q.H + u, dh * uu);
 }
-template <int EPI, bool COH>
+template <int EPI, bool COH, int FL>
 __device__ __forceinline__ SkPre sk_pre(const SkEpi& e, int row, int col, int N) {
     SkPre p;
 #pragma unroll
     for (int i = 0; i < 6; ++i) p.f[i] = 0.f;
-    if (e.bias) p.f[0] = e.bias[col];
-    if (e.res) p.f[0] += v1_ld<COH>(e.res + (size_t)row * e.ldr + col);
+    if (sk_has<FL, SKF_BIAS>(e.bias)) p.f[0] = e.bias[col];
+    if (sk_has<FL, SKF_RES>(e.res)) p.f[0] += v1_ld<COH>(e.res + (size_t)row * e.ldr + col);
     const int X = e.X, H = e.H, Wd = X + H;
     if constexpr (EPI == SK_GATE) {
         if (col < H) p.f[1] = v1_ld<COH>(e.cat + (size_t)row * Wd + X + col);
     } else if constexpr (EPI == SK_BLEND) {
         p.f[1] = v1_ld<COH>(e.ru + (size_t)row * 2 * H + H + col); p.f[2] = v1_ld<COH>(e.cat + (size_t)row * Wd + X + col);
-        if (e.y0.p || e.y1.p) p.f[3] = v1_ld<COH>(e.cat + (size_t)row * Wd + col);
+        if (sk_has<FL, SKF_Y0>(e.y0.p) || sk_has<FL, SKF_Y1>(e.y1.p)) p.f[3] = v1_ld<COH>(e.cat + (size_t)row * Wd + col);
     } else if constexpr (EPI == SK_BWD2) {
         if (col >= X) {
             p.f[1] = v1_ld<COH>(e.ru + (size_t)row * 2 * H + col - X); p.f[2] = v1_ld<COH>(e.cat + (size_t)row * Wd + col);
@@ -434,23 +445,23 @@ __device__ __forceinline__ SkPre sk_pre(const SkEpi& e, int row, int col, int N)
     } else if constexpr (EPI == SK_BWD3) {
         if (col < X) {
             p.f[1] = v1_ld<COH>(e.dcatr + (size_t)row * Wd + col);
-            if (e.dres) p.f[1] += v1_ld<COH>(e.dres + (size_t)row * e.ldres + col);
-            if (e.b1x.dzc) sk_bwd1_load<COH>(e.b1x, row, col, p.f + 2);
+            if (sk_has<FL, SKF_DRES>(e.dres)) p.f[1] += v1_ld<COH>(e.dres + (size_t)row * e.ldres + col);
+            if (sk_has<FL, SKF_B1X>(e.b1x.dzc)) sk_bwd1_load<COH, FL>(e.b1x, row, col, p.f + 2);
         } else {
             p.f[1] = v1_ld<COH>(e.keep + (size_t)row * H + col - X);
-            if (e.b1c.dzc) sk_bwd1_load<COH>(e.b1c, row, col - X, p.f + 2);
+            if (sk_has<FL, SKF_B1C>(e.b1c.dzc)) sk_bwd1_load<COH, FL>(e.b1c, row, col - X, p.f + 2);
         }
     } else if constexpr (EPI == SK_DCTX) {
         if (col >= e.A) p.f[1] = v1_ld<COH>(e.cin + (size_t)row * (N - e.A) + col - e.A);
     } else if constexpr (EPI == SK_BWD1) {
-        sk_bwd1_load<COH>(e.b1x, row, col, p.f + 2);
+        sk_bwd1_load<COH, FL>(e.b1x, row, col, p.f + 2);
     }
     return p;
 }
-template <int EPI, bool COH>
+template <int EPI, bool COH, int FL>
 __device__ __forceinline__ void sk_post(const SkEpi& e, int row, int col, float v, const SkPre& p) {
     v += p.f[0];
-    if (e.y) v1_st<COH>(e.y + (size_t)row * e.ldy + col, v);
+    if (sk_has<FL, SKF_Y>(e.y)) v1_st<COH>(e.y + (size_t)row * e.ldy + col, v);
     const int X = e.X, H = e.H, Wd = X + H;
     if constexpr (EPI == SK_GATE) {                   // N = 2H: [r | u] = sigmoid(v); [x | r h]
         const float sg = sigmoidf_(v);
@@ -460,12 +471,12 @@ __device__ __forceinline__ void sk_post(const SkEpi& e, int row, int col, float 
         const float cc = tanhf(v), uu = p.f[1], h = p.f[2];
         const float hn = uu * h + (1.0f - uu) * cc;
         v1_st<COH>(e.cnd + (size_t)row * H + col, cc);
-        if (e.h0.p) v1_st<COH>(e.h0.p + (size_t)row * e.h0.ld + col, hn);
-        if (e.h1.p) v1_st<COH>(e.h1.p + (size_t)row * e.h1.ld + col, hn);
-        if (e.y0.p || e.y1.p) {
+        if (sk_has<FL, SKF_H0>(e.h0.p)) v1_st<COH>(e.h0.p + (size_t)row * e.h0.ld + col, hn);
+        if (sk_has<FL, SKF_H1>(e.h1.p)) v1_st<COH>(e.h1.p + (size_t)row * e.h1.ld + col, hn);
+        if (sk_has<FL, SKF_Y0>(e.y0.p) || sk_has<FL, SKF_Y1>(e.y1.p)) {
             const float yy = p.f[3] + hn;
-            if (e.y0.p) v1_st<COH>(e.y0.p + (size_t)row * e.y0.ld + col, yy);
-            if (e.y1.p) v1_st<COH>(e.y1.p + (size_t)row * e.y1.ld + col, yy);
+            if (sk_has<FL, SKF_Y0>(e.y0.p)) v1_st<COH>(e.y0.p + (size_t)row * e.y0.ld + col, yy);
+            if (sk_has<FL, SKF_Y1>(e.y1.p)) v1_st<COH>(e.y1.p + (size_t)row * e.y1.ld + col, yy);
         }
     } else if constexpr (EPI == SK_BWD2) {            // N = X + H: v = d [x | r h]; d zr, keep += d(r h) r
         if (col >= X) {
@@ -477,11 +488,11 @@ __device__ __forceinline__ void sk_post(const SkEpi& e, int row, int col, float 
         if (col < X) {
             const float g = p.f[1] + v;
             v1_st<COH>(e.dx + (size_t)row * e.lddx + col, g);
-            if (e.b1x.dzc) sk_bwd1_apply<COH>(e.b1x, row, col, g, p.f + 2);
+            if (sk_has<FL, SKF_B1X>(e.b1x.dzc)) sk_bwd1_apply<COH>(e.b1x, row, col, g, p.f + 2);
         } else {
             const float cr = p.f[1] + v;
             v1_st<COH>(e.carry + (size_t)row * H + col - X, cr);
-            if (e.b1c.dzc) sk_bwd1_apply<COH>(e.b1c, row, col - X, cr, p.f + 2);
+            if (sk_has<FL, SKF_B1C>(e.b1c.dzc)) sk_bwd1_apply<COH>(e.b1c, row, col - X, cr, p.f + 2);
         }
     } else if constexpr (EPI == SK_DCTX) {            // N = A + E: v = d [h_att | ctx] of the output projection
         if (col >= e.A) v1_st<COH>(e.dctx + (size_t)row * e.row_stride + col - e.A, v + p.f[1]);
@@ -490,7 +501,7 @@ __device__ __forceinline__ void sk_post(const SkEpi& e, int row, int col, float 
     }
 }
 // one product + epilogue by workgroup `wg` of `nwg` (16 columns each) with NWV waves; red: LDS [NWV][MB][64] float4
-template <int MB, int EPI, int NWV, bool COH>
+template <int MB, int EPI, int NWV, bool COH, int FL = SKF_DYN>
 __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const float* __restrict__ w, int N, const SkEpi& e, int rows, int wg, int nwg,
                                         f32x4* red) {
     constexpr int NT_ = 64 * NWV, UK = NWV >= 16 ? 2 : 4, EL = (MB * 256 + NT_ - 1) / NT_;       // UK k-blocks in flight per wave: K <= 512 is one batch
@@ -501,11 +512,18 @@ __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const fl
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = lane >> 4, c16 = lane & 15;
     const int n0 = wg * 16, n = min(n0 + c16, N - 1);
     // epilogue ownership: element i = tid + NT_ * el -> (row, column) with the column fastest
+#ifdef V1D_STAMPS
+    const bool stamp_ = COH && wg == 0 && threadIdx.x == 0;
+    unsigned long long tb_ = __builtin_amdgcn_s_memrealtime();
+#define SKB_STAMP(i) do { if (stamp_) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); g_v1d_body[i] += n_ - tb_; tb_ = n_; } } while (0)
+#else
+#define SKB_STAMP(i) do { } while (0)
+#endif
     SkPre pre[EL];
 #pragma unroll
     for (int el = 0; el < EL; ++el) {
         const int i = tid + NT_ * el, row = i >> 4, col = n0 + (i & 15);
-        if (i < MB * 256 && row < rows && col < N) pre[el] = sk_pre<EPI, COH>(e, row, col, N);
+        if (i < MB * 256 && row < rows && col < N) pre[el] = sk_pre<EPI, COH, FL>(e, row, col, N);
     }
     f32x4 acc[MB];
 #pragma unroll
@@ -528,6 +546,7 @@ __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const fl
             for (int j = 0; j < 4; ++j) bw[i][j] = w[(size_t)(k0 + j) * N + n];
         }
         if constexpr (COH) __builtin_amdgcn_sched_barrier(0);     // every load of the batch is in flight before the first product waits
+        SKB_STAMP(0);
 #pragma unroll
         for (int i = 0; i < UK; ++i) {
             const bool live = kb0 + NWV * i < nkb;           // a clamped (repeated) k-block contributes nothing
@@ -541,6 +560,7 @@ __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const fl
     }
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
+    SKB_STAMP(1);
     if constexpr (EPI == SK_GATE) {
         // the x half of the candidate's operand is a copy: every workgroup moves its share of the rows * X words
         const int total = rows * e.X, per = (total + nwg - 1) / nwg, Wd = e.X + e.H;
@@ -550,6 +570,7 @@ __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const fl
         }
     }
     __syncthreads();
+    SKB_STAMP(2);
     // D layout: reg r of lane (kg, c16) = row 4 kg + r, column c16
 #pragma unroll
     for (int el = 0; el < EL; ++el) {
@@ -559,8 +580,9 @@ __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const fl
         float v = 0.f;
 #pragma unroll
         for (int wv = 0; wv < NWV; ++wv) v += red[(wv * MB + rb) * 64 + l][r];
-        sk_post<EPI, COH>(e, row, col, v, pre[el]);
+        sk_post<EPI, COH, FL>(e, row, col, v, pre[el]);
     }
+    SKB_STAMP(3);
 }
 #define V1D_SK_WAVES 8
 template <int MB, int EPI>
@@ -577,6 +599,16 @@ __global__ __launch_bounds__(64 * V1D_SK_WAVES) void v1d_skinny_gemm_kernel(cons
 // owns output columns 16 g .. 16 g + 15 of a product (or batch row g of the attention); workgroups beyond a stage's width only
 // hop.  Every spin is bounded (persist.h SPIN_LIMIT_TICKS): a timeout leaves the loop with the error word set and the caller
 // re-runs the recurrence on the launch-per-stage schedule.
+// Diagnostic builds only (-DV1D_STAMPS, tools/v1_train_stamps.py): thread 0 of the first workgroup of each half sums the time
+// (s_memrealtime, 10 ns ticks) spent in stage bodies / arrive / wait per stage slot; the product build has no stamps.
+#ifdef V1D_STAMPS
+__device__ unsigned long long g_v1d_stamps[2][2][16];       // [kernel][half][3 * slot + {body, arrive, wait}]
+#define V1D_STAMP(kern, i) do { if (threadIdx.x == 0 && lw == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    g_v1d_stamps[kern][grp][i] += now_ - st_prev; st_prev = now_; } } while (0)
+#else
+#define V1D_STAMP(kern, i) do { } while (0)
+#endif
+template <int F> using FLG = std::integral_constant<int, F>;
 struct V1PFwd {
     int B, T, S, A, E, D;
     const float *Wga, *Wca;                    // rows [P1, P1 + E + A) of the attention GRU's kernels (the PreNet rows are batched)
@@ -603,25 +635,35 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_fwd_persist_kernel(V1PFwd
     const unsigned per = gridDim.x / pz::NSHARD;
     unsigned epoch = 0;
     f32x4* red = reinterpret_cast<f32x4*>(dsm);
-    auto hop = [&]() -> bool { pz::hop_arrive(a.bar); ++epoch; return pz::hop_wait(a.bar, per * epoch, &s_abort); };
-    auto gates = [&](const float* cat, float* catr, int X, int H, const float* Wg, const float* bg, const float* zgp, float* ru) {
+    [[maybe_unused]] unsigned long long st_prev = __builtin_amdgcn_s_memrealtime();
+    int slot = 0;
+    auto hop = [&]() -> bool {
+        V1D_STAMP(0, 3 * slot); pz::hop_arrive(a.bar); V1D_STAMP(0, 3 * slot + 1); ++epoch;
+        const bool r = pz::hop_wait(a.bar, per * epoch, &s_abort);
+        V1D_STAMP(0, 3 * slot + 2); slot = slot == 4 ? 0 : slot + 1;
+        return r;
+    };
+    auto gates = [&](auto fl, const float* cat, float* catr, int X, int H, const float* Wg, const float* bg, const float* zgp, float* ru) {
+        constexpr int FL = decltype(fl)::value;
         const int Wd = X + H, ng = (2 * H + 15) / 16;
         if (lw >= ng) return;
         SkEpi g; g.bias = bg; g.res = zgp; g.ldr = 2 * H; g.cat = cat; g.X = X; g.H = H; g.ru = ru; g.catr = catr;
-        sk_body<MB, SK_GATE, NWV, true>(cat, Wd, Wd, Wg, 2 * H, g, B, lw, ng, red);
+        sk_body<MB, SK_GATE, NWV, true, FL>(cat, Wd, Wd, Wg, 2 * H, g, B, lw, ng, red);
     };
-    auto blend = [&](const float* cat, const float* catr, int X, int H, const float* Wc, const float* bc, const float* zcp, float* ru, float* cnd, V1Dst h0, V1Dst h1,
+    auto blend = [&](auto fl, const float* cat, const float* catr, int X, int H, const float* Wc, const float* bc, const float* zcp, float* ru, float* cnd, V1Dst h0, V1Dst h1,
                      V1Dst y0) {
+        constexpr int FL = decltype(fl)::value;
         const int Wd = X + H, nc = (H + 15) / 16;
         if (lw >= nc) return;
         SkEpi c; c.bias = bc; c.res = zcp; c.ldr = H; c.cat = cat; c.X = X; c.H = H; c.ru = ru; c.cnd = cnd; c.h0 = h0; c.h1 = h1; c.y0 = y0;
-        sk_body<MB, SK_BLEND, NWV, true>(catr, Wd, Wd, Wc, H, c, B, lw, nc, red);
+        sk_body<MB, SK_BLEND, NWV, true, FL>(catr, Wd, Wd, Wc, H, c, B, lw, nc, red);
     };
-    auto plain = [&](const float* x, int ldx, int K, const float* w, int N, const float* bias, float* y, int ldy) {
+    auto plain = [&](auto fl, const float* x, int ldx, int K, const float* w, int N, const float* bias, float* y, int ldy) {
+        constexpr int FL = decltype(fl)::value;
         const int nw = (N + 15) / 16;
         if (lw >= nw) return;
         SkEpi e; e.bias = bias; e.y = y; e.ldy = ldy;
-        sk_body<MB, SK_PLAIN, NWV, true>(x, ldx, K, w, N, e, B, lw, nw, red);
+        sk_body<MB, SK_PLAIN, NWV, true, FL>(x, ldx, K, w, N, e, B, lw, nw, red);
     };
     bool ok = true;
     for (int i = 0; i <= S; ++i) {
@@ -634,27 +676,27 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_fwd_persist_kernel(V1PFwd
         float *cat2 = a.CAT2 + tt * B * 2 * D, *cat2_n = cat2 + (size_t)B * 2 * D, *cat2r = a.CAT2R + tt * B * 2 * D;
         float *rua = a.RUa + tt * B * 2 * A, *ru1 = a.RU1 + tt * B * 2 * D, *ru2 = a.RU2 + tt * B * 2 * D, *q = a.Q + tt * B * A;
         if (act) {
-            if (grp) gates(cata, catar, E, A, a.Wga, nullptr, a.zgp + tt * B * 2 * A, rua);
-            else plain(cato, A + E, A + E, a.Wo, D, a.bo, cat1, 2 * D);
+            if (grp) gates(FLG<SKF_RES>{}, cata, catar, E, A, a.Wga, nullptr, a.zgp + tt * B * 2 * A, rua);
+            else plain(FLG<SKF_BIAS | SKF_Y>{}, cato, A + E, A + E, a.Wo, D, a.bo, cat1, 2 * D);
         }
         if (!(ok = hop())) break;
         if (act) {
-            if (grp) blend(cata, catar, E, A, a.Wca, nullptr, a.zcp + tt * B * A, rua, a.Ca + tt * B * A, V1Dst{cato, A + E}, V1Dst{cata_n + E, XA}, V1Dst{nullptr, 0});
-            else gates(cat1, cat1r, D, D, a.Wg1, a.bg1, nullptr, ru1);
+            if (grp) blend(FLG<SKF_RES | SKF_H0 | SKF_H1>{}, cata, catar, E, A, a.Wca, nullptr, a.zcp + tt * B * A, rua, a.Ca + tt * B * A, V1Dst{cato, A + E}, V1Dst{cata_n + E, XA}, V1Dst{nullptr, 0});
+            else gates(FLG<SKF_BIAS>{}, cat1, cat1r, D, D, a.Wg1, a.bg1, nullptr, ru1);
         }
         if (!(ok = hop())) break;
         if (act) {
-            if (grp) plain(cato, A + E, A, a.Wq, A, nullptr, q, A);
-            else blend(cat1, cat1r, D, D, a.Wc1, a.bc1, nullptr, ru1, a.C1 + tt * B * D, V1Dst{cat1_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{cat2, 2 * D});
+            if (grp) plain(FLG<SKF_Y>{}, cato, A + E, A, a.Wq, A, nullptr, q, A);
+            else blend(FLG<SKF_BIAS | SKF_H0 | SKF_Y0>{}, cat1, cat1r, D, D, a.Wc1, a.bc1, nullptr, ru1, a.C1 + tt * B * D, V1Dst{cat1_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{cat2, 2 * D});
         }
         if (!(ok = hop())) break;
         if (act) {
             if (grp) {
                 if (lw < B) v1d_attn_fwd_body<true>(a.keys, a.values, q, a.va, a.lens, T, A, E, a.ALIGN + tt * B * T, V1Dst{cato + A, A + E}, V1Dst{cata_n, XA}, lw, dsm, s_red);
-            } else gates(cat2, cat2r, D, D, a.Wg2, a.bg2, nullptr, ru2);
+            } else gates(FLG<SKF_BIAS>{}, cat2, cat2r, D, D, a.Wg2, a.bg2, nullptr, ru2);
         }
         if (!(ok = hop())) break;
-        if (act && !grp) blend(cat2, cat2r, D, D, a.Wc2, a.bc2, nullptr, ru2, a.C2 + tt * B * D, V1Dst{cat2_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{a.Y2 + tt * B * D, D});
+        if (act && !grp) blend(FLG<SKF_BIAS | SKF_H0 | SKF_Y0>{}, cat2, cat2r, D, D, a.Wc2, a.bc2, nullptr, ru2, a.C2 + tt * B * D, V1Dst{cat2_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{a.Y2 + tt * B * D, D});
         if (!(ok = hop())) break;
     }
     if (!ok && threadIdx.x == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -665,7 +707,7 @@ struct V1PBwd {
     const int* lens;
     const float *CATA, *RUa, *Ca, *Q, *ALIGN, *CAT1, *RU1, *C1, *CAT2, *RU2, *C2, *DY2;
     float *DZC2, *DZG2, *DZC1, *DZG1, *DY0, *DQ, *DZCa, *DZGa, *DCTX, *dkeys, *dvpart;
-    float *cHA, *cCTX, *cH1, *cH2, *keep, *keep1, *keepA, *dcatr, *dcatrA, *dy1, *dcato;
+    float *cHA, *cCTX, *cH1, *cH2, *keep, *keep1, *keepA, *dcatr, *dcatrA, *dy1, *dcato, *sink;
     unsigned* bar; int* err;
 };
 // Backward, last step first: the same split --
@@ -684,22 +726,30 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
     const unsigned per = gridDim.x / pz::NSHARD;
     unsigned epoch = 0;
     f32x4* red = reinterpret_cast<f32x4*>(dsm);
-    auto hop = [&]() -> bool { pz::hop_arrive(a.bar); ++epoch; return pz::hop_wait(a.bar, per * epoch, &s_abort); };
+    [[maybe_unused]] unsigned long long st_prev = __builtin_amdgcn_s_memrealtime();
+    int slot = 0;
+    auto hop = [&]() -> bool {
+        V1D_STAMP(1, 3 * slot); pz::hop_arrive(a.bar); V1D_STAMP(1, 3 * slot + 1); ++epoch;
+        const bool r = pz::hop_wait(a.bar, per * epoch, &s_abort);
+        V1D_STAMP(1, 3 * slot + 2); slot = slot == 4 ? 0 : slot + 1;
+        return r;
+    };
     // stages 2 and 3 of a GRU cell's backward (stage 1 rode in the epilogue that produced the cell's d h')
     auto stage2 = [&](const float* cat, const float* ru, int X, int H, const float* WcT, const float* dzc, float* dzg, float* keep, float* dcatr) {
         const int Wd = X + H, nw = (Wd + 15) / 16;
         if (lw >= nw) return;
         SkEpi e2; e2.y = dcatr; e2.ldy = Wd; e2.cat = cat; e2.X = X; e2.H = H; e2.ru = const_cast<float*>(ru); e2.dzg = dzg; e2.keep = keep;
-        sk_body<MB, SK_BWD2, NWV, true>(dzc, H, H, WcT, Wd, e2, B, lw, nw, red);
+        sk_body<MB, SK_BWD2, NWV, true, SKF_Y>(dzc, H, H, WcT, Wd, e2, B, lw, nw, red);
     };
-    auto stage3 = [&](int X, int H, const float* WgT, const float* dzg, const float* dres, int ldres, float* carry, float* dx, int lddx, float* keep, const float* dcatr,
+    auto stage3 = [&](auto fl, int X, int H, const float* WgT, const float* dzg, const float* dres, int ldres, float* carry, float* dx, int lddx, float* keep, const float* dcatr,
                       const SkBwd1* b1x, const SkBwd1* b1c) {
+        constexpr int FL = decltype(fl)::value;
         const int Wd = X + H, nw = (Wd + 15) / 16;
         if (lw >= nw) return;
         SkEpi e3; e3.X = X; e3.H = H; e3.dcatr = dcatr; e3.dres = dres; e3.ldres = ldres; e3.keep = keep; e3.carry = carry; e3.dx = dx; e3.lddx = lddx;
         if (b1x) e3.b1x = *b1x;
         if (b1c) e3.b1c = *b1c;
-        sk_body<MB, SK_BWD3, NWV, true>(dzg, 2 * H, 2 * H, WgT, Wd, e3, B, lw, nw, red);
+        sk_body<MB, SK_BWD3, NWV, true, FL>(dzg, 2 * H, 2 * H, WgT, Wd, e3, B, lw, nw, red);
     };
     bool ok = true;
     for (int i = 0; i <= S; ++i) {
@@ -715,7 +765,7 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
             if (!grp) stage2(cat2, a.RU2 + tt * B * 2 * D, D, D, a.Wc2T, a.DZC2 + tt * B * D, a.DZG2 + tt * B * 2 * D, a.keep, a.dcatr);
             else if (lw < (A + E + 15) / 16) {
                 SkEpi e; e.y = a.dcato; e.ldy = A + E; e.cin = a.cCTX; e.dctx = dctx_t; e.row_stride = (long long)S * E; e.A = A;
-                sk_body<MB, SK_DCTX, NWV, true>(dy0, D, D, a.WoT, A + E, e, B, lw, (A + E + 15) / 16, red);
+                sk_body<MB, SK_DCTX, NWV, true, SKF_Y>(dy0, D, D, a.WoT, A + E, e, B, lw, (A + E + 15) / 16, red);
             }
         }
         if (!(ok = hop())) break;
@@ -724,13 +774,11 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
             if (!grp) {
                 SkBwd1 s1; s1.add = a.cH1; s1.ldadd = D; s1.cat = cat1; s1.ru = a.RU1 + tt * B * 2 * D; s1.cnd = a.C1 + tt * B * D; s1.X = D; s1.H = D;
                 s1.dzc = a.DZC1 + tt * B * D; s1.dzg = a.DZG1 + tt * B * 2 * D; s1.keep = a.keep1;
-                SkBwd1 s2;
-                if (t > 0) {
-                    const size_t u = tt - 1;
-                    s2.add = a.DY2 + u * B * D; s2.ldadd = D; s2.cat = a.CAT2 + u * B * 2 * D; s2.ru = a.RU2 + u * B * 2 * D; s2.cnd = a.C2 + u * B * D; s2.X = D; s2.H = D;
-                    s2.dzc = a.DZC2 + u * B * D; s2.dzg = a.DZG2 + u * B * 2 * D; s2.keep = a.keep;
-                }
-                stage3(D, D, a.Wg2T, a.DZG2 + tt * B * 2 * D, dy2, D, a.cH2, a.dy1, D, a.keep, a.dcatr, &s1, t > 0 ? &s2 : nullptr);
+                SkBwd1 s2;                                       // GRU 2 one step earlier; at t = 0 the same loads, results into the sink
+                const size_t u = t > 0 ? tt - 1 : 0;
+                s2.add = a.DY2 + u * B * D; s2.ldadd = D; s2.cat = a.CAT2 + u * B * 2 * D; s2.ru = a.RU2 + u * B * 2 * D; s2.cnd = a.C2 + u * B * D; s2.X = D; s2.H = D;
+                s2.dzc = t > 0 ? a.DZC2 + u * B * D : a.sink; s2.dzg = t > 0 ? a.DZG2 + u * B * 2 * D : a.sink; s2.keep = t > 0 ? a.keep : a.sink;
+                stage3(FLG<SKF_DRES | SKF_B1X | SKF_B1C | SKF_ADD>{}, D, D, a.Wg2T, a.DZG2 + tt * B * 2 * D, dy2, D, a.cH2, a.dy1, D, a.keep, a.dcatr, &s1, &s2);
             } else if (lw < B) {
                 v1d_attn_bwd_body<true>(a.keys, a.values, a.Q + tt * B * A, a.va, a.lens, a.ALIGN + tt * B * T, dctx_t, (long long)S * E, T, A, E, dq, a.dkeys, a.dvpart, lw,
                                         dsm, s_red);
@@ -744,18 +792,18 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
                 SkEpi e; e.res = a.dcato; e.ldr = A + E;
                 e.b1x.add = a.cHA; e.b1x.ldadd = A; e.b1x.cat = cata; e.b1x.ru = a.RUa + tt * B * 2 * A; e.b1x.cnd = a.Ca + tt * B * A; e.b1x.X = E; e.b1x.H = A;
                 e.b1x.dzc = a.DZCa + tt * B * A; e.b1x.dzg = a.DZGa + tt * B * 2 * A; e.b1x.keep = a.keepA;
-                sk_body<MB, SK_BWD1, NWV, true>(dq, A, A, a.WqT, A, e, B, lw, (A + 15) / 16, red);
+                sk_body<MB, SK_BWD1, NWV, true, SKF_RES | SKF_ADD>(dq, A, A, a.WqT, A, e, B, lw, (A + 15) / 16, red);
             }
         }
         if (!(ok = hop())) break;
         // stage 3: GRU 1 stage 3 -> d y0 of this step | attention GRU stage 2
         if (act) {
-            if (!grp) stage3(D, D, a.Wg1T, a.DZG1 + tt * B * 2 * D, a.dy1, D, a.cH1, dy0, D, a.keep1, a.dcatr, nullptr, nullptr);
+            if (!grp) stage3(FLG<SKF_DRES>{}, D, D, a.Wg1T, a.DZG1 + tt * B * 2 * D, a.dy1, D, a.cH1, dy0, D, a.keep1, a.dcatr, nullptr, nullptr);
             else stage2(cata, a.RUa + tt * B * 2 * A, E, A, a.WcaT, a.DZCa + tt * B * A, a.DZGa + tt * B * 2 * A, a.keepA, a.dcatrA);
         }
         if (!(ok = hop())) break;
         // stage 4: - | attention GRU stage 3 -> the carries d h_att, d ctx of the step before
-        if (act && grp) stage3(E, A, a.WgaT, a.DZGa + tt * B * 2 * A, nullptr, 0, a.cHA, a.cCTX, E, a.keepA, a.dcatrA, nullptr, nullptr);
+        if (act && grp) stage3(FLG<0>{}, E, A, a.WgaT, a.DZGa + tt * B * 2 * A, nullptr, 0, a.cHA, a.cCTX, E, a.keepA, a.dcatrA, nullptr, nullptr);
         if (!(ok = hop())) break;
     }
     if (!ok && threadIdx.x == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -766,7 +814,7 @@ struct t2v1_dtrainer {
     int B = 0, T = 0, S = 0;
     t2_trainer ws;                       // workspace carrier of the shared helpers (split-K partials, column sums, offsets)
     char* slab = nullptr;
-    bool have_forward = false;
+    bool have_forward = false, forward_only = false;
     const float* params = nullptr;
     const float* glob_counts = nullptr;  // dev [2] or null
     float drop_rate = 0.f;
@@ -777,7 +825,7 @@ struct t2v1_dtrainer {
     float *zg, *zc, *mel_sb, *stop_sb, *mel_bt, *stop_bs, *loss6;
     // backward
     float *dmel_sb, *dstop_sb, *DY2, *DZG2, *DZC2, *DZG1, *DZC1, *DY0, *DQ, *DZGa, *DZCa, *DCTX, *dkeys, *dvpart, *dvalues;
-    float *cHA, *cCTX, *cH1, *cH2, *keep, *keep1, *keepA, *dcatr, *dcat, *dy1, *dy0, *dcato, *dha, *dP1, *dP0;
+    float *cHA, *cCTX, *cH1, *cH2, *keep, *keep1, *keepA, *sink, *dcatr, *dcat, *dy1, *dy0, *dcato, *dha, *dP1, *dP0;
     float *WmT, *WsT, *Wg2T, *Wc2T, *Wg1T, *Wc1T, *WoT, *WqT, *WgaT, *WcaT, *WgpT, *WcpT, *Wp1T, *WmemT;
     // the two recurrence loops as hipGraphs (S x 15 / S x 17 launches each): every pointer in them is the trainer's own or lies in
     // the flat parameter buffer, so a graph stays valid as long as that buffer's address does
@@ -827,7 +875,12 @@ extern "C" int t2v1_decoder_trainer_destroy(t2v1_dtrainer* tr) {
     return T2_OK;
 }
 
+static int dt_create(t2v1_model* m, int B, int T_in, int S, bool forward_only, t2v1_dtrainer** out);
 extern "C" int t2v1_decoder_trainer_create(t2v1_model* m, int B, int T_in, int S, t2v1_dtrainer** out) {
+    return dt_create(m, B, T_in, S, false, out);
+}
+// forward_only: the engine's own instance behind teacher-forced decodes (v1_teacher_via_trainer): no backward buffers
+static int dt_create(t2v1_model* m, int B, int T_in, int S, bool forward_only, t2v1_dtrainer** out) {
     T2_TRY(v1_ready(m));
     if (!out || S < 1) return fail(T2_EINVAL, "bad argument");
     T2_TRY(check_batch(B, T_in));
@@ -856,16 +909,19 @@ extern "C" int t2v1_decoder_trainer_create(t2v1_model* m, int B, int T_in, int S
     const size_t Hmax = std::max(A, D), Wmax = std::max(E + A, 2 * D);
     want(&tr->zg, (size_t)B * 2 * Hmax); want(&tr->zc, (size_t)B * Hmax);
     want(&tr->mel_sb, SB * rM); want(&tr->stop_sb, SB); want(&tr->mel_bt, SB * rM); want(&tr->stop_bs, SB); want(&tr->loss6, 8);
+    tr->forward_only = forward_only;
+    if (!forward_only) {
     want(&tr->dmel_sb, SB * rM); want(&tr->dstop_sb, SB); want(&tr->DY2, SB * D); want(&tr->DZG2, SB * 2 * D); want(&tr->DZC2, SB * D);
     want(&tr->DZG1, SB * 2 * D); want(&tr->DZC1, SB * D); want(&tr->DY0, SB * D); want(&tr->DQ, SB * A); want(&tr->DZGa, SB * 2 * A); want(&tr->DZCa, SB * A);
     want(&tr->DCTX, SB * E); want(&tr->dkeys, BT * A); want(&tr->dvpart, (size_t)B * A); want(&tr->dvalues, BT * E);
     want(&tr->cHA, (size_t)B * A); want(&tr->cCTX, (size_t)B * E); want(&tr->cH1, (size_t)B * D); want(&tr->cH2, (size_t)B * D);
-    want(&tr->keep, (size_t)B * Hmax); want(&tr->keep1, (size_t)B * Hmax); want(&tr->keepA, (size_t)B * Hmax); want(&tr->dcatr, (size_t)B * Wmax); want(&tr->dcat, (size_t)B * Wmax);
+    want(&tr->keep, (size_t)B * Hmax); want(&tr->keep1, (size_t)B * Hmax); want(&tr->keepA, (size_t)B * Hmax); want(&tr->sink, (size_t)B * 2 * Hmax); want(&tr->dcatr, (size_t)B * Wmax); want(&tr->dcat, (size_t)B * Wmax);
     want(&tr->dy1, (size_t)B * D); want(&tr->dy0, (size_t)B * D); want(&tr->dcato, (size_t)B * (A + E)); want(&tr->dha, (size_t)B * A);
     want(&tr->dP1, SB * P1); want(&tr->dP0, SB * P0);
     want(&tr->WmT, rM * D); want(&tr->WsT, D); want(&tr->Wg2T, 2 * D * 2 * D); want(&tr->Wc2T, D * 2 * D); want(&tr->Wg1T, 2 * D * 2 * D); want(&tr->Wc1T, D * 2 * D);
     want(&tr->WoT, D * (A + E)); want(&tr->WqT, A * A); want(&tr->WgaT, 2 * A * (E + A)); want(&tr->WcaT, A * (E + A)); want(&tr->WgpT, 2 * A * P1);
     want(&tr->WcpT, A * P1); want(&tr->Wp1T, P1 * P0); want(&tr->WmemT, A * E);
+    }
     const size_t o_lens = cv.take((size_t)B * 4), o_bar = cv.take((size_t)(pz::NSHARD * 32 + 64) * 4);
     hipError_t e = hipMalloc((void**)&tr->slab, cv.off);
     if (e != hipSuccess) { delete tr; return fail(T2_ENOMEM, "hipMalloc(V1 decoder trainer, %zu bytes) failed: %s", cv.off, hipGetErrorString(e)); }
@@ -992,6 +1048,20 @@ static void dt_transpose(t2v1_dtrainer* tr, const float* src, float* dst, int R,
     hipLaunchKernelGGL(transpose_kernel, dt_grid((long long)R * C), dim3(256), 0, tr->m->base.ctx->stream, dst, R, src, C, C, R);
 }
 
+#ifdef V1D_STAMPS
+extern "C" int t2v1_debug_stamps(unsigned long long* out, int reset) {     // diagnostic builds only: [2][2][16] + [8] tick sums (10 ns)
+    if (out) {
+        HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v1d_stamps), sizeof(unsigned long long) * 64));
+        HIP_TRY(hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(g_v1d_body), sizeof(unsigned long long) * 8));
+    }
+    if (reset) {
+        unsigned long long z[64] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_v1d_stamps), z, sizeof(z)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_v1d_body), z, sizeof(unsigned long long) * 8));
+    }
+    return T2_OK;
+}
+#endif
 extern "C" int t2v1_model_get_stat(t2v1_model* m, const char* name, double* out) {
     if (!m || !name || !out) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "train_persist_launches")) { *out = (double)m->n_train_persist; return T2_OK; }
@@ -1133,6 +1203,7 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
                                            float* dmemory, float* loss_out) {
     if (!tr || !done || !spec_mask || !bin_mask || !flat_grads || !dmemory || !loss_out) return fail(T2_EINVAL, "null argument");
     if (!tr->have_forward) return fail(T2_ESTATE, "t2v1_train_decoder_forward has not run");
+    if (tr->forward_only) return fail(T2_ESTATE, "internal: a forward-only decoder trainer has no backward pass");
     t2v1_model* m = tr->m;
     t2_model* b = &m->base;
     HIP_TRY(hipSetDevice(b->ctx->device));
@@ -1198,7 +1269,7 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
         a.DZC2 = tr->DZC2; a.DZG2 = tr->DZG2; a.DZC1 = tr->DZC1; a.DZG1 = tr->DZG1; a.DY0 = tr->DY0; a.DQ = tr->DQ; a.DZCa = tr->DZCa; a.DZGa = tr->DZGa;
         a.DCTX = tr->DCTX; a.dkeys = tr->dkeys; a.dvpart = tr->dvpart;
         a.cHA = tr->cHA; a.cCTX = tr->cCTX; a.cH1 = tr->cH1; a.cH2 = tr->cH2; a.keep = tr->keep; a.keep1 = tr->keep1; a.keepA = tr->keepA;
-        a.dcatr = tr->dcatr; a.dcatrA = tr->dcat; a.dy1 = tr->dy1; a.dcato = tr->dcato;
+        a.dcatr = tr->dcatr; a.dcatrA = tr->dcat; a.sink = tr->sink; a.dy1 = tr->dy1; a.dcato = tr->dcato;
         bool timed_out = false;
         T2_TRY(dt_persist_launch(tr, 1, a, &timed_out));
         looped = !timed_out;
@@ -1306,4 +1377,44 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
     HIP_TRY(hipGetLastError());
     tr->have_forward = false;
     return T2_OK;
+}
+
+// ---- teacher-forced inference decodes on the training forward ------------------------------------------------------------------
+// t2v1_decode_teacher(teacher_forcing = 1) (TrainingHelper / ValidationHelper(teacher_forcing=True), helpers.py:97-184) is the
+// training forward with drop_rate 0 (tacotron_v1.py:94-153): the engine keeps a forward-only trainer per shape and a flat copy of
+// the decoder's variables (taken at finalize), so such a decode runs as the ONE persistent launch above instead of ~10 launches per
+// step.  Shapes outside the persistent class keep the launch-per-phase schedule of v1.h (the parity twin, option "tf_persist" 0).
+static int v1_teacher_via_trainer(t2v1_model* m, const float* memory, const int64_t* lens, const float* targets, int B, int T_in, int S, float* mel, float* stop,
+                                  float* align, bool* done) {
+    *done = false;
+    if (!m->opt_tf_persist || !m->opt_tfbatch || m->tf_flat == nullptr) return T2_OK;
+    t2v1_dtrainer* tr = nullptr;
+    for (t2v1_dtrainer* c : m->tf_trainers)
+        if (c->B == B && c->T == T_in && c->S == S) { tr = c; break; }
+    if (!tr) {
+        {   // eligibility before anything is allocated (the conditions of dt_persist_ok that do not need a trainer)
+            const t2v1_dims& d = m->d;
+            const int A = d.attention_out_units, E = d.cbhg_out_units, D = d.decoder_out_units;
+            if (!(m->opt_train_persist && m->opt_skinny && B <= 48 && A % 16 == 0 && E % 16 == 0 && D % 16 == 0 && m->base.n_cu >= 64)) return T2_OK;
+            const size_t NW = V1D_ATT_THREADS / 64;
+            if (std::max({NW * (size_t)ceil_div(B, 16) * 64 * 16, (2 * (size_t)A + T_in + NW * E) * 4, ((size_t)E + T_in + 2 * NW * A) * 4}) + 256 > 64 * 1024) return T2_OK;
+        }
+        if (m->tf_trainers.size() >= 4) {                          // a few shapes at most (each holds its tape)
+            HIP_TRY(hipStreamSynchronize(m->base.ctx->stream));
+            for (t2v1_dtrainer* c : m->tf_trainers) (void)t2v1_decoder_trainer_destroy(c);
+            m->tf_trainers.clear();
+        }
+        T2_TRY(dt_create(m, B, T_in, S, true, &tr));
+        tr->ws.offsets = m->tf_offsets;
+        m->tf_trainers.push_back(tr);
+    }
+    if (!dt_persist_ok(tr)) return T2_OK;                          // e.g. held off after a timeout: the launch-per-phase schedule serves
+    T2_TRY(t2v1_train_decoder_forward(tr, m->tf_flat, memory, lens, targets, 0.0f, 0u, mel, stop, align));
+    tr->have_forward = false;
+    *done = true;
+    return T2_OK;
+}
+static void v1_tf_trainers_free(t2v1_model* m) {
+    for (t2v1_dtrainer* c : m->tf_trainers) (void)t2v1_decoder_trainer_destroy(c);
+    m->tf_trainers.clear();
 }

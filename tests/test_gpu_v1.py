@@ -111,13 +111,17 @@ def test_decoder_v1_teacher_and_validation(name, B, T, S, teacher_forcing):
     target = rng.uniform(0, 1, (B, S * d.outputs_per_step, d.num_mels)).astype(np.float32)
     mel_o, stop_o, st = V.decoder_v1(d, w, memory, is_validation=True, teacher_forcing=teacher_forcing,
                                      memory_sequence_length=lens, target=target, max_iters=S)
+    n0 = eng.get_stat("train_persist_launches")
     mel, stop, align = eng.decode_teacher(memory, lens, target, teacher_forcing=teacher_forcing)
+    # teacher-forced decodes at the reference widths run as the training forward's ONE persistent launch (csrc/v1_dec_train.h)
+    assert eng.get_stat("train_persist_launches") == n0 + (1 if teacher_forcing and name == "ref" else 0)
     np.testing.assert_allclose(_np(mel), mel_o, atol=ATOL)
     np.testing.assert_allclose(_np(stop), stop_o, atol=ATOL)
     np.testing.assert_allclose(_np(align), np.stack(st[0].alignment_history, 0), atol=ATOL)
-    if teacher_forcing:          # the per-step PreNet / projection launches (option tfbatch = 0) give the same frames
+    if teacher_forcing:          # the per-step PreNet / projection launches (option tfbatch = 0: launch-per-phase schedule) give the same frames
         eng.set_option("tfbatch", 0)
         mel2, stop2, align2 = eng.decode_teacher(memory, lens, target, teacher_forcing=True)
+        assert eng.get_stat("train_persist_launches") == n0 + (1 if name == "ref" else 0)
         eng.set_option("tfbatch", 1)
         np.testing.assert_allclose(_np(mel2), mel_o, atol=ATOL)
         np.testing.assert_allclose(_np(mel2), _np(mel), atol=1e-5)
