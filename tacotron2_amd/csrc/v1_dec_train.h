@@ -278,6 +278,194 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_attn_bwd_kernel(const flo
     __shared__ float s_red[32];
     v1d_attn_bwd_body<false>(keys, values, q, v, lens, align, dctx, dctx_row_stride, T, A, E, dq, dkeys, dvpart, blockIdx.x, sm, s_red);
 }
+// ---- the attention of a row on V1D_ATT_C workgroups (persistent launches only) ----------------------------------------------------
+// One workgroup per row is bound by its own vector pipe: T * A tanh per row and step = 3.3 us of a CU at T = 140, A = 256.  Inside
+// the persistent launches workgroup (b, c) takes a quarter of the row.  Forward, two stages: (1) scores of positions chunk c ->
+// en [b][j]; (2) every workgroup of the row normalises the whole row (redundantly) and adds up columns chunk c of the context
+// (no partial sums cross workgroups).  Backward, one stage: positions chunk c; the row-wide term of the softmax backward is taken
+// from the taped context (sum_j a_j da_j = d ctx . ctx, as in csrc/train_step.h), so the chunks need nothing from each other; their
+// partial d q go to dq4 [b][c][A] and the query layer's backward product sums them as K = C * A against C stacked copies of W_q^T.
+#define V1D_ATT_C 4
+__device__ __forceinline__ void v1d_attn_scores_body(const float* __restrict__ keys, const float* q, const float* __restrict__ v, const int* __restrict__ lens,
+                                                     int T, int A, float* en, int b, int c, float* sm) {
+    constexpr int NW = V1D_ATT_THREADS / 64, U = 3;
+    float *s_q = sm, *s_v = sm + A;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int len = lens[b], Tc = (T + V1D_ATT_C - 1) / V1D_ATT_C, j_lo = c * Tc, j_hi = min(len, j_lo + Tc);
+    if (j_lo >= j_hi) return;                                   // (uniform over the workgroup)
+    for (int u = tid; u < A; u += V1D_ATT_THREADS) { s_q[u] = v1_ld<true>(q + (size_t)b * A + u); s_v[u] = v[u]; }
+    __syncthreads();
+    for (int j0 = j_lo + wave; j0 < j_hi; j0 += NW * U) {
+        float p[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) p[i] = 0.f;
+        for (int u0 = 0; u0 < A; u0 += 256) {
+            float kk[U][4];
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) kk[i][cc] = keys[((size_t)b * T + min(j0 + i * NW, j_hi - 1)) * A + min(u0 + lane + 64 * cc, A - 1)];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int u = u0 + lane + 64 * cc;
+                const float qv = s_q[min(u, A - 1)], vv = u < A ? s_v[u] : 0.f;
+#pragma unroll
+                for (int i = 0; i < U; ++i) p[i] += vv * fast_tanhf(kk[i][cc] + qv);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) p[i] += __shfl_xor(p[i], off);
+            if (lane == 0 && j0 + i * NW < j_hi) v1_st<true>(en + (size_t)b * T + j0 + i * NW, p[i]);
+        }
+    }
+}
+__device__ __forceinline__ void v1d_attn_context_body(const float* __restrict__ values, const float* en, const int* __restrict__ lens, int T, int E,
+                                                      float* __restrict__ align, V1Dst c0, V1Dst c1, int b, int c, float* sm, float* s_red) {
+    constexpr int NW = V1D_ATT_THREADS / 64, U = V1D_ATT_U;
+    const int Ec = (E + V1D_ATT_C - 1) / V1D_ATT_C, e_lo = c * Ec, e_hi = min(E, e_lo + Ec);
+    float *s_e = sm, *s_part = sm + T;                           // s_part [NW][Ec]
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int len = lens[b];
+    float mx = -INFINITY;
+    for (int j = tid; j < len; j += V1D_ATT_THREADS) { const float e = v1_ld<true>(en + (size_t)b * T + j); s_e[j] = e; mx = fmaxf(mx, e); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = s_red[0];
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, s_red[w]);
+    float sum = 0.f;
+    for (int j = tid; j < T; j += V1D_ATT_THREADS) { const float e = j < len ? expf(s_e[j] - mx) : 0.f; s_e[j] = e; sum += e; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) s_red[NW + wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+    for (int w = 0; w < NW; ++w) sum += s_red[NW + w];
+    for (int j = tid; j < T; j += V1D_ATT_THREADS) { const float p = s_e[j] / sum; s_e[j] = p; if (c == 0) align[(size_t)b * T + j] = p; }
+    __syncthreads();
+    for (int e0 = e_lo; e0 < e_hi; e0 += 64) {                   // a lane per column of the chunk, a wave per position (mod 16)
+        const int e = min(e0 + lane, e_hi - 1);
+        float acc = 0.f;
+        for (int j0 = wave; j0 < len; j0 += NW * U) {
+            float vv[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) vv[i] = values[((size_t)b * T + min(j0 + i * NW, len - 1)) * E + e];
+#pragma unroll
+            for (int i = 0; i < U; ++i) acc = fmaf(j0 + i * NW < len ? s_e[j0 + i * NW] : 0.f, vv[i], acc);
+        }
+        if (e0 + lane < e_hi) s_part[wave * Ec + e0 - e_lo + lane] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < e_hi - e_lo; i += V1D_ATT_THREADS) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += s_part[w * Ec + i];
+        if (c0.p) v1_st<true>(c0.p + (size_t)b * c0.ld + e_lo + i, acc);
+        if (c1.p) v1_st<true>(c1.p + (size_t)b * c1.ld + e_lo + i, acc);
+    }
+}
+__device__ __forceinline__ void v1d_attn_bwd_chunk_body(const float* __restrict__ keys, const float* __restrict__ values, const float* __restrict__ q,
+                                                        const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align, const float* dctx,
+                                                        long long dctx_row_stride, const float* __restrict__ ctx, int ldctx, int T, int A, int E, float* dq4,
+                                                        float* dkeys, float* dvpart, int b, int c, float* sm, float* s_red) {
+    constexpr int NW = V1D_ATT_THREADS / 64, U = 3;
+    const int Tc = (T + V1D_ATT_C - 1) / V1D_ATT_C;
+    float *s_dc = sm, *s_de = sm + E, *s_pq = sm + E + Tc, *s_pv = s_pq + NW * A;        // partial d q / d v [NW][A]
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int len = lens[b], j_lo = c * Tc, j_hi = min(len, j_lo + Tc);
+    float s = 0.f;                                               // sum_j a_j da_j over the whole row = d ctx . ctx
+    for (int e = tid; e < E; e += V1D_ATT_THREADS) { const float dc = v1_ld<true>(dctx + (size_t)b * dctx_row_stride + e); s_dc[e] = dc; s += dc * ctx[(size_t)b * ldctx + e]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) s_red[wave] = s;
+    __syncthreads();
+    s = 0.f;
+    for (int w = 0; w < NW; ++w) s += s_red[w];
+    for (int j0 = j_lo + wave; j0 < j_hi; j0 += NW * U) {
+        float p[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) p[i] = 0.f;
+        for (int e0 = 0; e0 < E; e0 += 256) {
+            float vv[U][4];
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) vv[i][cc] = values[((size_t)b * T + min(j0 + i * NW, j_hi - 1)) * E + min(e0 + lane + 64 * cc, E - 1)];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int e = e0 + lane + 64 * cc;
+                const float dc = e < E ? s_dc[e] : 0.f;
+#pragma unroll
+                for (int i = 0; i < U; ++i) p[i] += dc * vv[i][cc];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) p[i] += __shfl_xor(p[i], off);
+            const int j = j0 + i * NW;
+            if (lane == 0 && j < j_hi) s_de[j - j_lo] = align[(size_t)b * T + j] * (p[i] - s);
+        }
+    }
+    __syncthreads();
+    for (int u0 = 0; u0 < A; u0 += 256) {
+        float aq[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f}, qu[4], vu[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { const int u = min(u0 + lane + 64 * cc, A - 1); qu[cc] = q[(size_t)b * A + u]; vu[cc] = v[u]; }
+        for (int j0 = j_lo + wave; j0 < j_hi; j0 += NW * U) {
+            float kk[U][4], dk[U][4];
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const size_t ki = ((size_t)b * T + min(j0 + i * NW, j_hi - 1)) * A + min(u0 + lane + 64 * cc, A - 1);
+                    kk[i][cc] = keys[ki]; dk[i][cc] = dkeys[ki];
+                }
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const bool live = j0 + i * NW < j_hi;
+                const float de = live ? s_de[j0 + i * NW - j_lo] : 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float th = fast_tanhf(kk[i][cc] + qu[cc]);
+                    const float gg = de * vu[cc] * (1.0f - th * th);
+                    aq[cc] += gg; av[cc] += de * th;
+                    if (live && u0 + lane + 64 * cc < A) dkeys[((size_t)b * T + j0 + i * NW) * A + u0 + lane + 64 * cc] = dk[i][cc] + gg;
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+            if (u0 + lane + 64 * cc < A) { s_pq[wave * A + u0 + lane + 64 * cc] = aq[cc]; s_pv[wave * A + u0 + lane + 64 * cc] = av[cc]; }
+    }
+    __syncthreads();
+    for (int u = tid; u < A; u += V1D_ATT_THREADS) {
+        float aq = 0.f, av = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { aq += s_pq[w * A + u]; av += s_pv[w * A + u]; }
+        v1_st<true>(dq4 + ((size_t)b * V1D_ATT_C + c) * A + u, aq);
+        dvpart[((size_t)b * V1D_ATT_C + c) * A + u] += av;      // a chunk's d keys / d v words belong to the same thread in every step
+    }
+}
+// dq [m][u] = sum_c dq4 [m][c][u] (after a persistent backward launch: the tape the query layer's weight gradient reads)
+__global__ __launch_bounds__(256) void v1d_sum_chunks_kernel(const float* __restrict__ dq4, float* __restrict__ dq, long long rows, int A) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * A; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / A; const int u = (int)(i - m * A);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < V1D_ATT_C; ++c) sum += dq4[((size_t)m * V1D_ATT_C + c) * A + u];
+        dq[i] = sum;
+    }
+}
 // GRU cell backward, stage 1: d h' = d0 (+ d1) -> d zc, d zu, and the part of d h that does not pass a GEMM (d h' u)
 __global__ __launch_bounds__(256) void v1d_bwd1_kernel(const float* __restrict__ d0, int ld0, const float* __restrict__ d1, int ld1, const float* __restrict__ cat,
                                                        const float* __restrict__ ru, const float* __restrict__ cnd, int X, int H, float* __restrict__ dzc,
@@ -503,7 +691,7 @@ __device__ __forceinline__ void sk_post(const SkEpi& e, int row, int col, float 
 // one product + epilogue by workgroup `wg` of `nwg` (16 columns each) with NWV waves; red: LDS [NWV][MB][64] float4
 template <int MB, int EPI, int NWV, bool COH, int FL = SKF_DYN>
 __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const float* __restrict__ w, int N, const SkEpi& e, int rows, int wg, int nwg,
-                                        f32x4* red) {
+                                        f32x4* red, int wmod = 0) {        // wmod: w holds wmod rows, used by every K segment of that length
     constexpr int NT_ = 64 * NWV, UK = NWV >= 16 ? 2 : 4, EL = (MB * 256 + NT_ - 1) / NT_;       // UK k-blocks in flight per wave: K <= 512 is one batch
     int tid = threadIdx.x;
     // inside the persistent loops: an opaque copy of the thread index, or every stage's step-invariant addresses are hoisted out of
@@ -542,8 +730,9 @@ __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const fl
                 if constexpr (COH) a[i][rb] = pz::ld16(xr, (unsigned)(off * 4));
                 else a[i][rb] = *reinterpret_cast<const f32x4*>(x + off);
             }
+            const int kw = wmod ? k0 % wmod : k0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bw[i][j] = w[(size_t)(k0 + j) * N + n];
+            for (int j = 0; j < 4; ++j) bw[i][j] = w[(size_t)(kw + j) * N + n];
         }
         if constexpr (COH) __builtin_amdgcn_sched_barrier(0);     // every load of the batch is in flight before the first product waits
         SKB_STAMP(0);
@@ -616,10 +805,12 @@ struct V1PFwd {
     const float *zgp, *zcp, *keys, *values;
     const int* lens;
     float *CATA, *CATAR, *RUa, *Ca, *Q, *ALIGN, *CATO, *CAT1, *CAT1R, *RU1, *C1, *CAT2, *CAT2R, *RU2, *C2, *Y2;
+    float* en;                                 // scores of the step in flight [B][T]
+    int nd;                                    // workgroups of the decoder chain (the rest: attention chain)
     unsigned* bar; int* err;
 };
 // Forward: two chains run side by side on the two halves of the grid, one stage per hop --
-//   attention chain of step i      : attention GRU gates | candidate | query layer | attention        (needs ctx, h_att of step i - 1)
+//   attention chain of step i      : attention GRU gates | candidate | query layer | scores | softmax + context   (needs ctx, h_att of step i - 1)
 //   decoder chain of step i - 1    : output projection   | GRU 1 gates | candidate | GRU 2 gates | candidate   (needs [h_att | ctx] of step i - 1)
 // so a decoder step costs five hops instead of nine.
 template <int MB>
@@ -631,7 +822,7 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_fwd_persist_kernel(V1PFwd
     if (threadIdx.x == 0) s_abort = 0;
     __syncthreads();
     const int B = a.B, T = a.T, S = a.S, A = a.A, E = a.E, D = a.D, XA = E + A;
-    const int half = gridDim.x / 2, grp = blockIdx.x >= half ? 1 : 0, lw = blockIdx.x - grp * half;
+    const int half = a.nd, grp = (int)blockIdx.x >= half ? 1 : 0, lw = blockIdx.x - grp * half;       // a.nd workgroups for the decoder chain, the rest for the attention chain
     const unsigned per = gridDim.x / pz::NSHARD;
     unsigned epoch = 0;
     f32x4* red = reinterpret_cast<f32x4*>(dsm);
@@ -692,10 +883,14 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_fwd_persist_kernel(V1PFwd
         if (!(ok = hop())) break;
         if (act) {
             if (grp) {
-                if (lw < B) v1d_attn_fwd_body<true>(a.keys, a.values, q, a.va, a.lens, T, A, E, a.ALIGN + tt * B * T, V1Dst{cato + A, A + E}, V1Dst{cata_n, XA}, lw, dsm, s_red);
+                if (lw < B * V1D_ATT_C) v1d_attn_scores_body(a.keys, q, a.va, a.lens, T, A, a.en, lw / V1D_ATT_C, lw % V1D_ATT_C, dsm);
             } else gates(FLG<SKF_BIAS>{}, cat2, cat2r, D, D, a.Wg2, a.bg2, nullptr, ru2);
         }
         if (!(ok = hop())) break;
+        if (act && grp) {
+            if (lw < B * V1D_ATT_C)
+                v1d_attn_context_body(a.values, a.en, a.lens, T, E, a.ALIGN + tt * B * T, V1Dst{cato + A, A + E}, V1Dst{cata_n, XA}, lw / V1D_ATT_C, lw % V1D_ATT_C, dsm, s_red);
+        }
         if (act && !grp) blend(FLG<SKF_BIAS | SKF_H0 | SKF_Y0>{}, cat2, cat2r, D, D, a.Wc2, a.bc2, nullptr, ru2, a.C2 + tt * B * D, V1Dst{cat2_n + D, 2 * D}, V1Dst{nullptr, 0}, V1Dst{a.Y2 + tt * B * D, D});
         if (!(ok = hop())) break;
     }
@@ -705,8 +900,9 @@ struct V1PBwd {
     int B, T, S, A, E, D;
     const float *Wc2T, *Wg2T, *Wc1T, *Wg1T, *WoT, *WqT, *WcaT, *WgaT, *va, *keys, *values;
     const int* lens;
-    const float *CATA, *RUa, *Ca, *Q, *ALIGN, *CAT1, *RU1, *C1, *CAT2, *RU2, *C2, *DY2;
-    float *DZC2, *DZG2, *DZC1, *DZG1, *DY0, *DQ, *DZCa, *DZGa, *DCTX, *dkeys, *dvpart;
+    const float *CATA, *CATO, *RUa, *Ca, *Q, *ALIGN, *CAT1, *RU1, *C1, *CAT2, *RU2, *C2, *DY2;
+    float *DZC2, *DZG2, *DZC1, *DZG1, *DY0, *DQ4, *DZCa, *DZGa, *DCTX, *dkeys, *dvpart;     // DQ4 [S][B][C][A], dvpart [B][C][A]
+    int nd;
     float *cHA, *cCTX, *cH1, *cH2, *keep, *keep1, *keepA, *dcatr, *dcatrA, *dy1, *dcato, *sink;
     unsigned* bar; int* err;
 };
@@ -722,7 +918,7 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
     if (threadIdx.x == 0) s_abort = 0;
     __syncthreads();
     const int B = a.B, T = a.T, S = a.S, A = a.A, E = a.E, D = a.D, XA = E + A;
-    const int half = gridDim.x / 2, grp = blockIdx.x >= half ? 1 : 0, lw = blockIdx.x - grp * half;
+    const int half = a.nd, grp = (int)blockIdx.x >= half ? 1 : 0, lw = blockIdx.x - grp * half;
     const unsigned per = gridDim.x / pz::NSHARD;
     unsigned epoch = 0;
     f32x4* red = reinterpret_cast<f32x4*>(dsm);
@@ -759,7 +955,7 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
         const float* cata = a.CATA + tt * B * XA;
         const float *cat1 = a.CAT1 + tt * B * 2 * D, *cat2 = a.CAT2 + tt * B * 2 * D;
         const float* dy2 = a.DY2 + tt * B * D;
-        float *dy0 = a.DY0 + tt * B * D, *dctx_t = a.DCTX + tt * E, *dq = a.DQ + tt * B * A;
+        float *dy0 = a.DY0 + tt * B * D, *dctx_t = a.DCTX + tt * E;
         // stage 0: GRU 2 stage 2 | output projection backward (+ d ctx)
         if (act) {
             if (!grp) stage2(cat2, a.RU2 + tt * B * 2 * D, D, D, a.Wc2T, a.DZC2 + tt * B * D, a.DZG2 + tt * B * 2 * D, a.keep, a.dcatr);
@@ -779,9 +975,9 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
                 s2.add = a.DY2 + u * B * D; s2.ldadd = D; s2.cat = a.CAT2 + u * B * 2 * D; s2.ru = a.RU2 + u * B * 2 * D; s2.cnd = a.C2 + u * B * D; s2.X = D; s2.H = D;
                 s2.dzc = t > 0 ? a.DZC2 + u * B * D : a.sink; s2.dzg = t > 0 ? a.DZG2 + u * B * 2 * D : a.sink; s2.keep = t > 0 ? a.keep : a.sink;
                 stage3(FLG<SKF_DRES | SKF_B1X | SKF_B1C | SKF_ADD>{}, D, D, a.Wg2T, a.DZG2 + tt * B * 2 * D, dy2, D, a.cH2, a.dy1, D, a.keep, a.dcatr, &s1, &s2);
-            } else if (lw < B) {
-                v1d_attn_bwd_body<true>(a.keys, a.values, a.Q + tt * B * A, a.va, a.lens, a.ALIGN + tt * B * T, dctx_t, (long long)S * E, T, A, E, dq, a.dkeys, a.dvpart, lw,
-                                        dsm, s_red);
+            } else if (lw < B * V1D_ATT_C) {
+                v1d_attn_bwd_chunk_body(a.keys, a.values, a.Q + tt * B * A, a.va, a.lens, a.ALIGN + tt * B * T, dctx_t, (long long)S * E, a.CATO + tt * B * (A + E) + A,
+                                        A + E, T, A, E, a.DQ4 + tt * B * V1D_ATT_C * A, a.dkeys, a.dvpart, lw / V1D_ATT_C, lw % V1D_ATT_C, dsm, s_red);
             }
         }
         if (!(ok = hop())) break;
@@ -792,7 +988,7 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
                 SkEpi e; e.res = a.dcato; e.ldr = A + E;
                 e.b1x.add = a.cHA; e.b1x.ldadd = A; e.b1x.cat = cata; e.b1x.ru = a.RUa + tt * B * 2 * A; e.b1x.cnd = a.Ca + tt * B * A; e.b1x.X = E; e.b1x.H = A;
                 e.b1x.dzc = a.DZCa + tt * B * A; e.b1x.dzg = a.DZGa + tt * B * 2 * A; e.b1x.keep = a.keepA;
-                sk_body<MB, SK_BWD1, NWV, true, SKF_RES | SKF_ADD>(dq, A, A, a.WqT, A, e, B, lw, (A + 15) / 16, red);
+                sk_body<MB, SK_BWD1, NWV, true, SKF_RES | SKF_ADD>(a.DQ4 + tt * B * V1D_ATT_C * A, V1D_ATT_C * A, V1D_ATT_C * A, a.WqT, A, e, B, lw, (A + 15) / 16, red, A);
             }
         }
         if (!(ok = hop())) break;
@@ -824,7 +1020,7 @@ struct t2v1_dtrainer {
     float *xin, *p0, *p1, *zgp, *zcp, *CATA, *CATAR, *RUa, *Ca, *Q, *ALIGN, *CATO, *CAT1, *CAT1R, *RU1, *C1, *CAT2, *CAT2R, *RU2, *C2, *Y2;
     float *zg, *zc, *mel_sb, *stop_sb, *mel_bt, *stop_bs, *loss6;
     // backward
-    float *dmel_sb, *dstop_sb, *DY2, *DZG2, *DZC2, *DZG1, *DZC1, *DY0, *DQ, *DZGa, *DZCa, *DCTX, *dkeys, *dvpart, *dvalues;
+    float *dmel_sb, *dstop_sb, *DY2, *DZG2, *DZC2, *DZG1, *DZC1, *DY0, *DQ, *DZGa, *DZCa, *DCTX, *dkeys, *dvpart, *dvalues, *DQ4, *en;
     float *cHA, *cCTX, *cH1, *cH2, *keep, *keep1, *keepA, *sink, *dcatr, *dcat, *dy1, *dy0, *dcato, *dha, *dP1, *dP0;
     float *WmT, *WsT, *Wg2T, *Wc2T, *Wg1T, *Wc1T, *WoT, *WqT, *WgaT, *WcaT, *WgpT, *WcpT, *Wp1T, *WmemT;
     // the two recurrence loops as hipGraphs (S x 15 / S x 17 launches each): every pointer in them is the trainer's own or lies in
@@ -908,12 +1104,13 @@ static int dt_create(t2v1_model* m, int B, int T_in, int S, bool forward_only, t
     want(&tr->CAT2, (SB + B) * 2 * D); want(&tr->CAT2R, SB * 2 * D); want(&tr->RU2, SB * 2 * D); want(&tr->C2, SB * D); want(&tr->Y2, SB * D);
     const size_t Hmax = std::max(A, D), Wmax = std::max(E + A, 2 * D);
     want(&tr->zg, (size_t)B * 2 * Hmax); want(&tr->zc, (size_t)B * Hmax);
+    want(&tr->en, BT);
     want(&tr->mel_sb, SB * rM); want(&tr->stop_sb, SB); want(&tr->mel_bt, SB * rM); want(&tr->stop_bs, SB); want(&tr->loss6, 8);
     tr->forward_only = forward_only;
     if (!forward_only) {
     want(&tr->dmel_sb, SB * rM); want(&tr->dstop_sb, SB); want(&tr->DY2, SB * D); want(&tr->DZG2, SB * 2 * D); want(&tr->DZC2, SB * D);
     want(&tr->DZG1, SB * 2 * D); want(&tr->DZC1, SB * D); want(&tr->DY0, SB * D); want(&tr->DQ, SB * A); want(&tr->DZGa, SB * 2 * A); want(&tr->DZCa, SB * A);
-    want(&tr->DCTX, SB * E); want(&tr->dkeys, BT * A); want(&tr->dvpart, (size_t)B * A); want(&tr->dvalues, BT * E);
+    want(&tr->DCTX, SB * E); want(&tr->dkeys, BT * A); want(&tr->dvpart, (size_t)B * V1D_ATT_C * A); want(&tr->DQ4, SB * V1D_ATT_C * A); want(&tr->dvalues, BT * E);
     want(&tr->cHA, (size_t)B * A); want(&tr->cCTX, (size_t)B * E); want(&tr->cH1, (size_t)B * D); want(&tr->cH2, (size_t)B * D);
     want(&tr->keep, (size_t)B * Hmax); want(&tr->keep1, (size_t)B * Hmax); want(&tr->keepA, (size_t)B * Hmax); want(&tr->sink, (size_t)B * 2 * Hmax); want(&tr->dcatr, (size_t)B * Wmax); want(&tr->dcat, (size_t)B * Wmax);
     want(&tr->dy1, (size_t)B * D); want(&tr->dy0, (size_t)B * D); want(&tr->dcato, (size_t)B * (A + E)); want(&tr->dha, (size_t)B * A);
@@ -954,18 +1151,21 @@ static size_t dt_persist_lds(t2v1_dtrainer* tr) {
     const size_t NW = V1D_ATT_THREADS / 64, A = d.attention_out_units, E = d.cbhg_out_units, MB = ceil_div(tr->B, 16);
     return std::max({NW * MB * 64 * 16, (2 * A + tr->T + NW * E) * 4, (E + tr->T + 2 * NW * A) * 4});
 }
+static int dt_persist_nd(t2v1_dtrainer* tr) {                 // workgroups of the decoder chain (a multiple of the counter shards)
+    const t2v1_dims& d = tr->m->d;
+    return ceil_div(ceil_div(2 * d.decoder_out_units, 16), pz::NSHARD) * pz::NSHARD;
+}
 static int dt_persist_grid(t2v1_dtrainer* tr) {
     const t2v1_dims& d = tr->m->d;
-    const int A = d.attention_out_units, E = d.cbhg_out_units, D = d.decoder_out_units;
-    const int wmax = std::max({2 * A, 2 * D, A + E, tr->B * 16});
-    return 2 * ceil_div(ceil_div(wmax, 16), pz::NSHARD) * pz::NSHARD;          // two halves, one per chain
+    const int A = d.attention_out_units, E = d.cbhg_out_units;
+    return dt_persist_nd(tr) + ceil_div(std::max({ceil_div(2 * A, 16), ceil_div(A + E, 16), tr->B * V1D_ATT_C}), pz::NSHARD) * pz::NSHARD;
 }
 static bool dt_persist_ok(t2v1_dtrainer* tr) {
     t2v1_model* m = tr->m;
     const t2v1_dims& d = m->d;
     const int A = d.attention_out_units, E = d.cbhg_out_units, D = d.decoder_out_units, B = tr->B;
     return m->opt_train_persist && m->opt_skinny && m->base.persist_holdoff == 0 && B <= 48 && A % 16 == 0 && E % 16 == 0 && D % 16 == 0 &&
-           dt_persist_lds(tr) + 256 <= 64 * 1024 && m->base.n_cu >= dt_persist_grid(tr) && m->base.n_cu >= 64;
+           dt_persist_lds(tr) + 256 <= 64 * 1024 && m->base.n_cu >= dt_persist_grid(tr);
 }
 // launches kernel `which` (0 forward, 1 backward) of the persistent pair; *timed_out: the caller re-runs the loop launch by launch
 template <typename ARGS>
@@ -1130,6 +1330,7 @@ extern "C" int t2v1_train_decoder_forward(t2v1_dtrainer* tr, const float* flat_p
         a.zgp = tr->zgp; a.zcp = tr->zcp; a.keys = tr->keys; a.values = tr->values; a.lens = tr->lens;
         a.CATA = tr->CATA; a.CATAR = tr->CATAR; a.RUa = tr->RUa; a.Ca = tr->Ca; a.Q = tr->Q; a.ALIGN = tr->ALIGN; a.CATO = tr->CATO;
         a.CAT1 = tr->CAT1; a.CAT1R = tr->CAT1R; a.RU1 = tr->RU1; a.C1 = tr->C1; a.CAT2 = tr->CAT2; a.CAT2R = tr->CAT2R; a.RU2 = tr->RU2; a.C2 = tr->C2; a.Y2 = tr->Y2;
+        a.en = tr->en; a.nd = dt_persist_nd(tr);
         bool timed_out = false;
         T2_TRY(dt_persist_launch(tr, 0, a, &timed_out));
         looped = !timed_out;          // every word of the tapes is rewritten by the launch-per-stage loop: nothing to reset
@@ -1247,7 +1448,7 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
     auto zero_carries = [&]() -> int {
         HIP_TRY(hipMemsetAsync(tr->cHA, 0, (size_t)B * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->cCTX, 0, (size_t)B * E * 4, st));
         HIP_TRY(hipMemsetAsync(tr->cH1, 0, (size_t)B * D * 4, st)); HIP_TRY(hipMemsetAsync(tr->cH2, 0, (size_t)B * D * 4, st));
-        HIP_TRY(hipMemsetAsync(tr->dkeys, 0, (size_t)B * T * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->dvpart, 0, (size_t)B * A * 4, st));
+        HIP_TRY(hipMemsetAsync(tr->dkeys, 0, (size_t)B * T * A * 4, st)); HIP_TRY(hipMemsetAsync(tr->dvpart, 0, (size_t)B * V1D_ATT_C * A * 4, st));
         return T2_OK;
     };
     T2_TRY(zero_carries());
@@ -1264,9 +1465,9 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
         a.B = B; a.T = T; a.S = S; a.A = A; a.E = E; a.D = D;
         a.Wc2T = tr->Wc2T; a.Wg2T = tr->Wg2T; a.Wc1T = tr->Wc1T; a.Wg1T = tr->Wg1T; a.WoT = tr->WoT; a.WqT = tr->WqT; a.WcaT = tr->WcaT; a.WgaT = tr->WgaT;
         a.va = va; a.keys = tr->keys; a.values = tr->values; a.lens = tr->lens;
-        a.CATA = tr->CATA; a.RUa = tr->RUa; a.Ca = tr->Ca; a.Q = tr->Q; a.ALIGN = tr->ALIGN; a.CAT1 = tr->CAT1; a.RU1 = tr->RU1; a.C1 = tr->C1;
+        a.CATA = tr->CATA; a.CATO = tr->CATO; a.RUa = tr->RUa; a.Ca = tr->Ca; a.Q = tr->Q; a.ALIGN = tr->ALIGN; a.CAT1 = tr->CAT1; a.RU1 = tr->RU1; a.C1 = tr->C1;
         a.CAT2 = tr->CAT2; a.RU2 = tr->RU2; a.C2 = tr->C2; a.DY2 = tr->DY2;
-        a.DZC2 = tr->DZC2; a.DZG2 = tr->DZG2; a.DZC1 = tr->DZC1; a.DZG1 = tr->DZG1; a.DY0 = tr->DY0; a.DQ = tr->DQ; a.DZCa = tr->DZCa; a.DZGa = tr->DZGa;
+        a.DZC2 = tr->DZC2; a.DZG2 = tr->DZG2; a.DZC1 = tr->DZC1; a.DZG1 = tr->DZG1; a.DY0 = tr->DY0; a.DQ4 = tr->DQ4; a.nd = dt_persist_nd(tr); a.DZCa = tr->DZCa; a.DZGa = tr->DZGa;
         a.DCTX = tr->DCTX; a.dkeys = tr->dkeys; a.dvpart = tr->dvpart;
         a.cHA = tr->cHA; a.cCTX = tr->cCTX; a.cH1 = tr->cH1; a.cH2 = tr->cH2; a.keep = tr->keep; a.keep1 = tr->keep1; a.keepA = tr->keepA;
         a.dcatr = tr->dcatr; a.dcatrA = tr->dcat; a.sink = tr->sink; a.dy1 = tr->dy1; a.dcato = tr->dcato;
@@ -1274,6 +1475,7 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
         T2_TRY(dt_persist_launch(tr, 1, a, &timed_out));
         looped = !timed_out;
         if (timed_out) T2_TRY(zero_carries());       // the accumulators start again; the tapes are rewritten
+        else hipLaunchKernelGGL(v1d_sum_chunks_kernel, dt_grid((long long)SB * A), dim3(256), 0, st, tr->DQ4, tr->DQ, (long long)SB, A);
     }
     if (!looped) T2_TRY(dt_run_loop(tr, 1, [&]() -> int {
     for (int t = S - 1; t >= 0; --t) {
@@ -1355,7 +1557,7 @@ extern "C" int t2v1_train_decoder_backward(t2v1_dtrainer* tr, const float* done,
     T2_TRY(bwd_wgrad(ws, tr->CAT1R, 2 * D, 2 * D, tr->DZC1, D, D, SB, gWc1, D)); T2_TRY(col_sum(ws, tr->DZC1, SB, D, gbc1));
     T2_TRY(bwd_wgrad(ws, tr->CATO, A + E, A + E, tr->DY0, D, D, SB, gWo, D)); T2_TRY(col_sum(ws, tr->DY0, SB, D, gbo));
     T2_TRY(bwd_wgrad(ws, tr->CATO, A + E, A, tr->DQ, A, A, SB, gWq, A));
-    T2_TRY(col_sum(ws, tr->dvpart, B, A, gva));
+    T2_TRY(col_sum(ws, tr->dvpart, B * V1D_ATT_C, A, gva));          // [B][C][A]: the launch-per-stage loop fills chunk-row 0 .. B - 1 only
     T2_TRY(bwd_wgrad(ws, tr->p1, P1, P1, tr->DZGa, 2 * A, 2 * A, SB, gWga, 2 * A));
     T2_TRY(bwd_wgrad(ws, tr->CATA, XA, XA, tr->DZGa, 2 * A, 2 * A, SB, gWga + (size_t)P1 * 2 * A, 2 * A)); T2_TRY(col_sum(ws, tr->DZGa, SB, 2 * A, gbga));
     T2_TRY(bwd_wgrad(ws, tr->p1, P1, P1, tr->DZCa, A, A, SB, gWca, A));
