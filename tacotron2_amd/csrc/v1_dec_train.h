@@ -375,85 +375,79 @@ __device__ __forceinline__ void v1d_attn_bwd_chunk_body(const float* __restrict_
                                                         const float* __restrict__ v, const int* __restrict__ lens, const float* __restrict__ align, const float* dctx,
                                                         long long dctx_row_stride, const float* __restrict__ ctx, int ldctx, int T, int A, int E, float* dq4,
                                                         float* dkeys, float* dvpart, int b, int c, float* sm, float* s_red) {
+    // A, E <= 256 (dt_persist_ok): a lane holds four features of a position, a wave three positions per batch.  Everything a batch
+    // reads (values, keys, d keys, alignments) depends on nothing of this step: the first batch is requested before the row-wide
+    // term s is reduced, so the stage pays one memory round trip, not three.
     constexpr int NW = V1D_ATT_THREADS / 64, U = 3;
     const int Tc = (T + V1D_ATT_C - 1) / V1D_ATT_C;
-    float *s_dc = sm, *s_de = sm + E, *s_pq = sm + E + Tc, *s_pv = s_pq + NW * A;        // partial d q / d v [NW][A]
+    float *s_dc = sm, *s_pq = sm + E, *s_pv = s_pq + NW * A;                              // partial d q / d v [NW][A]
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     const int len = lens[b], j_lo = c * Tc, j_hi = min(len, j_lo + Tc);
-    float s = 0.f;                                               // sum_j a_j da_j over the whole row = d ctx . ctx
-    for (int e = tid; e < E; e += V1D_ATT_THREADS) { const float dc = v1_ld<true>(dctx + (size_t)b * dctx_row_stride + e); s_dc[e] = dc; s += dc * ctx[(size_t)b * ldctx + e]; }
+    float dcv = 0.f, cxv = 0.f;
+    if (tid < E) { dcv = v1_ld<true>(dctx + (size_t)b * dctx_row_stride + tid); cxv = ctx[(size_t)b * ldctx + tid]; }
+    float vv[U][4], kk[U][4], dk[U][4], al[U], qu[4], vu[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) { const int u = min(lane + 64 * cc, A - 1); qu[cc] = q[(size_t)b * A + u]; vu[cc] = v[u]; }
+    auto load = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const size_t row = (size_t)b * T + min(j0 + i * NW, j_hi - 1);
+            al[i] = align[row];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                vv[i][cc] = values[row * E + min(lane + 64 * cc, E - 1)];
+                kk[i][cc] = keys[row * A + min(lane + 64 * cc, A - 1)];
+                dk[i][cc] = dkeys[row * A + min(lane + 64 * cc, A - 1)];
+            }
+        }
+    };
+    const int jw = j_lo + wave;
+    if (jw < j_hi) load(jw);
+    // s = sum_j a_j da_j over the whole row = d ctx . ctx
+    float s = dcv * cxv;
+    if (tid < E) s_dc[tid] = dcv;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) s_red[wave] = s;
     __syncthreads();
     s = 0.f;
     for (int w = 0; w < NW; ++w) s += s_red[w];
-    for (int j0 = j_lo + wave; j0 < j_hi; j0 += NW * U) {
-        float p[U];
+    float dcl[4];
 #pragma unroll
-        for (int i = 0; i < U; ++i) p[i] = 0.f;
-        for (int e0 = 0; e0 < E; e0 += 256) {
-            float vv[U][4];
-#pragma unroll
-            for (int i = 0; i < U; ++i)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) vv[i][cc] = values[((size_t)b * T + min(j0 + i * NW, j_hi - 1)) * E + min(e0 + lane + 64 * cc, E - 1)];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int e = e0 + lane + 64 * cc;
-                const float dc = e < E ? s_dc[e] : 0.f;
-#pragma unroll
-                for (int i = 0; i < U; ++i) p[i] += dc * vv[i][cc];
-            }
-        }
+    for (int cc = 0; cc < 4; ++cc) dcl[cc] = lane + 64 * cc < E ? s_dc[lane + 64 * cc] : 0.f;
+    float aq[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = jw; j0 < j_hi; j0 += NW * U) {
+        if (j0 != jw) load(j0);
 #pragma unroll
         for (int i = 0; i < U; ++i) {
+            float p = 0.f;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) p[i] += __shfl_xor(p[i], off);
-            const int j = j0 + i * NW;
-            if (lane == 0 && j < j_hi) s_de[j - j_lo] = align[(size_t)b * T + j] * (p[i] - s);
-        }
-    }
-    __syncthreads();
-    for (int u0 = 0; u0 < A; u0 += 256) {
-        float aq[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f}, qu[4], vu[4];
+            for (int cc = 0; cc < 4; ++cc) p += dcl[cc] * vv[i][cc];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) { const int u = min(u0 + lane + 64 * cc, A - 1); qu[cc] = q[(size_t)b * A + u]; vu[cc] = v[u]; }
-        for (int j0 = j_lo + wave; j0 < j_hi; j0 += NW * U) {
-            float kk[U][4], dk[U][4];
+            for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+            const bool live = j0 + i * NW < j_hi;
+            const float de = live ? al[i] * (p - s) : 0.f;
 #pragma unroll
-            for (int i = 0; i < U; ++i)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const size_t ki = ((size_t)b * T + min(j0 + i * NW, j_hi - 1)) * A + min(u0 + lane + 64 * cc, A - 1);
-                    kk[i][cc] = keys[ki]; dk[i][cc] = dkeys[ki];
-                }
-#pragma unroll
-            for (int i = 0; i < U; ++i) {
-                const bool live = j0 + i * NW < j_hi;
-                const float de = live ? s_de[j0 + i * NW - j_lo] : 0.f;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const float th = fast_tanhf(kk[i][cc] + qu[cc]);
-                    const float gg = de * vu[cc] * (1.0f - th * th);
-                    aq[cc] += gg; av[cc] += de * th;
-                    if (live && u0 + lane + 64 * cc < A) dkeys[((size_t)b * T + j0 + i * NW) * A + u0 + lane + 64 * cc] = dk[i][cc] + gg;
-                }
+            for (int cc = 0; cc < 4; ++cc) {
+                const float th = fast_tanhf(kk[i][cc] + qu[cc]);
+                const float gg = de * vu[cc] * (1.0f - th * th);
+                aq[cc] += gg; av[cc] += de * th;
+                if (live && lane + 64 * cc < A) dkeys[((size_t)b * T + j0 + i * NW) * A + lane + 64 * cc] = dk[i][cc] + gg;
             }
         }
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-            if (u0 + lane + 64 * cc < A) { s_pq[wave * A + u0 + lane + 64 * cc] = aq[cc]; s_pv[wave * A + u0 + lane + 64 * cc] = av[cc]; }
     }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+        if (lane + 64 * cc < A) { s_pq[wave * A + lane + 64 * cc] = aq[cc]; s_pv[wave * A + lane + 64 * cc] = av[cc]; }
     __syncthreads();
     for (int u = tid; u < A; u += V1D_ATT_THREADS) {
-        float aq = 0.f, av = 0.f;
+        float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { aq += s_pq[w * A + u]; av += s_pv[w * A + u]; }
-        v1_st<true>(dq4 + ((size_t)b * V1D_ATT_C + c) * A + u, aq);
-        dvpart[((size_t)b * V1D_ATT_C + c) * A + u] += av;      // a chunk's d keys / d v words belong to the same thread in every step
+        for (int w = 0; w < NW; ++w) { a1 += s_pq[w * A + u]; a2 += s_pv[w * A + u]; }
+        v1_st<true>(dq4 + ((size_t)b * V1D_ATT_C + c) * A + u, a1);
+        dvpart[((size_t)b * V1D_ATT_C + c) * A + u] += a2;      // a chunk's d keys / d v words belong to the same thread in every step
     }
 }
 // dq [m][u] = sum_c dq4 [m][c][u] (after a persistent backward launch: the tape the query layer's weight gradient reads)
@@ -689,10 +683,10 @@ __device__ __forceinline__ void sk_post(const SkEpi& e, int row, int col, float 
     }
 }
 // one product + epilogue by workgroup `wg` of `nwg` (16 columns each) with NWV waves; red: LDS [NWV][MB][64] float4
-template <int MB, int EPI, int NWV, bool COH, int FL = SKF_DYN>
+template <int MB, int EPI, int NWV, bool COH, int FL = SKF_DYN, int UKX = 0>
 __device__ __forceinline__ void sk_body(const float* x, int ldx, int K, const float* __restrict__ w, int N, const SkEpi& e, int rows, int wg, int nwg,
                                         f32x4* red, int wmod = 0) {        // wmod: w holds wmod rows, used by every K segment of that length
-    constexpr int NT_ = 64 * NWV, UK = NWV >= 16 ? 2 : 4, EL = (MB * 256 + NT_ - 1) / NT_;       // UK k-blocks in flight per wave: K <= 512 is one batch
+    constexpr int NT_ = 64 * NWV, UK = UKX ? UKX : (NWV >= 16 ? 2 : 4), EL = (MB * 256 + NT_ - 1) / NT_;       // UK k-blocks in flight per wave: K <= 512 is one batch
     int tid = threadIdx.x;
     // inside the persistent loops: an opaque copy of the thread index, or every stage's step-invariant addresses are hoisted out of
     // the step loop, stay live across all stages and push the K loop's loads into a wait-per-load schedule (persist.h, fresh())
@@ -988,7 +982,7 @@ __global__ __launch_bounds__(V1D_ATT_THREADS) void v1d_bwd_persist_kernel(V1PBwd
                 SkEpi e; e.res = a.dcato; e.ldr = A + E;
                 e.b1x.add = a.cHA; e.b1x.ldadd = A; e.b1x.cat = cata; e.b1x.ru = a.RUa + tt * B * 2 * A; e.b1x.cnd = a.Ca + tt * B * A; e.b1x.X = E; e.b1x.H = A;
                 e.b1x.dzc = a.DZCa + tt * B * A; e.b1x.dzg = a.DZGa + tt * B * 2 * A; e.b1x.keep = a.keepA;
-                sk_body<MB, SK_BWD1, NWV, true, SKF_RES | SKF_ADD>(a.DQ4 + tt * B * V1D_ATT_C * A, V1D_ATT_C * A, V1D_ATT_C * A, a.WqT, A, e, B, lw, (A + 15) / 16, red, A);
+                sk_body<MB, SK_BWD1, NWV, true, SKF_RES | SKF_ADD, 4>(a.DQ4 + tt * B * V1D_ATT_C * A, V1D_ATT_C * A, V1D_ATT_C * A, a.WqT, A, e, B, lw, (A + 15) / 16, red, A);
             }
         }
         if (!(ok = hop())) break;
@@ -1164,7 +1158,7 @@ static bool dt_persist_ok(t2v1_dtrainer* tr) {
     t2v1_model* m = tr->m;
     const t2v1_dims& d = m->d;
     const int A = d.attention_out_units, E = d.cbhg_out_units, D = d.decoder_out_units, B = tr->B;
-    return m->opt_train_persist && m->opt_skinny && m->base.persist_holdoff == 0 && B <= 48 && A % 16 == 0 && E % 16 == 0 && D % 16 == 0 &&
+    return m->opt_train_persist && m->opt_skinny && m->base.persist_holdoff == 0 && B <= 48 && A % 16 == 0 && E % 16 == 0 && D % 16 == 0 && A <= 256 && E <= 256 &&
            dt_persist_lds(tr) + 256 <= 64 * 1024 && m->base.n_cu >= dt_persist_grid(tr);
 }
 // launches kernel `which` (0 forward, 1 backward) of the persistent pair; *timed_out: the caller re-runs the loop launch by launch

@@ -37,7 +37,7 @@ out = (C.c_ulonglong * 72)()
 lib.t2v1_debug_stamps(out, 0)
 body = np.array(list(out)[64:68], dtype=np.float64) * 0.01 / (n * S)
 a = np.array(list(out)[:64], dtype=np.float64).reshape(2, 2, 16) * 0.01 / (n * S)       # us per decoder step
-names = [["decoder chain (oproj, g1, c1, g2, c2)", "attention chain (ga, ca, q, attn, -)"],
+names = [["decoder chain (oproj, g1, c1, g2, c2)", "attention chain (ga, ca, q, scores, softmax + context)"],
          ["decoder chain (2.2, 2.3, 1.2, 1.3, -)", "attention chain (oproj', attn', q'+1, a.2, a.3)"]]
 for k, kn in enumerate(("forward", "backward")):
     for g in range(2):
