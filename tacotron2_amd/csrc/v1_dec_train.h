@@ -4,14 +4,17 @@
 // two losses of models.py:58-61, and the hand-written backward pass (BPTT) of all of it.  Included by t2mi.hip after v1_train.h.
 // With t2v1_encoder_train_* this is SingleSpeakerTacotronV1Model.model_fn(mode=TRAIN) (models.py:40-76).
 //
-// Design: correctness first -- plain row-major operands, one launch per phase (8 small GEMMs + 7 elementwise / attention
-// launches per decoder step forward, 8 + 9 backward), weights read in place from the caller's flat parameter buffer.  What keeps
-// the launch count down: (1) every operand a cell multiplies is kept CONCATENATED the way TF's kernels expect it ([ctx | h],
-// [ctx | r*h], [h_att | ctx], [y | h]), written in place by the kernels that produce the pieces, so a GRU cell is two GEMMs and
-// the per-step slices double as the tape of the weight-gradient GEMMs; (2) everything that does not feed the recurrence is
-// batched over all S*B rows: PreNets and their share of the attention GRU's pre-activations before the loop, the mel / stop
-// projections after it; in the backward pass the projection gradient before the loop, every weight gradient, the PreNets,
-// d values and the memory layer after it.
+// Design: plain row-major operands, weights read in place from the caller's flat parameter buffer.
+// (1) Every operand a cell multiplies is kept CONCATENATED the way TF's kernels expect it ([ctx | h], [ctx | r*h], [h_att | ctx],
+// [y | h]), written in place by the stages that produce the pieces, so a GRU cell is two products and the per-step slices double
+// as the tape of the weight-gradient GEMMs.  (2) Everything that does not feed the recurrence is batched over all S*B rows:
+// PreNets and their share of the attention GRU's pre-activations before the loop, the mel / stop projections after it; in the
+// backward pass the projection gradient before the loop, every weight gradient, the PreNets, d values and the memory layer after
+// it.  (3) A stage of the recurrence = one skinny product with the elementwise step that consumes it in its epilogue (sk_body):
+// nine stages per decoder step forward, nine backward.  (4) At the reference widths both recurrences are ONE persistent launch
+// each (v1d_fwd_persist_kernel / v1d_bwd_persist_kernel): two independent chains of stages side by side, five hops per step, a
+// row's attention on four workgroups; other shapes run the same stages as launches inside a hipGraph (the parity twin and the
+// fallback after a hop timeout).  Teacher-forced inference decodes reuse the forward launch (v1_teacher_via_trainer).
 #pragma once
 
 #define T2_STREAM_V1_DEC_PRENET 60
