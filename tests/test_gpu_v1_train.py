@@ -565,3 +565,81 @@ def test_single_speaker_v1_model_fn_train_loop_against_oracle():
     assert res["global_step"] == 3 and np.isfinite(float(res["loss"]))
     fresh.close()
     model.close()
+
+
+# ---- data parallel: SingleSpeakerTacotronV1Model.train_step(group=...) ----
+def _v1dp_case():
+    from tests.test_gpu_v1 import DIMS
+    d = DIMS["ref"].replace(num_symbols=40, max_iters=6, min_iters=2)
+    w = init_weights_v1(d, 23, perturb=True)
+    B, T, S = 6, 10, 4
+    ids = np.random.default_rng(8).integers(0, d.num_symbols, (B, T))
+    _, lens, labels = _dec_case(d, B, T, S, 91)
+    return d, w, ids, lens, labels
+
+
+def _v1dp_rank(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tacotron2_amd.tacotron_v1 import SingleSpeakerTacotronV1Model
+        d, w, ids, lens, labels = _v1dp_case()
+        rows = slice(3 * rank, 3 * rank + 3)
+        model = SingleSpeakerTacotronV1Model(d, weights=w, seed=100)
+        res = model.train_step({"source": ids[rows], "source_length": lens[rows]}, {k: v[rows] for k, v in labels.items()},
+                               {"initial_learning_rate": 0.002, "decay_learning_rate": False}, group=dist.group.WORLD)
+        torch.cuda.synchronize()
+        q.put((rank, float(res["loss"]), _np(model.flat_grads), _np(model.flat_params), model.engine.get_stat("train_persist_launches")))
+        dist.barrier()
+        model.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_speaker_v1_training_step_two_ranks():
+    """Data parallel for the whole V1 model through the product's own path: two processes (gloo, both on this one
+    GPU; their persistent launches are 160 workgroups each, so the second one's tail waits for the first inside the bounded
+    spins) run SingleSpeakerTacotronV1Model.train_step(group=...) on three utterances each.  Masks come from the rank-folded
+    seed, each rank differentiates its numerators / the GLOBAL non-zero weight counts, gradients are summed: the summed gradient
+    equals the sum of the oracle's per-rank gradients, the loss is sum of numerators / global counts, replicas stay identical."""
+    import socket
+    import torch.multiprocessing as mp
+    from tacotron2_amd import training as TR
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_v1dp_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=150) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d, w, ids, lens, labels = _v1dp_case()
+    counts = (float((labels["spec_loss_mask"] != 0).sum() * d.num_mels), float((labels["binary_loss_mask"] != 0).sum()))
+    grads, loss = {}, 0.0
+    for r in range(2):
+        rows = slice(3 * r, 3 * r + 3)
+        seed = TR.rank_seed(100, r, 2)
+        lab = {k: v[rows] for k, v in labels.items()}
+        enc = VT.encoder_train_forward_backward(d, w, ids[rows], None, np.zeros((3, ids.shape[1], d.cbhg_out_units), np.float32), 0.5, seed)
+        dec = VT.decoder_train_forward_backward(d, w, enc["memory"], lens[rows], lab, 0.5, seed, loss_counts=counts)
+        enc = VT.encoder_train_forward_backward(d, w, ids[rows], None, dec["dmemory"], 0.5, seed)
+        loss += dec["loss"]                                                  # numerators / the global counts
+        for k, g in list(dec["grads"].items()) + list(enc["grads"].items()):
+            grads[k] = grads.get(k, 0) + g
+    names = sorted(k for k in w if not k.startswith("v1/postnet/"))
+    spec = TR.flatten_spec({k: w[k] for k in names})
+    np.testing.assert_array_equal(res[0][3], res[1][3])                      # identical replicas after the step
+    assert res[0][4] >= 2 and res[1][4] >= 2                                 # both ranks ran their recurrences as persistent launches
+    for r in res:
+        assert abs(r[1] - loss) <= 5e-4 * max(1.0, abs(loss)), (r[1], loss)
+        for name, shape, off, size in spec:
+            if name.endswith(("moving_mean", "moving_variance")):
+                continue
+            g_ref = np.asarray(grads[name], np.float32).reshape(-1)
+            scale = float(np.abs(g_ref).max())
+            assert float(np.abs(r[2][off:off + size] - g_ref).max()) <= 5e-3 * scale + 1e-9, name
