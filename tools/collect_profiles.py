@@ -28,6 +28,8 @@ def put(src, dst, comment=True):
 
 put(f"{tag}_bench_kernel_stats.txt", f"{rnd}_bench_kernel_stats.txt")
 put(f"{tag}_pmc.txt", f"{rnd}_pmc.txt")
+if os.path.exists(os.path.join(G, f"{tag}_v1train_kernel_stats.txt")):
+    put(f"{tag}_v1train_kernel_stats.txt", f"{rnd}_v1_train_kernel_stats.txt")
 line = [l for l in open(os.path.join(G, f"{tag}_bench_line_under_rocprof.json")) if l.startswith("{")][-1]
 d = json.loads(line)
 d["_captured"] = head.strip("# \n")
