@@ -364,6 +364,10 @@ int t2v1_postnet_trainer_bind(t2v1_ptrainer* tr, const char* name, int64_t offse
 /* PostNet(is_training=True)(mel) (tacotron_v1.py:180-183; the CBHG gets no lengths): mel dev [B,T,num_mels], flat_params dev,
  * spec_out dev [B,T,num_freq].  Leaves the tape of the backward pass and the batch statistics in the trainer. */
 int t2v1_postnet_train_forward(t2v1_ptrainer* tr, const float* flat_params, const float* mel, float* spec_out);
+/* CBHG.call(is_training=True) (tacotron/modules.py:205-229) as a block: the CBHG of the trainer (a PostNet trainer: v1/postnet/cbhg,
+ * an encoder trainer: v1/encoder/cbhg) with batch-statistics batch norm.  x dev [B][T][in_units], lens host [B] or NULL,
+ * out dev [B][T][out_units].  No backward pass follows this entry. */
+int t2v1_cbhg_train_forward(t2v1_ptrainer* tr, const float* flat_params, const float* x, const int64_t* lens, float* out);
 /* Gradient of spec_loss(last forward, spec_target dev [B,T,num_freq], mask dev [B,T]) into flat_grads (dev; every trainable
  * v1/postnet/ slice is written, nothing else); loss_out dev [3] = {sum, non-zero weight count, loss}.  glob_count: dev [1], the
  * count of a larger data-parallel batch, or NULL (this batch's own).  Consumes the tape: ESTATE without a forward before it. */

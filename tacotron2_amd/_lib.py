@@ -89,6 +89,7 @@ _SIGS = {
     "t2v1_postnet_trainer_destroy": (C.c_int, [_p]),
     "t2v1_postnet_trainer_bind": (C.c_int, [_p, C.c_char_p, C.c_int64]),
     "t2v1_postnet_train_forward": (C.c_int, [_p, _p, _p, _p]),
+    "t2v1_cbhg_train_forward": (C.c_int, [_p, _p, _p, _p, _p]),
     "t2v1_postnet_train_backward": (C.c_int, [_p, _p, _p, _p, _p, _p]),
     "t2v1_postnet_trainer_update_moving_stats": (C.c_int, [_p, _p, C.c_float]),
     "t2v1_postnet_trainer_export": (C.c_int, [_p, _p]),

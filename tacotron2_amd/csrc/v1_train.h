@@ -341,6 +341,24 @@ extern "C" int t2v1_postnet_train_forward(t2v1_ptrainer* tr, const float* flat_p
     return T2_OK;
 }
 
+// CBHG.call(is_training=True) (modules.py:205-229) on its own: the trainer's CBHG (the PostNet's for a PostNet trainer, the
+// encoder's for an encoder trainer) with batch statistics.  x dev [B][T][in_units]; lens host [B] or null; out dev [B][T][out_units].
+// Block-level mirror only: no backward pass follows this entry (the model-level forwards above keep their tapes).
+extern "C" int t2v1_cbhg_train_forward(t2v1_ptrainer* tr, const float* flat_params, const float* x, const int64_t* lens, float* out) {
+    if (!tr || !flat_params || !x || !out) return fail(T2_EINVAL, "null argument");
+    t2v1_model* m = tr->m;
+    HIP_TRY(hipSetDevice(m->base.ctx->device));
+    hipStream_t st = m->base.ctx->stream;
+    tr->params = flat_params;
+    tr->have_forward = false;
+    tr->have_stats = false;
+    T2_TRY(v1_lens_to_dev(m, lens, tr->B, tr->T, 0, tr->lens));
+    T2_TRY(cbhg_train_forward_impl(tr, x));
+    HIP_TRY(hipMemcpyAsync(out, tr->out, (size_t)tr->B * tr->T * 2 * tr->c->half * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
+
 // batch-norm backward of one layer: d_out = gradient of the layer's output, act_out = its output when the activation is relu
 // (the mask), null for the identity; raw = the convolution output; -> d raw (dy), dgamma / dbeta in tr->dgam[l] / dbet[l]
 static int pt_bn_backward(t2v1_ptrainer* tr, const float* d_out, const float* act_out, const float* raw, int l, int C, const float* gamma, float* dy) {

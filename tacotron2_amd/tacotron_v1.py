@@ -147,20 +147,39 @@ class EngineV1:
 
 
 class CBHG:
-    """modules.py:163-232.  ``which`` selects the encoder's (0) or the PostNet's (1) instance of the bound engine."""
+    """modules.py:163-232.  ``which`` selects the encoder's (0) or the PostNet's (1) instance of the bound engine.
+    ``is_training=True`` (batch-statistics batch norm, modules.py:153) runs the CBHG of a trainer on the flat buffer of that
+    block's variables: ``flat_params`` / ``spec`` (``training.flatten_spec`` of the embedding + v1/encoder/ variables for
+    ``which=0``, of the v1/postnet/ variables for ``which=1``)."""
 
     def __init__(self, out_units, conv_channels, max_filter_width, projection1_out_channels, projection2_out_channels,
-                 num_highway, is_training, engine: EngineV1 = None, which: int = 0, name=None, dtype=None):
+                 num_highway, is_training, engine: EngineV1 = None, which: int = 0, name=None, dtype=None,
+                 flat_params: Optional[torch.Tensor] = None, spec=None):
         assert out_units % 2 == 0                                        # modules.py:169
-        if is_training:
-            raise NotImplementedError("training-mode batch norm (batch statistics) is not built; inference arithmetic only")
+        if is_training and (flat_params is None or spec is None):
+            raise ValueError("CBHG(is_training=True) needs flat_params and spec: batch-statistics batch norm runs on the training step's buffer")
         self.out_units, self._engine, self._which = out_units, engine, which
+        self.is_training, self.flat_params, self.spec, self.trainer = bool(is_training), flat_params, spec, None
 
     def __call__(self, inputs, input_lengths=None, **kwargs):
         return self.call(inputs, input_lengths=input_lengths)
 
     def call(self, inputs, input_lengths=None, **kwargs):
-        return self._engine.cbhg(self._which, inputs, input_lengths)
+        if not self.is_training:
+            return self._engine.cbhg(self._which, inputs, input_lengths)
+        eng = self._engine
+        x = eng._f32(inputs)
+        B, T = int(x.shape[0]), int(x.shape[1])
+        if self.trainer is None or (self.trainer.B, self.trainer.T) != (B, T):
+            if self.trainer is not None:
+                self.trainer.close()
+            self.trainer = (PostNetTrainer if self._which == 1 else EncoderV1Trainer)(eng, B, T, self.spec)
+        out = eng._out(B, T, self.out_units)
+        lens = _i64(input_lengths)
+        with eng.context.ordered():
+            _lib.check(eng.lib.t2v1_cbhg_train_forward(self.trainer._h, self.trainer._flat(self.flat_params, "flat_params").data_ptr(), x.data_ptr(),
+                                                       _hp(lens), out.data_ptr()))
+        return out
 
     def compute_output_shape(self, input_shape):
         return (input_shape[0], input_shape[1], self.out_units)
@@ -214,10 +233,15 @@ class _AlignmentHistory:
 class DecoderV1:
     """tacotron_v1.py:94-153: same constructor arguments, ``call`` signature, helper selection (:134-147) and return
     triple ``(mel [B, S*r, M], stop [B, S, 1], final_state)`` with ``final_state[0].alignment_history.stack()``
-    -> [S, B, T_in] (models.py:53)."""
+    -> [S, B, T_in] (models.py:53).  ``is_training=True`` with ``drop_rate > 0`` (PreNet dropout, ``modules.py:90``) runs the
+    training forward of ``DecoderV1Trainer`` on the flat buffer of the decoder's variables: ``flat_params`` / ``spec``
+    (``training.flatten_spec(DecoderV1Trainer.decoder_weights(w))``); ``seed`` advances per call; ``self.trainer`` then holds the
+    tape for ``DecoderV1Trainer.backward``."""
 
     def __init__(self, prenet_out_units=(256, 128), drop_rate=0.5, attention_out_units=256, decoder_out_units=256, num_mels=80,
-                 outputs_per_step=2, max_iters=200, n_feed_frame=1, min_iters=10, engine: EngineV1 = None, name=None, dtype=None):
+                 outputs_per_step=2, max_iters=200, n_feed_frame=1, min_iters=10, engine: EngineV1 = None, name=None, dtype=None,
+                 flat_params: Optional[torch.Tensor] = None, spec=None, seed: int = 0):
+        self.flat_params, self.spec, self.seed, self.trainer = flat_params, spec, int(seed), None
         if decoder_out_units < 1:
             raise ValueError("Parameter output_size must be > 0: %d." % decoder_out_units)      # rnn_wrappers.py:155-156
         self._prenet_out_units = tuple(prenet_out_units)
@@ -233,13 +257,25 @@ class DecoderV1:
     def call(self, source, is_training=None, is_validation=None, teacher_forcing=False, memory_sequence_length=None, target=None):
         assert is_training is not None                                   # tacotron_v1.py:120
         assert self.n_feed_frame <= self.outputs_per_step                # helpers.py:55,100,144
-        if is_training and self._drop_rate > 0:
-            raise NotImplementedError("dropout sampling (training mode) is not built; use drop_rate=0 or is_training=False")
         eng, r = self._engine, self.outputs_per_step
         d = eng.dims
         if (self._prenet_out_units, self.attention_out_units, self.decoder_out_units, self.num_mels, r, self.n_feed_frame) != \
                 (tuple(d.decoder_prenet_out_units), d.attention_out_units, d.decoder_out_units, d.num_mels, d.outputs_per_step, d.n_feed_frame):
             raise ValueError("DecoderV1 arguments do not match the bound engine's dimensions")
+        if is_training and self._drop_rate > 0:
+            if self.flat_params is None or self.spec is None:
+                raise ValueError("DecoderV1(is_training=True, drop_rate > 0) needs flat_params and spec (training.flatten_spec of "
+                                 "DecoderV1Trainer.decoder_weights): PreNet dropout runs on the training step's buffer")
+            B, T_in = int(source.shape[0]), int(source.shape[1])
+            S = min(int(target.shape[1]) // r, self.max_iters)           # maximum_iterations (:150)
+            if self.trainer is None or (self.trainer.B, self.trainer.T_in, self.trainer.S) != (B, T_in, S):
+                if self.trainer is not None:
+                    self.trainer.close()
+                self.trainer = DecoderV1Trainer(eng, B, T_in, S, self.spec)
+            mel, stop, align = self.trainer.forward(self.flat_params, source, memory_sequence_length, eng._f32(target)[:, :S * r].contiguous(),
+                                                    drop_rate=self._drop_rate, seed=self.seed)
+            self.seed += 1
+            return mel, stop, (SimpleNamespace(alignment_history=_AlignmentHistory(align)), None, None)
         if is_training or is_validation:
             tf_on = bool(is_training or teacher_forcing)                 # TrainingHelper always feeds targets (helpers.py:182)
             mel, stop, align = eng.decode_teacher(source, memory_sequence_length, target, teacher_forcing=tf_on)

@@ -643,3 +643,79 @@ def test_single_speaker_v1_training_step_two_ranks():
             g_ref = np.asarray(grads[name], np.float32).reshape(-1)
             scale = float(np.abs(g_ref).max())
             assert float(np.abs(r[2][off:off + size] - g_ref).max()) <= 5e-3 * scale + 1e-9, name
+
+
+# ---- block-level mirrors in training mode: DecoderV1(is_training=True, drop_rate > 0), CBHG(is_training=True) ----
+def test_decoder_v1_block_in_training_mode_with_dropout():
+    """DecoderV1.call(is_training=True) with drop_rate 0.5 (tacotron_v1.py:94-153, modules.py:90): the block runs the training
+    forward on the flat buffer it is given; frames, stop logits and alignments against the oracle with the same masks; the
+    seed advances per call; the trainer it holds accepts the backward pass."""
+    import torch
+    from tests.test_gpu_v1 import DIMS
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import DecoderV1, DecoderV1Trainer, EngineV1
+    d = DIMS["ref"]
+    B, T, S = 6, 17, 5
+    w = init_weights_v1(d, 9, perturb=True)
+    eng = EngineV1(d, w)
+    dw = DecoderV1Trainer.decoder_weights(w)
+    spec = TR.flatten_spec(dw)
+    flat = torch.tensor(TR.flatten(dw, spec), device="cuda")
+    mem, lens, labels = _dec_case(d, B, T, S, 5)
+    kw = dict(prenet_out_units=d.decoder_prenet_out_units, attention_out_units=d.attention_out_units, decoder_out_units=d.decoder_out_units,
+              num_mels=d.num_mels, outputs_per_step=d.outputs_per_step, max_iters=d.max_iters, n_feed_frame=d.n_feed_frame, engine=eng)
+    with pytest.raises(ValueError):
+        DecoderV1(drop_rate=0.5, **kw)(mem, is_training=True, memory_sequence_length=lens, target=labels["mel"])
+    dec = DecoderV1(drop_rate=0.5, flat_params=flat, spec=spec, seed=31, **kw)
+    for call in range(2):
+        ref = VT.decoder_train_forward_backward(d, w, mem, lens, labels, 0.5, 31 + call)
+        mel, stop, state = dec(mem, is_training=True, memory_sequence_length=lens, target=labels["mel"])
+        np.testing.assert_allclose(_np(mel), ref["mel"], atol=ATOL)
+        np.testing.assert_allclose(_np(stop)[..., 0], ref["stop"], atol=ATOL)
+        np.testing.assert_allclose(_np(state[0].alignment_history.stack()), ref["alignments"], atol=ATOL)
+    grads = torch.zeros_like(flat)
+    dmem, losses = dec.trainer.backward(labels["done"], labels["spec_loss_mask"], labels["binary_loss_mask"], grads)
+    assert abs(float(losses[2]) - ref["loss"]) <= 2e-4 * max(1.0, ref["loss"])
+    scale = float(np.abs(ref["dmemory"]).max())
+    assert float(np.abs(_np(dmem) - ref["dmemory"]).max()) <= 2e-3 * scale + 1e-9
+    dec.trainer.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_cbhg_block_in_training_mode(which):
+    """CBHG.call(is_training=True) (modules.py:205-229, batch statistics) as a block, the encoder's instance with lengths and the
+    PostNet's without, against the fp64 oracle."""
+    import torch
+    from oracle.v1_torch_train import _t, cbhg_train
+    from tacotron2_amd import training as TR
+    from tacotron2_amd.tacotron_v1 import CBHG, EncoderV1Trainer, EngineV1, PostNetTrainer
+    d = ENC if which == 0 else POST
+    w = init_weights_v1(d, 21, perturb=True)
+    eng = EngineV1(d, w)
+    rng = np.random.default_rng(3 + which)
+    B, T = 5, 19
+    if which == 0:
+        tw = {k: v for k, v in w.items() if k == "embedding" or k.startswith("v1/encoder/")}
+        cin, out_units, pfx, K, nh = d.encoder_prenet_out_units[1], d.cbhg_out_units, "v1/encoder/cbhg", d.max_filter_width, d.num_highway
+        lens = rng.integers(T // 2, T + 1, B).astype(np.int64); lens[0] = T
+    else:
+        tw = PostNetTrainer.postnet_weights(w)
+        cin, out_units, pfx, K, nh = d.num_mels, d.post_net_cbhg_out_units, "v1/postnet/cbhg", d.post_net_max_filter_width, d.post_net_num_highway
+        lens = None
+    spec = TR.flatten_spec(tw)
+    flat = torch.tensor(TR.flatten(tw, spec), device="cuda")
+    x = (rng.standard_normal((B, T, cin)) * 0.5).astype(np.float32)
+    with pytest.raises(ValueError):
+        CBHG(out_units, 0, 0, 0, 0, 0, is_training=True, engine=eng, which=which)
+    blk = CBHG(out_units, 0, 0, 0, 0, 0, is_training=True, engine=eng, which=which, flat_params=flat, spec=spec)
+    got = _np(blk(x, input_lengths=lens))
+    W = {k: _t(v) for k, v in tw.items()}
+    ref = cbhg_train(W, pfx, _t(x), K, nh, d.bn_eps, {}, False, lens).numpy()
+    assert got.shape == ref.shape == (B, T, out_units)
+    np.testing.assert_allclose(got, ref, atol=ATOL)
+    # the inference-mode block (moving statistics) gives something else: the switch is live
+    inf = _np(CBHG(out_units, 0, 0, 0, 0, 0, is_training=False, engine=eng, which=which)(x, input_lengths=lens))
+    assert float(np.abs(inf - got).max()) > 1e-3
+    blk.trainer.close()
+    eng.close()
