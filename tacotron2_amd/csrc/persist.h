@@ -88,6 +88,7 @@ struct PExtra {
     const float* x2_all;                        // last PreNet layer's outputs of every step, frag16 per step
     unsigned x2_bytes, x2_stride;               // size of x2_all, bytes per step
     float* y_all;                               // LSTM 2's raw outputs [S][rows][1024] for the deferred projection (null: the tape has them)
+    unsigned oB1[4];                            // two-chain schedule (MODE 3 / 4): second bank of the h_att raw, h_att, h1, h2 slots (odd steps)
     PTape tp;
 };
 
@@ -251,7 +252,7 @@ __device__ unsigned long long g_pz_stamps[NWG][24];
 // of the other modes' code (a runtime switch cost it 2.4 us per step at B = 1).
 template <int MB, int MODE>
 __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
-    constexpr bool TEACH = MODE >= 1, TAPE = MODE == 2;
+    constexpr bool TEACH = MODE >= 1, TAPE = MODE == 2 || MODE == 4, TWO = MODE >= 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Thread coordinates are re-derived from an opaque copy of the thread index at the start of every phase (fresh()):
     // otherwise hipcc hoists every step-invariant address computation of every phase out of the step loop and spills them.
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
     __syncthreads();
 
     int t = 0;                 // decoder step
+    int tc = 0;                // the step a cell call belongs to (tape rows, mask counters): t, or the chain's own step (TWO)
     // gate sums of this thread's (row, unit) from the waves' partial tiles; D layout: col = lane & 15, row = 4 (lane >> 4) + reg
     auto gate4 = [&](float (&z)[4]) {
         const int rb = erow >> 4, rr = erow & 15;
@@ -372,9 +374,9 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
             const int unit = wg * 4 + euu, H = NWG * 4;
             const unsigned stream = (unsigned)(T2_STREAM_ZONE_ATT + 2 * layer);
             const float cp = c, hp = h;
-            c = (1.0f - a.zc) * dropout_train(cn - cp, a.zc, t2_u01(x.tp.seed, stream, (unsigned)t, (unsigned)erow, (unsigned)unit)) + cp;
-            h = (1.0f - a.zh) * dropout_train(hn - hp, a.zh, t2_u01(x.tp.seed, stream + 1u, (unsigned)t, (unsigned)erow, (unsigned)unit)) + hp;
-            const size_t ti = (size_t)t * B + erow;
+            c = (1.0f - a.zc) * dropout_train(cn - cp, a.zc, t2_u01(x.tp.seed, stream, (unsigned)tc, (unsigned)erow, (unsigned)unit)) + cp;
+            h = (1.0f - a.zh) * dropout_train(hn - hp, a.zh, t2_u01(x.tp.seed, stream + 1u, (unsigned)tc, (unsigned)erow, (unsigned)unit)) + hp;
+            const size_t ti = (size_t)tc * B + erow;
             float* tz = x.tp.z[layer] + ti * 4 * H;
             tz[unit] = zi; tz[H + unit] = zj; tz[2 * H + unit] = zf; tz[3 * H + unit] = zo;
             x.tp.cprev[layer][ti * H + unit] = cp; x.tp.cnew[layer][ti * H + unit] = cn;
@@ -469,10 +471,280 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[r][g] = 0.f;
-    if (TEACH && isAtt) attention_pre(0);
+    if (TEACH && !TWO && isAtt) attention_pre(0);
 
+    // ============================================================================================================================
+    // Teacher-forced modes, two-chain schedule (MODE 3 / 4).  With known inputs the attention chain of step i (attention LSTM ->
+    // query -> attention) needs only ctx and h_att of step i - 1, and the decoder chain of step i - 1 (LSTM 1 -> LSTM 2) only
+    // h_att, ctx of its own step: the two run side by side and a decoder step costs TWO hops instead of four --
+    //   X(i): attention LSTM (i)  +  LSTM 1 (i - 1)      critical: ctx(i - 1) against both kernels' context rows
+    //   Y(i): query + attention (i)  +  LSTM 2 (i - 1)   critical: y1(i - 1) . W2[0:1024]
+    // gap of X's hop: h2(i - 2) . W2[h rows], the query-independent part of attention (i); gap of Y's hop: everything of X(i + 1)
+    // that is known (x2, h_att, h_att raw, h1 products).  Slots whose readers sit in the gap right before their next write
+    // (h_att raw, h_att, h1, h2) are double-banked by step parity (x.oB1).
+    // ============================================================================================================================
+    if constexpr (TWO) {
+        const int S = a.max_steps;
+        float hnA_last = 0.f;
+        {   // accA = x2(0) . W_A[x rows]
+            f32x4 bx[2];
+            wload<2>(bx, rA, slabA + (unsigned)(wave * 2 * 1024), l16);
+            seg_mma<MB, 2>(accA, bx, rX2, (unsigned)(wave * 2 * MB * 1024), l16);
+        }
+        f32x4 bcA[4], bc1[4];
+        wload<4>(bcA, rA, slabA + (unsigned)((KBX + wave * 4) * 1024), l16);
+        wload<4>(bc1, r1, slab1 + (unsigned)((KBH + wave * 4) * 1024), l16);
+        for (int i = 0; i <= S; ++i) {
+            fresh();
+            const int ta = i, td = i - 1;
+            const bool actA = ta < S, actB = td >= 0;
+            const unsigned oHAr_a = (ta & 1) ? x.oB1[0] : a.oHAr, oHA_a = (ta & 1) ? x.oB1[1] : a.oHA;
+            const unsigned oH1_d = (td & 1) ? x.oB1[2] : a.oH1, oH2_d = (td & 1) ? x.oB1[3] : a.oH2;       // (td = -1: unused)
+            // ================= X(i): attention LSTM of step ta, LSTM 1 of step td =================
+            if (actA) {
+                if (i > 0) seg_mma<MB, 4>(accA, bcA, xs, a.oCTX + (unsigned)(wave * 4 * MB * 1024), l16);
+                put_red(accA);
+                __syncthreads();
+                if (tid < MB * 64) {
+                    float z[4];
+                    gate4(z);
+                    tc = ta;
+                    const float hn = cell(z, s_bias, cA, hA, 0);
+                    hnA_last = hn;
+                    publish4(hn, oHAr_a);
+                    publish4(hA, oHA_a);
+                }
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) accA[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (actB) {
+                seg_mma<MB, 4>(acc1, bc1, xs, a.oCTX + (unsigned)(wave * 4 * MB * 1024), l16);
+                if (actA) __syncthreads();                     // the attention LSTM's partial tiles have been read
+                put_red(acc1);
+                __syncthreads();
+                if (tid < MB * 64) {
+                    float z[4];
+                    gate4(z);
+                    tc = td;
+                    const float hn = cell(z, s_bias + 16, c1, h1, 1);
+                    publish4(hn, a.oY1);
+                    publish4(h1, oH1_d);
+                }
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) acc1[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            hop_arrive(a.bar); ++epoch; fresh();
+            // gap: LSTM 2's recurrent K range (h2 of step td - 1), the query-independent part of attention (ta)
+            if (td > 0) {
+                const unsigned oH2_p = ((td - 1) & 1) ? x.oB1[3] : a.oH2;
+                f32x4 b[8];
+                wload<8>(b, r2, slab2 + (unsigned)((KBH + wave * 8) * 1024), l16);
+                seg_mma<MB, 8>(acc2, b, xs, oH2_p + (unsigned)(wave * 8 * MB * 1024), l16);
+            }
+            if (isAtt && actA) { attention_pre(ta); fresh(); }
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (isQ) bq = ldw(rQ, l16, (unsigned)((qct * KBH + qks * 8 + wave) * 1024));
+            f32x4 by[8];
+            wload<8>(by, r2, slab2 + (unsigned)(wave * 8 * 1024), l16);
+            if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+            fresh();
+            // ================= Y(i): query + attention of step ta, LSTM 2 of step td =================
+            if (isQ && actA) {
+                const f32x4 av = ldx(xs, l16, oHAr_a + (unsigned)(((qks * 8 + wave) * MB + qrb) * 1024));
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[j], acc, 0, 0, 0);
+                red[wave * 64 + lane] = acc;
+                __syncthreads();
+                // partial tile -> tagged 8-byte granules {value, tag = step + 1}: the data is the flag (no drain, no counter)
+                if (tid < 256) {
+                    const int r16 = tid >> 4, c = tid & 15;
+                    const int sl = (r16 >> 2) * 16 + c, reg = r16 & 3;
+                    float sacc = 0.f;
+    #pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) sacc += red[w * 64 + sl][reg];
+                    const int row = qrb * 16 + r16;
+                    if (row < B)
+                        __hip_atomic_store(qgr + ((size_t)(qks * MB * 16 + row) * UA + qct * 16 + c),
+                                           ((unsigned long long)(unsigned)(ta + 1) << 32) | __builtin_bit_cast(unsigned, sacc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+
+            if (actB) {
+                seg_mma<MB, 8>(acc2, by, xs, a.oY1 + (unsigned)(wave * 8 * MB * 1024), l16);
+                if (isQ && actA) __syncthreads();              // the query tile's partial tiles have been read
+                put_red(acc2);
+                __syncthreads();
+                if (tid < MB * 64) {
+                    float z[4];
+                    gate4(z);
+                    tc = td;
+                    const float hn = cell(z, s_bias + 32, c2, h2, 2);
+                    publish4(hn, a.oY2);
+                    publish4(h2, oH2_d);
+                    if (x.y_all != nullptr && eown) x.y_all[((size_t)td * B + erow) * (NWG * 4) + wg * 4 + euu] = hn;
+                }
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) acc2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (isAtt && actA) {
+                const int p0 = att_p0, n = att_n, pl = att_pl;
+                const int NRT = (n + 15) >> 4;
+                // (a) processed query of this row: bias + the 8 K-split partials of its row block's query tiles (granule sweep by
+                //     the two waves that own the 128 units)
+                if (tid < UA) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    unsigned long long g[KSQ];
+                    for (;;) {
+                        bool ok = true;
+    #pragma unroll
+                        for (int k = 0; k < KSQ; ++k) {
+                            g[k] = __hip_atomic_load(qgr + ((size_t)(k * MB * 16 + ab) * UA + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok &= (unsigned)(g[k] >> 32) == (unsigned)(ta + 1);
+                        }
+                        if (__all(ok)) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { s_flag[0] = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    float q = a.b_a[tid];
+    #pragma unroll
+                    for (int k = 0; k < KSQ; ++k) q += __builtin_bit_cast(float, (unsigned)g[k]);
+                    s_q[tid] = q;
+                    if (TAPE && ac == 0) x.tp.q[((size_t)ta * B + ab) * UA + tid] = q;
+                }
+                __syncthreads();
+                if (s_flag[0]) { alive = false; break; }
+                // (b) energies e[p] = sum_u v[u] tanh(keys + q + processed location)[p][u]   (:66-78, :133)
+                const float q_l = s_q[wave * 16 + c16];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r < NRT) {
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float e = va_l * fast_tanhf(pre[r][g] + q_l);
+                            e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4); e += __shfl_xor(e, 8);
+                            if (c16 == 0) s_ep[wave * CHP + 16 * r + 4 * kg + g] = e;
+                        }
+                    }
+                }
+                __syncthreads();
+                // (c) group exchange of the energies as tagged 8-byte granules {value, tag = step + 1} (the data is the flag:
+                //     one aligned 8-byte sc1 store per position; readers re-read until every tag matches)
+                unsigned long long* eng = reinterpret_cast<unsigned long long*>(a.xs + a.oEN / 4) + (size_t)ab * T;
+                if (tid < n) {
+                    float e = 0.f;
+    #pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) e += s_ep[w * CHP + tid];
+                    __hip_atomic_store(eng + p0 + tid, ((unsigned long long)(unsigned)(ta + 1) << 32) | __builtin_bit_cast(unsigned, e), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // values of the context slice: in flight during the exchange, consumed after the softmax
+                const int ES = EW / C, nc4 = ES >> 2, NPG = NT / nc4;
+                const int c4 = tid % nc4, pg = tid / nc4;
+                const f32x4* vp = reinterpret_cast<const f32x4*>(a.values + (size_t)ab * T * EW + ac * ES) + c4;
+                constexpr int VN = 10;
+                f32x4 vv[VN];
+    #pragma unroll
+                for (int i = 0; i < VN; ++i) vv[i] = vp[(size_t)min(pg + i * NPG, len_b - 1) * (EW / 4)];
+                // (d) every wave sweeps all T granules and computes the masked softmax redundantly (score mask -inf -> probability
+                //     exactly 0; App. A5): no workgroup barrier between the exchange and the alignments
+                {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    bool bad = false;
+                    float m = -INFINITY;
+                    for (int i0 = 0; i0 < T; i0 += 64) {
+                        const int i = i0 + lane;
+                        float e = -INFINITY;
+                        for (;;) {
+                            unsigned long long g = (unsigned long long)(unsigned)(ta + 1) << 32;
+                            if (i < T) g = __hip_atomic_load(eng + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (__all((unsigned)(g >> 32) == (unsigned)(ta + 1))) { if (i < len_b) e = __builtin_bit_cast(float, (unsigned)g); break; }
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { bad = true; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (bad) break;
+                        if (i < T) s_e[wave * TP + i] = e;
+                        m = fmaxf(m, e);
+                    }
+                    if (bad) s_flag[0] = 1;
+    #pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+                    float sum = 0.f;
+                    for (int i = lane; i < T; i += 64) {
+                        const float ex = (i < len_b) ? expf(s_e[wave * TP + i] - m) : 0.f;
+                        s_e[wave * TP + i] = ex;
+                        sum += ex;
+                    }
+    #pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                    // wave w publishes the probabilities of positions i with (i >> 6) % 8 == w ... every wave holds all of them; each
+                    // writes the same values, so one copy per position is enough: wave (i / 64) % 8 writes block i / 64
+                    for (int i0 = 0; i0 < T; i0 += 64)
+                        if (((i0 >> 6) & (NWAVE - 1)) == wave && i0 + lane < T) s_a[i0 + lane] = s_e[wave * TP + i0 + lane] / sum;
+                }
+                __syncthreads();
+                if (s_flag[0]) { alive = false; break; }
+                // (e) this chunk's alignments: history row and the next attention state (:137-140)
+                if (tid < n) {
+                    const float p = s_a[p0 + tid];
+                    a.hist[((size_t)ta * B + ab) * T + p0 + tid] = p;
+                    if constexpr (TAPE) x.tp.state_prev[((size_t)ta * B + ab) * T + p0 + tid] = s_cum[tid + pl];
+                    st4(xs, a.oCUM + (unsigned)((ta & 1) * B * T * 4) + (unsigned)((ab * T + p0 + tid) * 4), a.cumulative ? p + s_cum[tid + pl] : p);
+                }
+                // (f) context slice = alignments . values[:, slice]   (AttentionWrapper._compute_attention)
+                {
+                    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                    for (int i = 0; i < VN; ++i) {
+                        const int p = pg + i * NPG;
+                        acc4 += (p < len_b ? s_a[p] : 0.f) * vv[i];
+                    }
+                    for (int p = pg + VN * NPG; p < len_b; p += NPG) acc4 += s_a[p] * vp[(size_t)p * (EW / 4)];
+                    *reinterpret_cast<f32x4*>(s_cx + pg * ES + c4 * 4) = acc4;
+                }
+                __syncthreads();
+                if (tid < nc4) {
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                    for (int g = 0; g < NPG; ++g) s += *reinterpret_cast<const f32x4*>(s_cx + g * ES + tid * 4);
+                    st16(xs, a.oCTX + frag_off16(ab, (ac * ES >> 2) + tid, MB), s);
+                    if constexpr (TAPE) *reinterpret_cast<f32x4*>(x.tp.ctx + ((size_t)ta * B + ab) * EW + ac * ES + tid * 4) = s;
+                }
+            }
+            hop_arrive(a.bar); ++epoch; fresh();
+            // gap: everything of X(i + 1) that is known
+            if (ta + 1 < S) {
+                f32x4 bx[2];
+                wload<2>(bx, rA, slabA + (unsigned)(wave * 2 * 1024), l16);
+                seg_mma<MB, 2>(accA, bx, rX2, (unsigned)(ta + 1) * x.x2_stride + (unsigned)(wave * 2 * MB * 1024), l16);
+                f32x4 b[8];
+                wload<8>(b, rA, slabA + (unsigned)((KBX + KBE + wave * 8) * 1024), l16);
+                seg_mma<MB, 8>(accA, b, xs, oHA_a + (unsigned)(wave * 8 * MB * 1024), l16);
+            }
+            if (actA) {
+                {
+                    f32x4 b[8];
+                    wload<8>(b, r1, slab1 + (unsigned)(wave * 8 * 1024), l16);
+                    seg_mma<MB, 8>(acc1, b, xs, oHAr_a + (unsigned)(wave * 8 * MB * 1024), l16);
+                }
+                if (ta >= 1) {
+                    const unsigned oH1_p = ((ta - 1) & 1) ? x.oB1[2] : a.oH1;
+                    f32x4 b[8];
+                    wload<8>(b, r1, slab1 + (unsigned)((KBH + KBE + wave * 8) * 1024), l16);
+                    seg_mma<MB, 8>(acc1, b, xs, oH1_p + (unsigned)(wave * 8 * MB * 1024), l16);
+                }
+            }
+            wload<4>(bcA, rA, slabA + (unsigned)((KBX + wave * 4) * 1024), l16);
+            wload<4>(bc1, r1, slab1 + (unsigned)((KBH + wave * 4) * 1024), l16);
+            if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+        }
+        // final_state reads bank 0: the last step's values once more (they live in registers)
+        fresh();
+        if (alive && tid < MB * 64) { publish4(hnA_last, a.oHAr); publish4(hA, a.oHA); publish4(h1, a.oH1); publish4(h2, a.oH2); }
+    }
+    if constexpr (!TWO)
     for (; t < a.max_steps; ++t) {
         fresh();
+        tc = t;
         float stop_v = 1.0f;
         if constexpr (!TEACH) {
         // gap work of the P5 -> P6 chain: the query-independent part of this step's attention.  The owners of a last-PreNet

@@ -146,6 +146,7 @@ struct t2_model {
     // part of the GPU) is re-run with the launch-per-phase schedule; the next persist_holdoff decodes skip the persistent kernels
     long long n_persist_timeouts = 0;   // stat "persist_timeouts"
     int persist_holdoff = 0;
+    int opt_tf2 = 1;                    // teacher-forced persistent decodes: two-chain schedule (two hops per step; persist.h MODE 3 / 4)
     int opt_inject_timeout = 0;         // tests: the next N persistent launches get their error word set after the launch
     // arguments of the free-running decode in flight (t2_decode_free_launch -> t2_decode_free_finish may have to re-run it)
     int pend_max_iters = 0, pend_min_iters = 0;
@@ -179,7 +180,7 @@ struct t2_state {
     int* ctl = nullptr;
     // persistent decoder (persist.h): exchange slab and hop counters, carved from the zeroable slab; null when not eligible
     float* pz_xs = nullptr; unsigned pz_bytes = 0; unsigned* pz_bar = nullptr;
-    unsigned pz_off[13] = {0};
+    unsigned pz_off[17] = {0};
     // output staging (graph-stable addresses)
     float *o_mel = nullptr, *o_stop = nullptr, *o_hist = nullptr, *i_targets = nullptr;
     float *tf_buf = nullptr, *tf_xin = nullptr, *tf_x[2] = {nullptr, nullptr}, *tf_frag = nullptr;   // batched teacher-forced PreNets (lazy)
@@ -491,6 +492,7 @@ extern "C" int t2_model_set_option(t2_model* m, const char* name, int value) {
         for (t2_state* s : m->states) for (int i = 0; i < 2; ++i) if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
     }
     else if (!strcmp(name, "persist")) { m->opt_persist = value; m->persist_holdoff = 0; }
+    else if (!strcmp(name, "tf2")) m->opt_tf2 = value;
     else if (!strcmp(name, "inject_timeout")) m->opt_inject_timeout = value;
     else if (!strcmp(name, "bwd_splitk")) m->opt_bwd_splitk = value;
     else if (!strcmp(name, "bwd_persist")) m->opt_bwd_persist = value;
@@ -670,7 +672,9 @@ extern "C" int t2_model_finalize(t2_model* m) {
     {
         const void* pk[] = {(const void*)pz::decode_kernel<1, 0>, (const void*)pz::decode_kernel<2, 0>, (const void*)pz::decode_kernel<4, 0>,
                             (const void*)pz::decode_kernel<1, 1>, (const void*)pz::decode_kernel<2, 1>, (const void*)pz::decode_kernel<4, 1>,
-                            (const void*)pz::decode_kernel<1, 2>, (const void*)pz::decode_kernel<2, 2>, (const void*)pz::decode_kernel<4, 2>};
+                            (const void*)pz::decode_kernel<1, 2>, (const void*)pz::decode_kernel<2, 2>, (const void*)pz::decode_kernel<4, 2>,
+                            (const void*)pz::decode_kernel<1, 3>, (const void*)pz::decode_kernel<2, 3>, (const void*)pz::decode_kernel<4, 3>,
+                            (const void*)pz::decode_kernel<1, 4>, (const void*)pz::decode_kernel<2, 4>, (const void*)pz::decode_kernel<4, 4>};
         for (const void* f : pk) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     }
     // the host copies stay: a trainer packs the transposed operands of the backward pass from them
@@ -1238,6 +1242,7 @@ static int state_alloc(t2_model* m, int B, int T, int cap, bool with_targets, t2
         s->pz_off[10] = pcarve((size_t)B * T * 8);                                // energies as tagged 8-byte granules
         s->pz_off[11] = pcarve(2 * (size_t)B * T * 4);                            // attention state, two step parities
         s->pz_off[12] = pcarve(256);                                              // stop logits
+        for (int i = 13; i < 17; ++i) s->pz_off[i] = pcarve(h);                   // second bank of h_att raw, h_att, h1, h2 (two-chain teacher schedule)
         o_pz = carve(pz_total);
         o_pzbar = carve((size_t)(pz::NSHARD + 64 + 4) * 32 * 4);
     }
@@ -1921,6 +1926,7 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
             return fail(T2_ESTATE, "internal: teacher-forced PreNet operands do not have the persistent decoder's geometry");
         x.x2_all = s->tf_frag; x.x2_stride = (unsigned)(s->tf_stride * 4); x.x2_bytes = (unsigned)((long long)max_steps * s->tf_stride * 4);
         x.y_all = tape ? nullptr : s->y_all;            // the training tape keeps LSTM 2's raw outputs itself (hraw[2])
+        for (int i = 0; i < 4; ++i) x.oB1[i] = s->pz_off[13 + i];
         if (tape) persist_fill_tape(x.tp, tape);
     } else {
         // x1 of step 0 = relu(bias of the first PreNet layer): the go frame is zeros (helpers.py:187-188)
@@ -1929,13 +1935,15 @@ static int persist_decode(t2_state* s, int max_steps, int min_iters, int stop_en
     }
     const size_t lds = persist_lds_bytes(s->B, s->T);
     const dim3 grid(pz::NWG), blk(pz::NT);
-    const int mode = teacher ? (tape ? 2 : 1) : 0;        // pz::decode_kernel's MODE
+    const int mode = teacher ? (m->opt_tf2 ? (tape ? 4 : 3) : (tape ? 2 : 1)) : 0;        // pz::decode_kernel's MODE (3 / 4: two-chain teacher schedule)
     XwgGate gate;
     T2_TRY(gate.begin(m->ctx));
 #define T2_PZ_LAUNCH(MBv) do { \
         if (mode == 0) hipLaunchKernelGGL((pz::decode_kernel<MBv, 0>), grid, blk, lds, st, a, x); \
         else if (mode == 1) hipLaunchKernelGGL((pz::decode_kernel<MBv, 1>), grid, blk, lds, st, a, x); \
-        else hipLaunchKernelGGL((pz::decode_kernel<MBv, 2>), grid, blk, lds, st, a, x); } while (0)
+        else if (mode == 2) hipLaunchKernelGGL((pz::decode_kernel<MBv, 2>), grid, blk, lds, st, a, x); \
+        else if (mode == 3) hipLaunchKernelGGL((pz::decode_kernel<MBv, 3>), grid, blk, lds, st, a, x); \
+        else hipLaunchKernelGGL((pz::decode_kernel<MBv, 4>), grid, blk, lds, st, a, x); } while (0)
     if (s->MB == 1) T2_PZ_LAUNCH(1);
     else if (s->MB == 2) T2_PZ_LAUNCH(2);
     else T2_PZ_LAUNCH(4);

@@ -142,6 +142,21 @@ def test_persistent_teacher_forced_against_oracle_and_launch_schedule(paper, B):
     np.testing.assert_allclose(mel1, _np(mel0), atol=eng.twin_atol[0])
     np.testing.assert_allclose(stop1, _np(stop0), atol=eng.twin_atol[0])
     np.testing.assert_allclose(align1, _np(align0), atol=eng.twin_atol[1])
+    # the two-chain schedule (two hops per step, csrc/persist.h MODE 3: the default) against the four-hop schedule (option tf2 = 0),
+    # and an even step count: the last step's hidden states then live in the second bank and are republished for final_state
+    for steps in (S, S - 1):
+        tgt = target[:, :steps * d.outputs_per_step]
+        got = {}
+        for tf2 in (1, 0):
+            eng.set_option("tf2", tf2)
+            before = eng.get_stat("persist_launches")
+            out = eng.decode_teacher(mem, lens[:B], tgt, teacher_forcing=True)
+            assert eng.get_stat("persist_launches") == before + 1 and eng.get_stat("persist_timeouts") == 0
+            got[tf2] = [_np(o).copy() for o in out] + [_np(eng.decode_final_state(n, B, T)).copy()
+                                                       for n in ("attention_h", "attention_output", "lstm1_h", "lstm2_h", "lstm2_c", "attention")]
+        eng.set_option("tf2", 1)
+        for a1, a0 in zip(got[1], got[0]):                                   # another summation order of the hoisted K ranges
+            np.testing.assert_allclose(a1, a0, atol=max(eng.twin_atol))
 
 
 def test_persistent_decode_after_a_device_side_parameter_refresh():
