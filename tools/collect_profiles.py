@@ -72,7 +72,7 @@ tj[f"{rnd}_persistent_decode_b64"] = entry("tools/b1_run.py B=64", "pz::decode_k
                                            "one launch = 400 decoder steps at B = 64, T_in = 100..140 (bench seed); memory-side counters, Infinity-Cache hits included")
 tj[f"{rnd}_persistent_decode_b1"] = entry("tools/b1_run.py B=1", "pz::decode_kernel<1, 0>", 400, old1.get("algorithmic_bytes_per_step"),
                                           "one launch = 400 decoder steps at B = 1, T_in = 100")
-tj[f"{rnd}_train_forward_b32"] = entry("tools/bwd_stamps.py B=32", "pz::decode_kernel<2, 2>", 400, None, "teacher-forced training forward, 400 steps at B = 32 (tape written)")
+tj[f"{rnd}_train_forward_b32"] = entry("tools/bwd_stamps.py B=32", "pz::decode_kernel<2, 4>", 400, None, "teacher-forced training forward (two-chain schedule), 400 steps at B = 32 (tape written)")
 tj[f"{rnd}_train_backward_b32"] = entry("tools/bwd_stamps.py B=32", "pz::backward_kernel<2>", 400, None, "reverse-time recurrence, 400 steps at B = 32")
 tj["current"] = f"{rnd}_persistent_decode_b64"
 json.dump(tj, open(os.path.join(P, "traffic.json"), "w"), indent=1)
