@@ -544,9 +544,10 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
             if (isAtt && actA) { attention_pre(ta); fresh(); }
             f32x4 bq = {0.f, 0.f, 0.f, 0.f};
             if (isQ) bq = ldw(rQ, l16, (unsigned)((qct * KBH + qks * 8 + wave) * 1024));
+            const unsigned pkx = hop_peek(a.bar);
             f32x4 by[8];
             wload<8>(by, r2, slab2 + (unsigned)(wave * 8 * 1024), l16);
-            if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+            if (!hop_wait(a.bar, 32u * epoch, s_flag, pkx)) { alive = false; break; }
             fresh();
             // ================= Y(i): query + attention of step ta, LSTM 2 of step td =================
             if (isQ && actA) {
@@ -733,9 +734,10 @@ __global__ __launch_bounds__(NT) void decode_kernel(PArgs a, PExtra x) {
                     seg_mma<MB, 8>(acc1, b, xs, oH1_p + (unsigned)(wave * 8 * MB * 1024), l16);
                 }
             }
+            const unsigned pky = hop_peek(a.bar);
             wload<4>(bcA, rA, slabA + (unsigned)((KBX + wave * 4) * 1024), l16);
             wload<4>(bc1, r1, slab1 + (unsigned)((KBH + wave * 4) * 1024), l16);
-            if (!hop_wait(a.bar, 32u * epoch, s_flag)) { alive = false; break; }
+            if (!hop_wait(a.bar, 32u * epoch, s_flag, pky)) { alive = false; break; }
         }
         // final_state reads bank 0: the last step's values once more (they live in registers)
         fresh();
