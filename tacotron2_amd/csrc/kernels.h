@@ -1482,7 +1482,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // division or divergent control flow in the main loop), no split-K, no transposed operand.  Same
 // tiles, same MFMA loop, same summation order and epilogue as the generic kernel (bit-identical results).
 // ------------------------------------------------------------------------------------------------
-template <int MI>      // M sub-tiles of 32 rows per wave: workgroup tile 64 * MI rows x 128 columns (MI = 1 for small M: more workgroups)
+// SPLIT: the k-tiles are dealt to gridDim.z slices (a.splits); a slice writes its raw partial sums to a.part[z][Mtot][N] and
+// conv_split_finish_kernel adds them in slice order and applies the epilogue (few output tiles against a long reduction, e.g.
+// the CBHG bank's data gradient: 70 tiles x 2048 k-tiles).
+template <int MI, bool SPLIT = false>      // M sub-tiles of 32 rows per wave: workgroup tile 64 * MI rows x 128 columns (MI = 1 for small M: more workgroups)
 __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
     constexpr int BM = 64 * MI;
     __shared__ float As[2][CG_BK][BM + 4];
@@ -1490,7 +1493,10 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * CG_BN;
-    const int nk = (a.ktaps * a.Cin) / CG_BK;
+    const int nk_all = (a.ktaps * a.Cin) / CG_BK;
+    const int kper = SPLIT ? (nk_all + a.splits - 1) / a.splits : nk_all;
+    const int kt0 = SPLIT ? (int)blockIdx.z * kper : 0;
+    const int nk = SPLIT ? min(nk_all, kt0 + kper) : nk_all;
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -1516,7 +1522,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
     const float* wcol = a.w + (size_t)b_k0 * a.N + (b_ok ? n_b : 0);
 
     float4 ra[MI], rbv[2];
-    int tap = 0, ci = 0;                          // k-tile kt covers channels [ci, ci + 16) of tap `tap`
+    int tap = (kt0 * CG_BK) / a.Cin, ci = (kt0 * CG_BK) % a.Cin;      // k-tile kt covers channels [ci, ci + 16) of tap `tap`
     auto load_tiles = [&](int kt) {
         const int dt = tap - a.pad_l;
 #pragma unroll
@@ -1548,11 +1554,13 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
         for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(&Bs[buf][b_k0 + p * 8][b_nq * 4]) = rbv[p];
     };
 
-    load_tiles(0);
-    store_tiles(0);
+    if (kt0 < nk) {
+        load_tiles(kt0);
+        store_tiles(kt0 & 1);
+    }
     __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(kt + 1);
 #pragma unroll
@@ -1581,13 +1589,31 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= a.Mtot) continue;
-                float v = acc[i][j][r] * sc + sh;
-                if (a.act == 1) v = fmaxf(v, 0.f);
-                else if (a.act == 2) v = tanhf(v);
-                if (a.res) v += a.res[(size_t)m * a.ldr + n];
-                a.y[(size_t)m * a.ldy + n] = v;
+                if constexpr (SPLIT) {
+                    a.part[((size_t)blockIdx.z * a.Mtot + m) * a.N + n] = acc[i][j][r];
+                } else {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (a.act == 1) v = fmaxf(v, 0.f);
+                    else if (a.act == 2) v = tanhf(v);
+                    if (a.res) v += a.res[(size_t)m * a.ldr + n];
+                    a.y[(size_t)m * a.ldy + n] = v;
+                }
             }
         }
+}
+// y = epilogue(sum_z part[z]) of a split conv_gemm_fast_kernel launch (slice order: deterministic)
+__global__ __launch_bounds__(256) void conv_split_finish_kernel(ConvArgs a) {
+    const long long n_el = (long long)a.Mtot * a.N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / a.N), n = (int)(i - (long long)m * a.N);
+        float s = 0.f;
+        for (int z = 0; z < a.splits; ++z) s += a.part[(size_t)z * n_el + i];
+        float v = s * (a.scale ? a.scale[n] : 1.f) + (a.shift ? a.shift[n] : 0.f);
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        else if (a.act == 2) v = tanhf(v);
+        if (a.res) v += a.res[(size_t)m * a.ldr + n];
+        a.y[(size_t)m * a.ldy + n] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -83,6 +83,8 @@ struct ConvLayer {
                             // w rewrites wt (conv_refresh_wt)
     int pad_l = -1;         // zero positions in front; -1: TF's SAME rule (k - 1) / 2.  The data gradient of an even-width SAME
                             // convolution is the flipped kernel with k - 1 - (k - 1) / 2 in front
+    float* part = nullptr;  // optional workspace of part_floats floats: lets launch_conv split a long reduction with few output
+    size_t part_floats = 0; // tiles over gridDim.z (conv_gemm_fast_kernel<1, true> + conv_split_finish_kernel)
 };
 
 struct t2_model {
@@ -727,6 +729,21 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
         }
     } else if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic) {
         // fewer than ~3 workgroups of 128 rows per CU: 64-row tiles (twice the workgroups) keep more waves per SIMD
+        const long long t64 = (long long)grid.x * ceil_div(Mtot, 64);
+        const int nk = L.k * L.cin / CG_BK;
+        if (L.part != nullptr && 2 * t64 <= m->n_cu && nk >= 128) {
+            // few output tiles against a long reduction: the k-tiles over gridDim.z slices, partial sums added in slice order
+            int z = (int)std::min<long long>({16LL, (4LL * m->n_cu + t64 - 1) / t64, (long long)nk / 32,
+                                              (long long)(L.part_floats / ((size_t)Mtot * L.cout))});
+            if (z >= 2) {
+                a.splits = z; a.part = L.part;
+                grid.y = ceil_div(Mtot, 64); grid.z = z;
+                hipLaunchKernelGGL((conv_gemm_fast_kernel<1, true>), grid, dim3(256), 0, m->ctx->stream, a);
+                hipLaunchKernelGGL(conv_split_finish_kernel, dim3(std::min(2048, ceil_div(Mtot * L.cout, 256))), dim3(256), 0, m->ctx->stream, a);
+                HIP_TRY(hipGetLastError());
+                return T2_OK;
+            }
+        }
         if ((long long)grid.x * grid.y < 3LL * m->n_cu || m->opt_conv_mi == 1) {
             grid.y = ceil_div(Mtot, 64);
             hipLaunchKernelGGL(conv_gemm_fast_kernel<1>, grid, dim3(256), 0, m->ctx->stream, a);

@@ -132,7 +132,7 @@ struct t2v1_ptrainer {
     // EncoderV1 only: token ids, embedded input, PreNet outputs (after relu and dropout), their gradients, transposed PreNet kernels,
     // the flipped unified bank kernel and the gradient of the CBHG's input
     int* ids = nullptr;
-    float *emb = nullptr, *pre[2] = {nullptr, nullptr}, *dpre[2] = {nullptr, nullptr}, *wpreT[2] = {nullptr, nullptr}, *wbankF = nullptr, *dx0 = nullptr;
+    float *emb = nullptr, *pre[2] = {nullptr, nullptr}, *dpre[2] = {nullptr, nullptr}, *wpreT[2] = {nullptr, nullptr}, *wbankF = nullptr, *dx0 = nullptr, *dxpart = nullptr;
     float drop_rate = 0.f;
     uint32_t seed = 0;
     bool have_ids = false;               // the last forward looked the input up in the table (its gradient goes to the table)
@@ -198,7 +198,7 @@ static int cbhg_trainer_create(t2v1_model* m, int which, int B, int T, t2v1_ptra
     if (which == 0) {
         const size_t E0 = m->d.embedding_dim, U0 = m->d.enc_prenet_units[0], U1 = m->d.enc_prenet_units[1];
         want(&tr->emb, M * E0); want(&tr->pre[0], M * U0); want(&tr->pre[1], M * U1); want(&tr->dpre[0], M * std::max(U0, E0)); want(&tr->dpre[1], M * U1);
-        want(&tr->wpreT[0], E0 * U0); want(&tr->wpreT[1], U0 * U1); want(&tr->wbankF, (size_t)c.K * cin * KC); want(&tr->dx0, M * cin);
+        want(&tr->wpreT[0], E0 * U0); want(&tr->wpreT[1], U0 * U1); want(&tr->wbankF, (size_t)c.K * cin * KC); want(&tr->dx0, M * cin); want(&tr->dxpart, M * cin * 16);
         o_ids = cv.take(M * 4);
     }
     const size_t o_lens = cv.take((size_t)B * 4);
@@ -575,6 +575,7 @@ static int cbhg_train_backward_impl(t2v1_ptrainer* tr, float* flat_grads, bool w
         hipLaunchKernelGGL(conv_flip_kernel, pt_grid((long long)K * cin * KC), dim3(256), 0, st, tr->wbankF, tr->wbank, K, cin, KC);
         ConvLayer L{};
         L.w = tr->wbankF; L.k = K; L.cin = KC; L.cout = cin; L.pad_l = K - 1 - (K - 1) / 2;
+        L.part = tr->dxpart; L.part_floats = (size_t)M * cin * 16;       // 70 output tiles x 2048 k-tiles at the reference sizes: split over gridDim.z
         T2_TRY(launch_conv(b, L, tr->dkc_a, KC, tr->dx0, cin, M, T, 0, d80, P2));
     }
     HIP_TRY(hipGetLastError());
