@@ -265,6 +265,7 @@ static int cbhg_train_forward_impl(t2v1_ptrainer* tr, const float* x) {
     L = ConvLayer{}; L.w = const_cast<float*>(W(p + "/proj1/kernel")); L.k = 3; L.cin = KC; L.cout = P1;
     const float *g1 = W(p + "/proj1/batch_normalization/gamma"), *b1 = W(p + "/proj1/batch_normalization/beta");
     if (err != T2_OK) return err;
+    if (tr->dxpart) { L.part = tr->dxpart; L.part_floats = (size_t)M * tr->c->cin * 16; }     // encoder sizes: 70 output tiles x 384 k-tiles
     T2_TRY(launch_conv(b, L, tr->pooled, KC, tr->p1raw, P1, M, T, 0, nullptr, 0));
     T2_TRY(pt_bn_forward(tr, tr->p1raw, 1, P1, g1, b1, 1, tr->p1));
     L = ConvLayer{}; L.w = const_cast<float*>(W(p + "/proj2/kernel")); L.k = 3; L.cin = P1; L.cout = P2;
