@@ -11,6 +11,7 @@ struct GruPacked {
 
 struct CbhgW {
     std::vector<ConvLayer> bank;
+    ConvLayer bank_u;                     // the K bank kernels as ONE convolution of width K (zero-padded taps, columns (k - 1) C + c): v1_bank_unify
     ConvLayer proj1, proj2, adj;
     bool has_adj = false;
     std::vector<ConvLayer> highway;       // one GEMM per layer: [Wh | Wt], shift = [bh | bt]
@@ -35,6 +36,7 @@ struct t2v1_model {
     ConvLayer dec_prenet_plain[2], proj_plain;   // teacher-forced decodes: PreNets and projections of all steps as batched GEMMs
     int opt_tfbatch = 1;
     int opt_gruseq = 1;                   // CBHG BiGRU of 128 units per direction as one persistent launch (gru_seq_kernel)
+    int opt_bank_unified = 1;             // CBHG inference: the conv bank as one width-K convolution when the batch is short
     int opt_skinny = 1;                   // training recurrence: per-step products on v1d_skinny_gemm_kernel (0: conv_gemm tiles)
     int opt_train_persist = 1;            // decoder trainer: each recurrence as one persistent launch (v1_dec_train.h)
     long long n_train_persist = 0;        // such launches so far (t2v1_model_get_stat "train_persist_launches")
@@ -197,12 +199,14 @@ extern "C" int t2v1_model_set_weight(t2v1_model* m, const char* name, const floa
 }
 
 static void v1_state_free(t2v1_state* s);
+static int v1_bank_unify(t2_model* b, CbhgW* c);       // v1_train.h (next to the trainer's bank kernels)
 
 extern "C" int t2v1_model_set_option(t2v1_model* m, const char* name, int value) {
     if (!m || !name) return fail(T2_EINVAL, "null argument");
     if (!strcmp(name, "graph")) m->opt_graph = value;
     else if (!strcmp(name, "chunk")) { if (value < 1 || value > 64) return fail(T2_EINVAL, "chunk 1..64"); m->opt_chunk = value; }
     else if (!strcmp(name, "skinny")) m->opt_skinny = value;
+    else if (!strcmp(name, "bank_unified")) m->opt_bank_unified = value;
     else if (!strcmp(name, "tf_persist")) m->opt_tf_persist = value;
     else if (!strcmp(name, "train_persist")) { m->opt_train_persist = value; m->base.persist_holdoff = 0; }
     else if (!strcmp(name, "inject_timeout")) m->base.opt_inject_timeout = value;
@@ -238,6 +242,8 @@ extern "C" int t2v1_model_finalize(t2v1_model* m) {
     T2_TRY(v1_make_cbhg(b, &m->post_cbhg, "v1/postnet/cbhg", d.num_mels, d.post_cbhg_out_units, d.post_conv_channels,
                         d.post_max_filter_width, d.post_proj1_channels, d.post_proj2_channels, d.post_num_highway));
     T2_TRY(v1_dense_conv(b, &m->post_linear, "v1/postnet/linear", d.post_cbhg_out_units, d.num_freq, true));
+    T2_TRY(v1_bank_unify(b, &m->enc_cbhg));
+    T2_TRY(v1_bank_unify(b, &m->post_cbhg));
     const int E = d.cbhg_out_units, A = d.attention_out_units, D = d.decoder_out_units, M = d.num_mels, r = d.outputs_per_step;
     const int P0 = d.dec_prenet_units[0], P1 = d.dec_prenet_units[1];
     T2_TRY(v1_dense_conv(b, &m->memory_layer, "v1/attention/memory_layer", E, A, false));
@@ -405,6 +411,11 @@ static int cbhg_forward(t2v1_model* m, const CbhgW& c, const float* x, int B, in
     int* ctl = (int*)(ws + cv.take(64));
     HIP_TRY(hipMemsetAsync(ws + zero_from, 0, cv.off - zero_from, st));
     // conv bank, concatenated along channels (modules.py:206)
+    // a short batch leaves each bank kernel (N = C columns) a fraction of the chip: the K kernels as ONE convolution of width K then
+    // (zero-padded taps: ~2x the products, K x the workgroups); long batches keep the K exact convolutions
+    if (c.bank_u.w != nullptr && m->opt_bank_unified && ceil_div(Mtot, 64) * ceil_div(c.C, CG_BN) * 2 <= b->n_cu)
+        T2_TRY(launch_conv(b, c.bank_u, x, c.cin, bank, KC, Mtot, T, 1, nullptr, 0));
+    else
     for (int k = 1; k <= c.K; ++k)
         T2_TRY(launch_conv(b, c.bank[k - 1], x, c.cin, bank + (size_t)(k - 1) * c.C, KC, Mtot, T, 1, nullptr, 0));
     {

@@ -44,6 +44,29 @@ __global__ void bank_vec_gather_kernel(BankPtrs src, float* __restrict__ dst, in
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K * C) dst[i] = src.p[i / C][i % C];
 }
+// The inference CBHG's unified bank layer (CbhgW::bank_u) from its K folded layers: kernel, scale, shift (+ the transposed copy
+// of the fast path).  Called at finalize and after a trainer's export.
+static int v1_bank_unify(t2_model* b, CbhgW* c) {
+    const int K = c->K, cin = c->cin, C = c->C, KC = K * C;
+    if (K > T2V1_MAX_BANK) return T2_OK;
+    hipStream_t st = b->ctx->stream;
+    ConvLayer& U = c->bank_u;
+    if (U.w == nullptr) {
+        U.k = K; U.cin = cin; U.cout = KC;
+        T2_TRY(dev_alloc(b, (void**)&U.w, (size_t)K * cin * KC * 4));
+        T2_TRY(dev_alloc(b, (void**)&U.scale, (size_t)KC * 4));
+        T2_TRY(dev_alloc(b, (void**)&U.shift, (size_t)KC * 4));
+        if (cin % 16 == 0) T2_TRY(dev_alloc(b, (void**)&U.wt, (size_t)K * cin * KC * 4));
+    }
+    BankPtrs w{}, sc{}, sh{};
+    for (int k = 0; k < K; ++k) { w.p[k] = c->bank[k].w; sc.p[k] = c->bank[k].scale; sh.p[k] = c->bank[k].shift; }
+    hipLaunchKernelGGL(bank_pack_kernel, dim3((unsigned)std::min<long long>(4096, ((long long)K * cin * KC + 255) / 256)), dim3(256), 0, st, w, U.w, K, cin, C);
+    hipLaunchKernelGGL(bank_vec_gather_kernel, dim3(ceil_div(KC, 256)), dim3(256), 0, st, sc, U.scale, K, C);
+    hipLaunchKernelGGL(bank_vec_gather_kernel, dim3(ceil_div(KC, 256)), dim3(256), 0, st, sh, U.shift, K, C);
+    conv_refresh_wt(st, U);
+    HIP_TRY(hipGetLastError());
+    return T2_OK;
+}
 __global__ void bank_vec_scatter_kernel(const float* __restrict__ src, BankDst dst, int K, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K * C) dst.p[i / C][i % C] = src[i];
@@ -635,6 +658,7 @@ extern "C" int t2v1_postnet_trainer_export(t2v1_ptrainer* tr, const float* flat_
         return T2_OK;
     };
     for (int k = 1; k <= c.K; ++k) T2_TRY(conv(c.bank[k - 1], p + "/conv1d_K" + std::to_string(k)));
+    T2_TRY(v1_bank_unify(&m->base, &c));
     T2_TRY(conv(c.proj1, p + "/proj1"));
     T2_TRY(conv(c.proj2, p + "/proj2"));
     auto cp2 = [&](const float* src, int lds, float* dst, int ldd, int rows, int cols) {

@@ -34,3 +34,11 @@ print("v1 postnet B=%d T=%d: %.1f ms -> %.0f spectrogram frames/s" % (B, T_out, 
 dt, _ = timed(lambda: eng.encode(ids, None))
 print("v1 encoder B=%d T_in=%d: %.2f ms" % (B, T_in, dt * 1e3))
 eng.close()
+# free-running decode (PREDICT): stop rule held off by the stop bias, 400 decoder steps
+w = init_weights_v1(d, 1234 + 5)
+w["v1/decoder/stop_token_projection/bias"] = np.array([-1e3], np.float32)
+eng = EngineV1(d, w)
+mem = eng.encode(ids, None)
+dt, out = timed(lambda: eng.decode_free(mem, lens, max_iters=400, min_iters=10))
+print("v1 free-running decode B=%d: %.1f ms for %d steps = %.1f us per decoder step" % (B, dt * 1e3, out[3], dt * 1e6 / max(out[3], 1)))
+eng.close()
