@@ -712,6 +712,23 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
     a.vec_a = (L.cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0);
     a.vec_b = (L.cout % 4 == 0) && (((uintptr_t)L.w) % 16 == 0);
     dim3 grid(ceil_div(L.cout, CG_BN), ceil_div(Mtot, CG_BM));
+    if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic) {
+        const long long t64 = (long long)grid.x * ceil_div(Mtot, 64);
+        const int nk = L.k * L.cin / CG_BK;
+        if (L.part != nullptr && 2 * t64 <= m->n_cu && nk >= 128) {
+            // few output tiles against a long reduction: the k-tiles over gridDim.z slices, partial sums added in slice order
+            int z = (int)std::min<long long>({16LL, (4LL * m->n_cu + t64 - 1) / t64, (long long)nk / 32,
+                                              (long long)(L.part_floats / ((size_t)Mtot * L.cout))});
+            if (z >= 2) {
+                a.splits = z; a.part = L.part;
+                grid.y = ceil_div(Mtot, 64); grid.z = z;
+                hipLaunchKernelGGL((conv_gemm_fast_kernel<1, true>), grid, dim3(256), 0, m->ctx->stream, a);
+                hipLaunchKernelGGL(conv_split_finish_kernel, dim3(std::min(2048, ceil_div(Mtot * L.cout, 256))), dim3(256), 0, m->ctx->stream, a);
+                HIP_TRY(hipGetLastError());
+                return T2_OK;
+            }
+        }
+    }
     if (a.vec_a && L.wt != nullptr && L.cin % CG_BK == 0 && !m->opt_conv_generic && m->opt_conv_kt) {
         // K-contiguous LDS tiles on the transposed kernel.  Tile height: 64 rows while 128-row tiles would leave fewer than ~3
         // workgroups per CU; otherwise 128 or 160 rows, whichever leaves the fuller last round on the CUs
@@ -729,21 +746,6 @@ static int launch_conv(t2_model* m, const ConvLayer& L, const float* x, int ldx,
         }
     } else if (a.vec_a && a.vec_b && L.cin % CG_BK == 0 && !m->opt_conv_generic) {
         // fewer than ~3 workgroups of 128 rows per CU: 64-row tiles (twice the workgroups) keep more waves per SIMD
-        const long long t64 = (long long)grid.x * ceil_div(Mtot, 64);
-        const int nk = L.k * L.cin / CG_BK;
-        if (L.part != nullptr && 2 * t64 <= m->n_cu && nk >= 128) {
-            // few output tiles against a long reduction: the k-tiles over gridDim.z slices, partial sums added in slice order
-            int z = (int)std::min<long long>({16LL, (4LL * m->n_cu + t64 - 1) / t64, (long long)nk / 32,
-                                              (long long)(L.part_floats / ((size_t)Mtot * L.cout))});
-            if (z >= 2) {
-                a.splits = z; a.part = L.part;
-                grid.y = ceil_div(Mtot, 64); grid.z = z;
-                hipLaunchKernelGGL((conv_gemm_fast_kernel<1, true>), grid, dim3(256), 0, m->ctx->stream, a);
-                hipLaunchKernelGGL(conv_split_finish_kernel, dim3(std::min(2048, ceil_div(Mtot * L.cout, 256))), dim3(256), 0, m->ctx->stream, a);
-                HIP_TRY(hipGetLastError());
-                return T2_OK;
-            }
-        }
         if ((long long)grid.x * grid.y < 3LL * m->n_cu || m->opt_conv_mi == 1) {
             grid.y = ceil_div(Mtot, 64);
             hipLaunchKernelGGL(conv_gemm_fast_kernel<1>, grid, dim3(256), 0, m->ctx->stream, a);

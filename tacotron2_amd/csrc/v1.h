@@ -372,11 +372,15 @@ struct Carver {
     size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; }
 };
 
+// split-K workspace of the first projection (launch_conv splits only when the output tiles fill less than half of a 256-CU chip)
+static size_t cbhg_p1part_floats(const CbhgW& c, size_t Mtot) {
+    return (ceil_div((long long)Mtot, 64) * ceil_div(c.P1, CG_BN) * 2 <= 256) ? Mtot * c.P1 * 16 : 0;
+}
 static size_t cbhg_ws_bytes(const CbhgW& c, int B, int T) {
     const int MB = mb_for(B);
     const size_t Mtot = (size_t)B * T;
     Carver cv;
-    cv.take(Mtot * c.K * c.C * 4); cv.take(Mtot * c.K * c.C * 4); cv.take(Mtot * c.P1 * 4); cv.take(Mtot * c.P2 * 4);
+    cv.take(Mtot * c.K * c.C * 4); cv.take(Mtot * c.K * c.C * 4); cv.take(Mtot * c.P1 * 4); cv.take(cbhg_p1part_floats(c, Mtot) * 4); cv.take(Mtot * c.P2 * 4);
     cv.take(Mtot * c.half * 4); cv.take(Mtot * c.half * 4); cv.take(Mtot * 2 * c.half * 4);
     const int KPh = pad16(c.half);
     cv.take(2 * (size_t)T * MB * 16 * KPh * 4);                 // per-step inputs, both directions
@@ -397,6 +401,8 @@ static int cbhg_forward(t2v1_model* m, const CbhgW& c, const float* x, int B, in
     float* bank = (float*)(ws + cv.take((size_t)Mtot * KC * 4));
     float* pooled = (float*)(ws + cv.take((size_t)Mtot * KC * 4));
     float* p1 = (float*)(ws + cv.take((size_t)Mtot * c.P1 * 4));
+    const size_t p1part_floats = cbhg_p1part_floats(c, (size_t)Mtot);
+    float* p1part = (float*)(ws + cv.take(p1part_floats * 4));
     float* p2 = (float*)(ws + cv.take((size_t)Mtot * c.P2 * 4));
     float* hwa = (float*)(ws + cv.take((size_t)Mtot * half * 4));
     float* hwb = (float*)(ws + cv.take((size_t)Mtot * half * 4));
@@ -423,7 +429,11 @@ static int cbhg_forward(t2v1_model* m, const CbhgW& c, const float* x, int B, in
         hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, st, bank, pooled,
                            (long long)Mtot, T, KC);
     }
-    T2_TRY(launch_conv(b, c.proj1, pooled, KC, p1, c.P1, Mtot, T, 1, nullptr, 0));
+    {   // few output tiles (N = P1) against K = 3 K C: split over gridDim.z where the batch is short (launch_conv decides)
+        ConvLayer L = c.proj1;
+        if (p1part_floats) { L.part = p1part; L.part_floats = p1part_floats; }
+        T2_TRY(launch_conv(b, L, pooled, KC, p1, c.P1, Mtot, T, 1, nullptr, 0));
+    }
     T2_TRY(launch_conv(b, c.proj2, p1, c.P1, p2, c.P2, Mtot, T, 0, x, c.cin));          // + residual (modules.py:214)
     const float* cur = p2;
     float* nxt = hwa;
